@@ -1,0 +1,613 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference (container-only).
+
+Run here (the reference never travels to the GPU box; only the .npz files this script writes do):
+
+    PYTHONPATH=/root/reference/src python tests/golden/make_golden.py
+
+What is stored is DATA ONLY: inputs, the noise draws consumed, and the outputs the reference's own
+functions returned for them. Reference symbols exercised (file:line under
+/root/reference/src/diffusion_for_multi_scale_molecular_dynamics/):
+
+  schedule_*.npz      NoiseScheduler.get_all_sampling_parameters      noise_schedulers/noise_scheduler.py:112-378
+  p1_coordinates.npz  LangevinGenerator._relative_coordinates_update  generators/langevin_generator.py:155-201
+                      map_relative_coordinates_to_unit_cell            utils/basis_transformations.py:95-119
+  p2_atom_types.npz   LangevinGenerator._atom_types_update             generators/langevin_generator.py:247-439
+  p3_lattice.npz      LangevinGenerator._lattice_parameters_update     generators/langevin_generator.py:441-490
+  noisers.npz         RelativeCoordinatesNoiser / AtomTypesNoiser      noisers/*.py
+  neighbors.npz       get_periodic_adjacency_information, get_edges_with_radial_cutoff
+                                                                      utils/neighbors.py:36-224, models/egnn_utils.py:107-144
+  traj_*.npz          LangevinGenerator.sample / ConstrainedLangevinGenerator.sample with record_samples=True
+                                                                      generators/*.py
+
+Third-party packages the reference imports but this image lacks (pykeops, e3nn, torch_geometric) are stubbed
+below *for this script only*; the KeOps LazyTensor stand-in is a dense torch evaluation of the same symbolic
+expression. torch.rand / torch.randn are wrapped so every draw the reference consumes is
+recorded in order: torch's CPU randn stream differs in the last bits between AVX2 and AVX512 hosts, so the
+fixtures carry the draws themselves rather than a seed.
+"""
+import itertools
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# --------------------------------------------------------------------------------------------------------------
+# container-only stubs for absent third-party modules
+# --------------------------------------------------------------------------------------------------------------
+if not hasattr(np, "NaN"):
+    np.NaN = np.nan
+
+
+class _Lazy:
+    """Dense stand-in for pykeops.torch.LazyTensor (only what utils/neighbors.py:155-186 uses)."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __sub__(self, o):
+        return _Lazy(self.t - o.t)
+
+    def __pow__(self, p):
+        return _Lazy(self.t ** p)
+
+    def sum(self, dim):
+        return _Lazy(self.t.sum(dim=dim))
+
+    def __le__(self, v):
+        return _Lazy((self.t <= v).to(torch.float32))
+
+    def sum_reduction(self, dim):
+        return self.t.sum(dim=dim, keepdim=True).transpose(dim, -1).squeeze(dim) if False else self.t.sum(dim=dim).unsqueeze(-1)
+
+    def Kmin_argKmin(self, K, dim):
+        v, i = torch.topk(self.t, K, dim=dim, largest=False)
+        return v, i
+
+
+def _install_stubs():
+    pk = types.ModuleType("pykeops")
+    pkt = types.ModuleType("pykeops.torch")
+    pkt.LazyTensor = _Lazy
+    pk.torch = pkt
+    sys.modules["pykeops"] = pk
+    sys.modules["pykeops.torch"] = pkt
+    e3 = types.ModuleType("e3nn")
+    o3 = types.ModuleType("e3nn.o3")
+    o3.Irreps = object
+    e3.o3 = o3
+    sys.modules["e3nn"] = e3
+    sys.modules["e3nn.o3"] = o3
+    tg = types.ModuleType("torch_geometric")
+    tgd = types.ModuleType("torch_geometric.data")
+    tgd.Data = object
+    tg.data = tgd
+    sys.modules["torch_geometric"] = tg
+    sys.modules["torch_geometric.data"] = tgd
+
+
+_install_stubs()
+
+from diffusion_for_multi_scale_molecular_dynamics.generators.constrained_langevin_generator import \
+    ConstrainedLangevinGenerator  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics.generators.langevin_generator import \
+    LangevinGenerator  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics.generators.predictor_corrector_axl_generator import \
+    PredictorCorrectorSamplingParameters  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics.generators.sampling_constraint import \
+    SamplingConstraint  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics.models.egnn_utils import \
+    get_edges_with_radial_cutoff  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics.models.score_networks.egnn_score_network import (  # noqa: E402
+    EGNNScoreNetwork, EGNNScoreNetworkParameters)
+from diffusion_for_multi_scale_molecular_dynamics.models.score_networks.mlp_score_network import (  # noqa: E402
+    MLPScoreNetwork, MLPScoreNetworkParameters)
+from diffusion_for_multi_scale_molecular_dynamics.models.score_networks.score_network import (  # noqa: E402
+    ScoreNetwork, ScoreNetworkParameters)
+from diffusion_for_multi_scale_molecular_dynamics.namespace import (  # noqa: E402
+    AXL, CARTESIAN_FORCES, NOISE, NOISY_AXL_COMPOSITION, TIME)
+from diffusion_for_multi_scale_molecular_dynamics.noise_schedulers.noise_parameters import \
+    NoiseParameters  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics.noise_schedulers.noise_scheduler import \
+    NoiseScheduler  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics.noisers.atom_types_noiser import \
+    AtomTypesNoiser  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics.noisers.relative_coordinates_noiser import \
+    RelativeCoordinatesNoiser  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics.sampling.diffusion_sampling import \
+    create_batch_of_samples  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics.utils.d3pm_utils import \
+    class_index_to_onehot  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics.utils.neighbors import \
+    get_periodic_adjacency_information  # noqa: E402
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    arrays["torch_version"] = np.array(torch.__version__)
+    arrays["cpu_capability"] = np.array(torch.backends.cpu.get_cpu_capability())
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------------------------------------------
+# RNG recorder: wraps torch.rand / torch.randn for the duration of a reference call
+# --------------------------------------------------------------------------------------------------------------
+class DrawRecorder:
+    def __init__(self):
+        self.kinds = []   # 0 = rand, 1 = randn
+        self.shapes = []
+        self.values = []
+
+    def __enter__(self):
+        self._rand, self._randn = torch.rand, torch.randn
+        rec = self
+
+        def rand(*size, **kw):
+            out = rec._rand(*size, **kw)
+            rec.kinds.append(0)
+            rec.shapes.append(tuple(out.shape))
+            rec.values.append(_np(out).ravel().copy())
+            return out
+
+        def randn(*size, **kw):
+            out = rec._randn(*size, **kw)
+            rec.kinds.append(1)
+            rec.shapes.append(tuple(out.shape))
+            rec.values.append(_np(out).ravel().copy())
+            return out
+
+        torch.rand, torch.randn = rand, randn
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.randn = self._rand, self._randn
+
+    def pack(self):
+        shapes = np.full((len(self.shapes), 4), -1, dtype=np.int64)
+        for i, s in enumerate(self.shapes):
+            shapes[i, : len(s)] = s
+        offsets = np.cumsum([0] + [v.size for v in self.values]).astype(np.int64)
+        flat = np.concatenate(self.values).astype(np.float32) if self.values else np.zeros(0, np.float32)
+        return dict(draw_kinds=np.array(self.kinds, dtype=np.int64), draw_shapes=shapes,
+                    draw_offsets=offsets, draw_values=flat)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# S1: schedule tables
+# --------------------------------------------------------------------------------------------------------------
+def golden_schedules():
+    cases = {
+        "T3_default": (dict(total_time_steps=3), 2),
+        "T10_default": (dict(total_time_steps=10), 3),
+        "T17_default": (dict(total_time_steps=17), 5),
+        "c1_T100_exp": (dict(total_time_steps=100, sigma_min=1e-4, sigma_max=0.25, schedule_type="exponential"), 2),
+        "c2_T1000_exp": (dict(total_time_steps=1000, sigma_min=1e-4, sigma_max=0.25, schedule_type="exponential"), 2),
+        "c3_T1000_lin": (dict(total_time_steps=1000, sigma_min=1e-4, sigma_max=0.2, schedule_type="linear",
+                              corrector_step_epsilon=2.5e-8), 2),
+        "c4_T1000_lin": (dict(total_time_steps=1000, sigma_min=1e-4, sigma_max=0.2, schedule_type="linear",
+                              corrector_step_epsilon=2.5e-8), 3),
+        "c5_T2000_lin": (dict(total_time_steps=2000, sigma_min=1e-4, sigma_max=0.2, schedule_type="linear",
+                              corrector_step_epsilon=2.5e-8), 2),
+        "test_T10": (dict(total_time_steps=10, time_delta=0.1, sigma_min=0.15, corrector_step_epsilon=0.25), 5),
+    }
+    out = {}
+    names = []
+    for name, (kw, num_classes) in cases.items():
+        p = NoiseParameters(**kw)
+        noise, ld = NoiseScheduler(p, num_classes=num_classes).get_all_sampling_parameters()
+        names.append(name)
+        out[f"{name}/params"] = np.array([p.total_time_steps, 0 if p.schedule_type == "exponential" else 1,
+                                          p.time_delta, p.sigma_min, p.sigma_max, p.corrector_step_epsilon,
+                                          num_classes], dtype=np.float64)
+        for k in ["time", "sigma", "sigma_squared", "g", "g_squared", "beta", "alpha_bar", "q_matrix",
+                  "q_bar_matrix", "q_bar_tm1_matrix"]:
+            out[f"{name}/{k}"] = _np(getattr(noise, k))
+        out[f"{name}/epsilon"] = _np(ld.epsilon)
+        out[f"{name}/sqrt_2_epsilon"] = _np(ld.sqrt_2_epsilon)
+    out["names"] = np.array(names)
+    save("schedules.npz", **out)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# helpers to build a generator whose noise draws are pinned
+# --------------------------------------------------------------------------------------------------------------
+class FakeAXLNetwork(ScoreNetwork):
+    """Same behaviour as the reference tests' fake network (tests/generators/conftest.py:14-26): echo the input."""
+
+    def _forward_unchecked(self, batch, conditional=False):
+        return AXL(A=class_index_to_onehot(batch[NOISY_AXL_COMPOSITION].A, num_classes=self.num_atom_types + 1),
+                   X=batch[NOISY_AXL_COMPOSITION].X, L=batch[NOISY_AXL_COMPOSITION].L)
+
+
+def make_generator(T, N, num_atom_types, M=1, greedy=True, one=True, in_corr=False, eps=1e-8, fixed=True,
+                   cell=None, d=3, noise_kw=None, net=None, record=False, constraint=None):
+    nkw = dict(total_time_steps=T)
+    nkw.update(noise_kw or {})
+    noise_parameters = NoiseParameters(**nkw)
+    skw = dict(number_of_corrector_steps=M, number_of_atoms=N, number_of_samples=1, spatial_dimension=d,
+               num_atom_types=num_atom_types, one_atom_type_transition_per_step=one,
+               atom_type_greedy_sampling=greedy, atom_type_transition_in_corrector=in_corr, small_epsilon=eps,
+               record_samples=record, record_samples_corrector_steps=record)
+    if fixed:
+        skw.update(use_fixed_lattice_parameters=True, cell_dimensions=cell or [5.43] * d)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sampling_parameters = PredictorCorrectorSamplingParameters(**skw)
+    if net is None:
+        net = FakeAXLNetwork(ScoreNetworkParameters(architecture="dummy", spatial_dimension=d,
+                                                    num_atom_types=num_atom_types))
+    if constraint is not None:
+        gen = ConstrainedLangevinGenerator(noise_parameters=noise_parameters, sampling_parameters=sampling_parameters,
+                                           axl_network=net, sampling_constraints=constraint)
+    else:
+        gen = LangevinGenerator(noise_parameters=noise_parameters, sampling_parameters=sampling_parameters,
+                                axl_network=net)
+    return gen, noise_parameters, sampling_parameters
+
+
+# --------------------------------------------------------------------------------------------------------------
+# P1 / P3
+# --------------------------------------------------------------------------------------------------------------
+def golden_p1_p3():
+    g = torch.Generator().manual_seed(101)
+    gen, _, _ = make_generator(T=10, N=8, num_atom_types=1)
+    out = {}
+    B, N, d = 6, 8, 3
+    x = torch.rand(B, N, d, generator=g)
+    # edge cases of the wrap (tests/utils/test_basis_transformations.py:76-110)
+    x[0, 0] = torch.tensor([0.0, 1.0 - 2.0 ** -24, 0.5])
+    s = torch.randn(B, N, d, generator=g) * 3.0
+    z = torch.randn(B, N, d, generator=g)
+    scal = []
+    outs = []
+    for (w, n, sig) in [(0.01, 0.1, 0.05), (2.5e-5, 7.07e-3, 1e-3), (0.3, 0.55, 0.5), (1e-9, 4.5e-5, 1e-4),
+                        (0.0, 0.0, 1.0)]:
+        w_, n_, sig_ = torch.tensor(w), torch.tensor(n), torch.tensor(sig)
+        xo = gen._relative_coordinates_update(x.clone(), s, sig_, w_, n_, z)
+        scal.append([_np(w_), _np(n_), _np(sig_)])
+        outs.append(_np(xo))
+    out["x"], out["s"], out["z"] = _np(x), _np(s), _np(z)
+    out["scalars"] = np.array(scal, dtype=np.float32)
+    out["x_out"] = np.stack(outs)
+    # pure wrap edge cases
+    e = torch.tensor([-1e-8, -1e-12, 1.0, 2.0, -1.0, 1.0 - 2.0 ** -24, -0.25, 1.75, 3.999999, -2.0000002, 0.0,
+                      -0.0, 1e-30, -1e-30, 5e-8, -5e-8, -3e-8, 123.456, -123.456], dtype=torch.float32)
+    from diffusion_for_multi_scale_molecular_dynamics.utils.basis_transformations import \
+        map_relative_coordinates_to_unit_cell
+    out["wrap_in"] = _np(e)
+    out["wrap_out"] = _np(map_relative_coordinates_to_unit_cell(e.clone()))
+    save("p1_coordinates.npz", **out)
+
+    # P3 lattice (not fixed)
+    gen, _, _ = make_generator(T=10, N=8, num_atom_types=1, fixed=False)
+    lat = torch.randn(B, 6, generator=g) + 5.0
+    sl = torch.randn(B, 6, generator=g)
+    zl = torch.randn(B, 6, generator=g)
+    res = []
+    scal = []
+    for (w, n, sig) in [(0.01, 0.1, 0.05), (2.5e-5, 7.07e-3, 1e-3)]:
+        sig_t = torch.tensor(sig)
+        sigma_n = sig_t / (N ** (1 / d))  # langevin_generator.py:567-569
+        lo = gen._lattice_parameters_update(lat, sl, sigma_n, torch.tensor(w), torch.tensor(n), zl)
+        res.append(_np(lo))
+        scal.append([w, n, sig, float(sigma_n)])
+    save("p3_lattice.npz", l=_np(lat), s=_np(sl), z=_np(zl), scalars=np.array(scal, dtype=np.float32),
+         l_out=np.stack(res), n_atoms=np.array(N))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# P2
+# --------------------------------------------------------------------------------------------------------------
+def golden_p2():
+    g = torch.Generator().manual_seed(202)
+    out = {}
+    case_names = []
+    B, N = 12, 8
+    T = 10
+    for num_atom_types in (1, 2, 4):
+        C = num_atom_types + 1
+        for greedy, one in itertools.product((False, True), (False, True)):
+            for idx in (0, 4, 9):  # idx = index_i - 1 (0 is the last denoising step)
+                gen, _, _ = make_generator(T=T, N=N, num_atom_types=num_atom_types, greedy=greedy, one=one)
+                logits = torch.randn(B, N, C, generator=g) * 2.0
+                logits[..., -1] = -torch.inf
+                a = torch.randint(0, C, (B, N), generator=g)
+                a[0] = C - 1  # fully masked sample
+                a[1] = C - 1
+                a[2, ::2] = C - 1
+                a[3] = torch.randint(0, num_atom_types, (N,), generator=g)  # no mask at all
+                if idx == T - 1:
+                    a[:] = C - 1
+                u_g = torch.rand(B, N, C, generator=g)
+                gumbel = -torch.log(-torch.log(u_g.clip(min=gen.small_epsilon)))
+                u_b = torch.rand(B, N, generator=g)
+                gen._draw_gumbel_sample = lambda n, gumbel=gumbel: gumbel.clone()
+                gen._draw_binary_sample = lambda n, u_b=u_b: u_b.clone()
+                gen.record_atom_type_update = True
+                from diffusion_for_multi_scale_molecular_dynamics.utils.sample_trajectory import SampleTrajectory
+                gen.sample_trajectory_recorder = SampleTrajectory()
+                import einops
+                q = einops.repeat(gen.noise.q_matrix[idx], "i j -> b n i j", b=B, n=N)
+                qb = einops.repeat(gen.noise.q_bar_matrix[idx], "i j -> b n i j", b=B, n=N)
+                qbm = einops.repeat(gen.noise.q_bar_tm1_matrix[idx], "i j -> b n i j", b=B, n=N)
+                one_eff = one and idx != 0  # langevin_generator.py:601-604
+                a_out = gen._atom_types_update(logits, a, q, qb, qbm, atom_type_greedy_sampling=greedy,
+                                               one_atom_type_transition_per_step=one_eff)
+                rec = gen.sample_trajectory_recorder._internal_data["atom_type_update"][0]
+                name = f"C{C}_g{int(greedy)}_o{int(one)}_i{idx}"
+                case_names.append(name)
+                out[f"{name}/logits"] = _np(logits)
+                out[f"{name}/a"] = _np(a)
+                out[f"{name}/gumbel"] = _np(gumbel)
+                out[f"{name}/u"] = _np(u_b)
+                out[f"{name}/q"] = _np(gen.noise.q_matrix[idx])
+                out[f"{name}/qbar"] = _np(gen.noise.q_bar_matrix[idx])
+                out[f"{name}/qbar_tm1"] = _np(gen.noise.q_bar_tm1_matrix[idx])
+                out[f"{name}/flags"] = np.array([int(greedy), int(one_eff), idx, T], dtype=np.int64)
+                out[f"{name}/p"] = _np(rec["one_step_transition_probabilities"])
+                out[f"{name}/gumbel_used"] = _np(rec["gumbel_sample"])
+                out[f"{name}/a_out"] = _np(a_out)
+    out["names"] = np.array(case_names)
+    out["small_epsilon"] = np.array(1e-8)
+    save("p2_atom_types.npz", **out)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# F1 / F2
+# --------------------------------------------------------------------------------------------------------------
+def golden_noisers():
+    g = torch.Generator().manual_seed(303)
+    B, N, d = 5, 8, 3
+    out = {}
+    orig_gauss = RelativeCoordinatesNoiser.__dict__["_get_gaussian_noise"]
+    orig_unif = AtomTypesNoiser.__dict__["_get_uniform_noise"]
+    x0 = torch.rand(B, N, d, generator=g)
+    sig = torch.rand(B, 1, 1, generator=g).expand(B, N, d).contiguous() * 0.5
+    z = torch.randn(B, N, d, generator=g)
+    RelativeCoordinatesNoiser._get_gaussian_noise = staticmethod(lambda shape: z.clone())
+    xt = RelativeCoordinatesNoiser.get_noisy_relative_coordinates_sample(x0, sig)
+    out.update(f1_x0=_np(x0), f1_sigma=_np(sig), f1_z=_np(z), f1_xt=_np(xt))
+    names = []
+    for C in (2, 3, 5):
+        T = 10
+        sched = NoiseScheduler(NoiseParameters(total_time_steps=T), num_classes=C)
+        noise, _ = sched.get_all_sampling_parameters()
+        for idx in (0, 3, 9):
+            a0 = torch.randint(0, C - 1, (B, N), generator=g)
+            u = torch.rand(B, N, C, generator=g)
+            u[0, 0, 0] = 0.0  # un-clipped uniform (quirk 6)
+            AtomTypesNoiser._get_uniform_noise = staticmethod(lambda shape, u=u: u.clone())
+            import einops
+            qb = einops.repeat(noise.q_bar_matrix[idx], "i j -> b n i j", b=B, n=N)
+            at = AtomTypesNoiser.get_noisy_atom_types_sample(class_index_to_onehot(a0, C), qb)
+            nm = f"f2_C{C}_i{idx}"
+            names.append(nm)
+            out[f"{nm}/a0"] = _np(a0)
+            out[f"{nm}/u"] = _np(u)
+            out[f"{nm}/qbar"] = _np(noise.q_bar_matrix[idx])
+            out[f"{nm}/at"] = _np(at)
+    out["f2_names"] = np.array(names)
+    RelativeCoordinatesNoiser._get_gaussian_noise = orig_gauss
+    AtomTypesNoiser._get_uniform_noise = orig_unif
+    save("noisers.npz", **out)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# N1
+# --------------------------------------------------------------------------------------------------------------
+def golden_neighbors():
+    g = torch.Generator().manual_seed(404)
+    out = {}
+    names = []
+
+    def run(name, X, cell, rc):
+        cart = torch.matmul(X, cell)
+        info = get_periodic_adjacency_information(cart, cell, rc)
+        adj = _np(info.adjacency_matrix)
+        eb = _np(info.edge_batch_indices)
+        shifts = _np(info.shifts)
+        # canonical order for set comparison: (batch, src, dst, shift)
+        key = np.lexsort((shifts[:, 2], shifts[:, 1], shifts[:, 0], adj[1], adj[0], eb))
+        names.append(name)
+        out[f"{name}/X"] = _np(X)
+        out[f"{name}/cell"] = _np(cell)
+        out[f"{name}/cart"] = _np(cart)
+        out[f"{name}/rc"] = np.array(rc, dtype=np.float64)
+        out[f"{name}/adj_sorted"] = adj[:, key].astype(np.int32)
+        out[f"{name}/edge_batch_sorted"] = eb[key].astype(np.int32)
+        out[f"{name}/shifts_sorted"] = shifts[key]
+        out[f"{name}/number_of_edges"] = _np(info.number_of_edges)
+        edges = get_edges_with_radial_cutoff(X, cell, rc, drop_duplicate_edges=True)
+        out[f"{name}/unique_edges"] = _np(edges).astype(np.int32)
+
+    B = 4
+    # cubic Si 1x1x1-like, Si 2x2x2 with the EGNN clipped cell (quirk N2), small rc
+    run("n8_cubic", torch.rand(B, 8, 3, generator=g), torch.diag(torch.tensor([5.43] * 3)).repeat(B, 1, 1), 2.5)
+    run("n64_clip", torch.rand(B, 64, 3, generator=g), torch.diag(torch.tensor([16.5] * 3)).repeat(B, 1, 1), 7.5)
+    run("n64_cubic", torch.rand(B, 64, 3, generator=g), torch.diag(torch.tensor([10.86] * 3)).repeat(B, 1, 1), 5.0)
+    # slightly triclinic cells as in tests/utils/test_neighbors.py:180-236 (5-10 A, rc in {1.1, 2.2, 3.3})
+    for rc in (1.1, 2.2, 3.3):
+        diag = 5.0 + 5.0 * torch.rand(B, 3, generator=g)
+        cell = torch.diag_embed(diag) + 0.1 * (torch.rand(B, 3, 3, generator=g) - 0.5)
+        run(f"n32_tric_rc{rc}", torch.rand(B, 32, 3, generator=g), cell, rc)
+    run("n216_clip", torch.rand(2, 216, 3, generator=g), torch.diag(torch.tensor([16.5] * 3)).repeat(2, 1, 1), 7.5)
+    # coincident atoms (quirk 3): 0 < d^2 excludes them
+    X = torch.rand(2, 8, 3, generator=g)
+    X[0, 1] = X[0, 0]
+    run("n8_coincident", X, torch.diag(torch.tensor([6.0] * 3)).repeat(2, 1, 1), 2.9)
+    out["names"] = np.array(names)
+    save("neighbors.npz", **out)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# whole trajectories
+# --------------------------------------------------------------------------------------------------------------
+def _pack_records(gen, with_corrector=True):
+    data = gen.sample_trajectory_recorder._internal_data
+    out = {}
+    pred = data["predictor_step"]
+    out["pred_index"] = np.array([e["time_step_index"] for e in pred], dtype=np.int64)
+    for key in ("composition_i", "composition_im1", "model_predictions_i"):
+        out[f"pred_{key}_A"] = np.stack([_np(e[key].A) for e in pred])
+        out[f"pred_{key}_X"] = np.stack([_np(e[key].X) for e in pred])
+        out[f"pred_{key}_L"] = np.stack([_np(e[key].L) for e in pred])
+    corr = data.get("corrector_step", [])
+    if corr:
+        out["corr_index"] = np.array([e["time_step_index"] for e in corr], dtype=np.int64)
+        for key in ("composition_i", "corrected_composition_i", "model_predictions_i"):
+            out[f"corr_{key}_A"] = np.stack([_np(e[key].A) for e in corr])
+            out[f"corr_{key}_X"] = np.stack([_np(e[key].X) for e in corr])
+            out[f"corr_{key}_L"] = np.stack([_np(e[key].L) for e in corr])
+    return out
+
+
+def _mlp(N, num_atom_types, seed=1234, hidden=64, d=3):
+    torch.manual_seed(seed)
+    p = MLPScoreNetworkParameters(number_of_atoms=N, num_atom_types=num_atom_types, spatial_dimension=d,
+                                  n_hidden_dimensions=3, hidden_dimensions_size=hidden,
+                                  relative_coordinates_embedding_dimensions_size=32,
+                                  noise_embedding_dimensions_size=16, time_embedding_dimensions_size=16,
+                                  atom_type_embedding_dimensions_size=1,
+                                  lattice_parameters_embedding_dimensions_size=1, condition_embedding_size=64)
+    return MLPScoreNetwork(p).eval()
+
+
+def _egnn(num_atom_types, edges, rc, seed=1234, hidden=32, n_layers=2):
+    torch.manual_seed(seed)
+    p = EGNNScoreNetworkParameters(num_atom_types=num_atom_types, n_layers=n_layers,
+                                   coordinate_hidden_dimensions_size=hidden, coordinate_n_hidden_dimensions=2,
+                                   message_hidden_dimensions_size=hidden, message_n_hidden_dimensions=2,
+                                   node_hidden_dimensions_size=hidden, node_n_hidden_dimensions=2,
+                                   edges=edges, radial_cutoff=rc)
+    return EGNNScoreNetwork(p).eval()
+
+
+def _state_dict_np(net):
+    return {f"net/{k}": _np(v) for k, v in net.state_dict().items()}
+
+
+def golden_trajectories():
+    # (name, generator kwargs, network factory, B, seed)
+    runs = [
+        ("traj_fake_c2", dict(T=12, N=8, num_atom_types=1, M=1), None, 5, 11),
+        ("traj_fake_c3_m2", dict(T=10, N=8, num_atom_types=2, M=2, noise_kw=dict(schedule_type="linear")), None, 4, 12),
+        ("traj_fake_c5_nogreedy", dict(T=10, N=8, num_atom_types=4, M=1, greedy=False, one=False), None, 4, 13),
+        ("traj_fake_c5_test", dict(T=10, N=8, num_atom_types=4, M=2, eps=1e-6, in_corr=True,
+                                   noise_kw=dict(time_delta=0.1, sigma_min=0.15, corrector_step_epsilon=0.25)),
+         None, 5, 14),
+        ("traj_fake_free_lattice", dict(T=8, N=8, num_atom_types=1, M=1, fixed=False), None, 4, 15),
+        ("traj_mlp_c1", dict(T=20, N=8, num_atom_types=1, M=1,
+                             noise_kw=dict(sigma_min=1e-4, sigma_max=0.25)), lambda: _mlp(8, 1), 6, 16),
+        ("traj_mlp_c3", dict(T=16, N=8, num_atom_types=2, M=2, cell=[5.5421] * 3,
+                             noise_kw=dict(sigma_min=1e-4, sigma_max=0.2, schedule_type="linear",
+                                           corrector_step_epsilon=2.5e-8)), lambda: _mlp(8, 2), 4, 17),
+        ("traj_egnn_fc", dict(T=6, N=8, num_atom_types=1, M=1, one=False, greedy=False,
+                              noise_kw=dict(sigma_min=1e-4, sigma_max=0.2, schedule_type="linear",
+                                            corrector_step_epsilon=2.5e-8)),
+         lambda: _egnn(1, "fully_connected", None), 3, 18),
+        ("traj_egnn_rc", dict(T=4, N=64, num_atom_types=1, M=2, one=False, greedy=False, cell=[10.86] * 3,
+                              noise_kw=dict(sigma_min=1e-4, sigma_max=0.2, schedule_type="linear",
+                                            corrector_step_epsilon=2.5e-8)),
+         lambda: _egnn(1, "radial_cutoff", 7.5), 2, 19),
+    ]
+    for name, kw, netf, B, seed in runs:
+        net = netf() if netf else None
+        gen, npar, spar = make_generator(record=True, net=net, **kw)
+        torch.manual_seed(seed)
+        with torch.no_grad(), DrawRecorder() as rec:
+            axl = gen.sample(B, torch.device("cpu"))
+        out = dict(final_A=_np(axl.A), final_X=_np(axl.X), final_L=_np(axl.L), batch=np.array(B))
+        out.update(rec.pack())
+        out.update(_pack_records(gen))
+        if net is not None:
+            out.update(_state_dict_np(net))
+        save(name + ".npz", **out)
+
+    # repaint (ConstrainedLangevinGenerator), K = N/2 pinned atoms, fake and MLP nets
+    for name, kw, netf, B, seed, idxs in [
+        ("traj_repaint_fake", dict(T=10, N=8, num_atom_types=2, M=1), None, 4, 21, None),
+        ("traj_repaint_mlp", dict(T=12, N=8, num_atom_types=1, M=2,
+                                  noise_kw=dict(sigma_min=1e-4, sigma_max=0.2, schedule_type="linear",
+                                                corrector_step_epsilon=2.5e-8)), lambda: _mlp(8, 1), 3, 22,
+         torch.tensor([6, 1, 3, 4])),
+    ]:
+        g = torch.Generator().manual_seed(seed)
+        K = 4
+        nat = kw["num_atom_types"]
+        constraint = SamplingConstraint(elements=["Si", "Ge"][:nat],
+                                        constrained_relative_coordinates=torch.rand(K, 3, generator=g),
+                                        constrained_atom_types=torch.randint(0, nat, (K,), generator=g),
+                                        constrained_indices=idxs)
+        net = netf() if netf else None
+        gen, npar, spar = make_generator(record=True, net=net, constraint=constraint, **kw)
+        torch.manual_seed(seed)
+        with torch.no_grad(), DrawRecorder() as rec:
+            axl = gen.sample(B, torch.device("cpu"))
+        out = dict(final_A=_np(axl.A), final_X=_np(axl.X), final_L=_np(axl.L), batch=np.array(B),
+                   constrained_relative_coordinates=_np(constraint.constrained_relative_coordinates),
+                   constrained_atom_types=_np(constraint.constrained_atom_types),
+                   constrained_indices=_np(gen.constraint_indices))
+        out.update(rec.pack())
+        out.update(_pack_records(gen))
+        if net is not None:
+            out.update(_state_dict_np(net))
+        save(name + ".npz", **out)
+
+    # D1: create_batch_of_samples with sub-batches (sampling/diffusion_sampling.py:16-73)
+    gen, npar, spar = make_generator(T=6, N=8, num_atom_types=1, M=1)
+    spar.number_of_samples = 7
+    spar.sample_batchsize = 3
+    torch.manual_seed(31)
+    with torch.no_grad(), DrawRecorder() as rec:
+        batch = create_batch_of_samples(gen, spar, torch.device("cpu"))
+    out = dict(cartesian_positions=_np(batch["cartesian_positions"]), A=_np(batch["original_axl"].A),
+               X=_np(batch["original_axl"].X), L=_np(batch["original_axl"].L))
+    out.update(rec.pack())
+    save("batch_of_samples.npz", **out)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# score-network forwards (so the build's PyTorch nets can be checked against the reference's on the same weights)
+# --------------------------------------------------------------------------------------------------------------
+def golden_networks():
+    g = torch.Generator().manual_seed(505)
+    for name, net, N, nat, cell in [
+        ("net_mlp_c1", _mlp(8, 1), 8, 1, 5.43),
+        ("net_mlp_c3", _mlp(8, 2), 8, 2, 5.5421),
+        ("net_egnn_fc", _egnn(1, "fully_connected", None), 8, 1, 5.43),
+        ("net_egnn_rc", _egnn(2, "radial_cutoff", 7.5), 64, 2, 11.084),
+    ]:
+        B = 3
+        C = nat + 1
+        batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.randint(0, C, (B, N), generator=g),
+                                            X=torch.rand(B, N, 3, generator=g),
+                                            L=torch.tensor([cell, cell, cell, 0, 0, 0.0]).repeat(B, 1)),
+                 TIME: torch.rand(B, 1, generator=g), NOISE: torch.rand(B, 1, generator=g) * 0.2,
+                 CARTESIAN_FORCES: torch.zeros(B, N, 3)}
+        with torch.no_grad():
+            o = net(batch, conditional=False)
+        out = dict(A=_np(batch[NOISY_AXL_COMPOSITION].A), X=_np(batch[NOISY_AXL_COMPOSITION].X),
+                   L=_np(batch[NOISY_AXL_COMPOSITION].L), time=_np(batch[TIME]), noise=_np(batch[NOISE]),
+                   out_A=_np(o.A), out_X=_np(o.X), out_L=_np(o.L))
+        out.update(_state_dict_np(net))
+        save(name + ".npz", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    golden_schedules()
+    golden_p1_p3()
+    golden_p2()
+    golden_noisers()
+    golden_neighbors()
+    golden_trajectories()
+    golden_networks()
