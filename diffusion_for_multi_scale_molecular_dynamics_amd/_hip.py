@@ -1,0 +1,148 @@
+"""ctypes binding of csrc/libmdx_hip.so (the C ABI declared in include/mdx_hip.h).
+
+There is NO fallback: if the shared library is missing, or a tensor is not a contiguous device tensor of the
+expected dtype, the call raises.  PyTorch is used only as the owner of device memory and streams.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmdx_hip.so")
+
+MDX_OK = 0
+MDX_PREDICTOR, MDX_CORRECTOR = 0, 1
+STATUS_CUTOFF_TOO_LARGE, STATUS_MASK_AT_LAST_STEP = 1, 2
+MAX_CLASSES = 8
+TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
+    TAG_INIT_LATTICE = range(9)
+
+ABI_SYMBOLS = (
+    "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
+    "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
+    "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
+    "mdx_repaint_constrained_rows", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_rng_fill",
+    "mdx_math_probe",
+)
+
+
+class MdxError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+class Schedule(C.Structure):
+    """mdx_schedule_t"""
+    _fields_ = [("total_time_steps", C.c_int32), ("num_classes", C.c_int32), ("sigma_min", C.c_double),
+                ("time", C.c_void_p), ("sigma", C.c_void_p), ("g", C.c_void_p), ("g_squared", C.c_void_p),
+                ("epsilon", C.c_void_p), ("q_matrix", C.c_void_p), ("q_bar_matrix", C.c_void_p),
+                ("q_bar_tm1_matrix", C.c_void_p)]
+
+
+class Rng(C.Structure):
+    """mdx_rng_t"""
+    _fields_ = [("seed", C.c_uint64), ("call", C.c_uint32), ("draw_stride", C.c_uint32),
+                ("draw_offset", C.c_uint32)]
+
+
+class PcFlags(C.Structure):
+    """mdx_pc_flags_t"""
+    _fields_ = [("atom_type_greedy_sampling", C.c_int32), ("one_atom_type_transition_per_step", C.c_int32),
+                ("use_fixed_lattice_parameters", C.c_int32), ("update_atom_types", C.c_int32),
+                ("small_epsilon", C.c_float)]
+
+
+def build(force=False):
+    """Compile csrc/mdx_hip.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("mdx_hip.hip", "mdx_math.hpp")]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mdx_hip.h"))
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "-B"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MdxError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(or `make -C {CSRC}`). There is no CPU fallback for the sampling hot path.")
+        L = C.CDLL(LIB_PATH)
+        _declare(L)
+        if L.mdx_abi_version() != 1:
+            raise MdxError("libmdx_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _declare(L):
+    vp, i32, i64, f32, f64, u32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint32, C.c_uint64
+    L.mdx_abi_version.restype = i32
+    L.mdx_abi_version.argtypes = []
+    L.mdx_status_string.restype = C.c_char_p
+    L.mdx_status_string.argtypes = [i32]
+    L.mdx_noise_schedule_build.restype = i32
+    L.mdx_noise_schedule_build.argtypes = [i32, i32, f64, f64, f64, f64, i32] + [vp] * 12 + [vp]
+    L.mdx_index_set.restype = i32
+    L.mdx_index_set.argtypes = [vp, C.c_int32, vp]
+    L.mdx_index_add.restype = i32
+    L.mdx_index_add.argtypes = [vp, C.c_int32, vp]
+    L.mdx_fill_time_sigma.restype = i32
+    L.mdx_fill_time_sigma.argtypes = [C.POINTER(Schedule), i32, i32, vp, vp, vp, i64, vp]
+    L.mdx_relative_coordinates_update.restype = i32
+    L.mdx_relative_coordinates_update.argtypes = [vp, vp, vp, f32, f32, f32, i64, vp, vp]
+    L.mdx_lattice_parameters_update.restype = i32
+    L.mdx_lattice_parameters_update.argtypes = [vp, vp, vp, f32, f32, f32, i64, vp, vp]
+    L.mdx_atom_types_update.restype = i32
+    L.mdx_atom_types_update.argtypes = [vp] * 7 + [i64, i32, i32, f32, i32, i32, vp, vp, vp]
+    L.mdx_pc_step_update.restype = i32
+    L.mdx_pc_step_update.argtypes = [C.POINTER(Schedule), i32, i32, vp, C.POINTER(PcFlags)] + [vp] * 10 + \
+        [Rng, i64, i32, i32, vp, vp, vp, vp, vp]
+    L.mdx_noise_relative_coordinates.restype = i32
+    L.mdx_noise_relative_coordinates.argtypes = [vp, vp, f32, i64, vp, vp]
+    L.mdx_noise_atom_types.restype = i32
+    L.mdx_noise_atom_types.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+    L.mdx_repaint_constrained_rows.restype = i32
+    L.mdx_repaint_constrained_rows.argtypes = [C.POINTER(Schedule), i32, vp, vp, vp, vp, i32, vp, vp, Rng, i64, i32,
+                                               i32, vp, vp, vp]
+    L.mdx_radius_graph_count.restype = i32
+    L.mdx_radius_graph_count.argtypes = [vp, vp, f32, i64, i32, i32, vp, vp, vp]
+    L.mdx_radius_graph_fill.restype = i32
+    L.mdx_radius_graph_fill.argtypes = [vp, vp, f32, i64, i32, i32, vp, vp, vp, vp, vp]
+    L.mdx_rng_fill.restype = i32
+    L.mdx_rng_fill.argtypes = [i32, u64, u32, u32, u32, i64, i32, vp, vp]
+    L.mdx_math_probe.restype = i32
+    L.mdx_math_probe.argtypes = [i32, vp, i64, vp, vp]
+
+
+def check(status, what):
+    if status != MDX_OK:
+        msg = lib().mdx_status_string(status).decode()
+        raise MdxError(f"{what}: {msg} (status {status})")
+
+
+def stream_handle():
+    """The raw hipStream_t of torch's current stream (so launches are captured by torch.cuda.graph)."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype, name):
+    """Device pointer of a contiguous device tensor of the given dtype; None stays NULL."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise MdxError(f"{name} lives on {t.device}: the sampling hot path runs on the GPU only (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return C.c_void_p(t.data_ptr())

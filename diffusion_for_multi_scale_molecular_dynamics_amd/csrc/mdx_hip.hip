@@ -1,0 +1,980 @@
+// HIP kernels (gfx950 / CDNA4) + C ABI of the sampling hot path.  See include/mdx_hip.h for the contract and
+// DESIGN.md for data layout, roofline accounting and the arithmetic specification.
+//
+// Kernel inventory
+//   schedule_kernel        S1  variance-exploding schedule tables (one-off, one workgroup)
+//   fill_time_sigma_kernel     TIME / NOISE [B,1] network inputs from the device tables
+//   coords_update_kernel   P1  x' = wrap((x + w s / sigma) + n z)           flat, 16 B/lane
+//   pc_step_kernel         P2 (+P1 +P3) fused per-step update, one lane-group per structure,
+//                              wavefront-shuffle reductions over the atoms of a structure
+//   repaint_rows_kernel    R1  forward-noise + scatter of the constrained rows (F1 + F2 fused)
+//   radius_graph_kernel    N1  27-image radius graph, structure tile staged in LDS, one wavefront per source
+//                              row, ballot/scan ranked writes => edges come out sorted, no atomics
+//   rng_fill_kernel            Philox draws as arrays
+// 64-wide wavefronts are assumed throughout (gfx950).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+
+#include "../../include/mdx_hip.h"
+#include "mdx_math.hpp"
+
+using namespace mdx;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP; }
+inline hipStream_t as_stream(mdx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// S1
+// ---------------------------------------------------------------------------------------------------------------
+struct ScheduleArgs {
+    int T, type, C;
+    double time_delta, sigma_min, sigma_max, corrector_eps;
+    float *time, *sigma, *sigma2, *g, *g2, *eps, *sqrt2eps, *beta, *alpha_bar, *q, *qbar, *qbar_tm1;
+};
+
+__global__ __launch_bounds__(kBlock) void schedule_kernel(ScheduleArgs a)
+{
+    const int T = a.T, C = a.C;
+    const float start = (float)a.time_delta, end = 1.0f;
+    const float step = (end - start) / (float)(T - 1);
+    const int halfway = T / 2;
+    const float smin = (float)a.sigma_min, smax = (float)a.sigma_max;
+    const float ratio = smax / smin;
+    const float diff = smax - smin;
+    const double log_ratio = log_((double)ratio);
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+        const float t = (i < halfway) ? __builtin_fmaf(step, (float)i, start)
+                                      : __builtin_fmaf(-step, (float)(T - 1 - i), end);
+        a.time[i] = t;
+        float s;
+        if (a.type == 0) {
+            const float p = (float)exp_((double)t * log_ratio);
+            s = smin * p;
+        } else {
+            s = smin + diff * t;
+        }
+        a.sigma[i] = s;
+        a.sigma2[i] = s * s;
+        const float b = 1.0f / (float)(T - i);
+        a.beta[i] = b;
+        const float omb = 1.0f - b;
+        for (int r = 0; r < C; ++r)
+            for (int c = 0; c < C; ++c) {
+                float v = omb * (r == c ? 1.0f : 0.0f);
+                v = v + b * (c == C - 1 ? 1.0f : 0.0f);
+                a.q[((int64_t)i * C + r) * C + c] = v;
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+        const float g2 = (i == 0) ? a.sigma2[0] - (float)(a.sigma_min * a.sigma_min) : a.sigma2[i] - a.sigma2[i - 1];
+        a.g2[i] = g2;
+        a.g[i] = __builtin_sqrtf(g2);
+        float e;
+        if (i == 0) e = (1.0f / a.sigma2[0]) * (float)(0.5 * a.corrector_eps * (a.sigma_min * a.sigma_min));
+        else e = ((float)(0.5 * a.corrector_eps) * a.sigma2[i - 1]) / a.sigma2[0];
+        a.eps[i] = e;
+        a.sqrt2eps[i] = __builtin_sqrtf(2.0f * e);
+    }
+    // sequential chains: alpha_bar (binary64 running product) on one lane; Qbar row r on lane r (row r of
+    // Qbar_t depends only on row r of Qbar_{t-1}, so rows are independent chains)
+    if (threadIdx.x == kWave) {
+        double ab = 1.0;
+        for (int i = 0; i < T; ++i) {
+            ab = ab * (double)(1.0f - 1.0f / (float)(T - i));
+            a.alpha_bar[i] = (float)ab;
+        }
+    }
+    if ((int)threadIdx.x < C) {
+        const int r = threadIdx.x;
+        float prev[MDX_MAX_CLASSES * 2], cur[MDX_MAX_CLASSES * 2];
+        for (int c = 0; c < C; ++c) {
+            const float b = 1.0f / (float)T;
+            float v = (1.0f - b) * (r == c ? 1.0f : 0.0f);
+            v = v + b * (c == C - 1 ? 1.0f : 0.0f);
+            prev[c] = v;
+            a.qbar[r * C + c] = v;
+            a.qbar_tm1[r * C + c] = (r == c) ? 1.0f : 0.0f;
+        }
+        for (int i = 1; i < T; ++i) {
+            const float b = 1.0f / (float)(T - i);
+            const float omb = 1.0f - b;
+            for (int c = 0; c < C; ++c) {
+                float acc = 0.0f;
+                for (int k = 0; k < C; ++k) {
+                    float qkc = omb * (k == c ? 1.0f : 0.0f);
+                    qkc = qkc + b * (c == C - 1 ? 1.0f : 0.0f);
+                    acc = __builtin_fmaf(prev[k], qkc, acc);
+                }
+                cur[c] = acc;
+            }
+            for (int c = 0; c < C; ++c) {
+                a.qbar_tm1[((int64_t)i * C + r) * C + c] = prev[c];
+                a.qbar[((int64_t)i * C + r) * C + c] = cur[c];
+                prev[c] = cur[c];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// step index on the device
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void index_kernel(int32_t* d_index, int32_t value, int add)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *d_index = add ? *d_index + value : value;
+}
+
+struct SchedDev {  // by-value copy of mdx_schedule_t for kernels
+    int T, C;
+    double sigma_min;
+    const float *time, *sigma, *g, *g2, *eps, *q, *qbar, *qbar_tm1;
+};
+
+inline SchedDev to_dev(const mdx_schedule_t* s)
+{
+    SchedDev d;
+    d.T = s->total_time_steps;
+    d.C = s->num_classes;
+    d.sigma_min = s->sigma_min;
+    d.time = s->time; d.sigma = s->sigma; d.g = s->g; d.g2 = s->g_squared; d.eps = s->epsilon;
+    d.q = s->q_matrix; d.qbar = s->q_bar_matrix; d.qbar_tm1 = s->q_bar_tm1_matrix;
+    return d;
+}
+
+struct StepScalars {
+    float time, sigma, w, n, sigma_n;
+    int idx;        // row of the Q tables
+    int index;      // effective index_i
+};
+
+// predictor_step scalars (generators/langevin_generator.py:559-569) / corrector_step scalars (:719-733, :678, :749)
+__device__ __forceinline__ StepScalars step_scalars(const SchedDev& s, int mode, int index, double atoms_pow)
+{
+    StepScalars o;
+    o.index = index;
+    if (mode == MDX_PREDICTOR) {
+        const int idx = index - 1;
+        o.idx = idx;
+        o.time = s.time[idx];
+        o.sigma = s.sigma[idx];
+        o.w = s.g2[idx];
+        o.n = s.g[idx];
+        o.sigma_n = o.sigma / (float)atoms_pow;
+    } else {
+        if (index == 0) {
+            o.idx = 0;
+            o.time = 0.0f;
+            o.sigma = (float)s.sigma_min;
+            o.sigma_n = (float)(s.sigma_min / atoms_pow);
+        } else {
+            o.idx = index - 1;
+            o.time = s.time[o.idx];
+            o.sigma = s.sigma[o.idx];
+            o.sigma_n = o.sigma / (float)atoms_pow;
+        }
+        o.w = s.eps[index];
+        o.n = __builtin_sqrtf(2.0f * o.w);
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(kBlock) void fill_time_sigma_kernel(SchedDev s, int mode, int index_i,
+                                                                 const int32_t* d_index, float* time_out,
+                                                                 float* sigma_out, int64_t batch)
+{
+    const int index = (d_index ? *d_index : 0) + index_i;
+    const StepScalars sc = step_scalars(s, mode, index, 1.0);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < batch; i += (int64_t)gridDim.x * blockDim.x) {
+        time_out[i] = sc.time;
+        sigma_out[i] = sc.sigma;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// P1 / P3 / F1: flat elementwise kernels
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float coord_update(float x, float s, float z, float w, float n, float sigma)
+{
+    return wrap01((x + (w * s) / sigma) + n * z);
+}
+
+// VEC = 4: 16 B per lane per array; requires 16-B aligned pointers.  Tail handled by the scalar instantiation.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void coords_update_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                               const float* __restrict__ z, float w, float n,
+                                                               float sigma, int64_t count, float* __restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (VEC == 4) {
+        const int64_t nvec = count >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const float4* s4 = reinterpret_cast<const float4*>(s);
+        const float4* z4 = reinterpret_cast<const float4*>(z);
+        float4* o4 = reinterpret_cast<float4*>(out);
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += stride) {
+            const float4 xv = x4[i], sv = s4[i], zv = z4[i];
+            float4 o;
+            o.x = coord_update(xv.x, sv.x, zv.x, w, n, sigma);
+            o.y = coord_update(xv.y, sv.y, zv.y, w, n, sigma);
+            o.z = coord_update(xv.z, sv.z, zv.z, w, n, sigma);
+            o.w = coord_update(xv.w, sv.w, zv.w, w, n, sigma);
+            o4[i] = o;
+        }
+        for (int64_t i = (nvec << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += stride)
+            out[i] = coord_update(x[i], s[i], z[i], w, n, sigma);
+    } else {
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += stride)
+            out[i] = coord_update(x[i], s[i], z[i], w, n, sigma);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void lattice_update_kernel(const float* l, const float* s, const float* z, float w,
+                                                                float n, float sigma_n, int64_t count, float* out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (l[i] + (w * s[i]) / sigma_n) + n * z[i];
+}
+
+__global__ __launch_bounds__(kBlock) void noise_coords_kernel(const float* x0, const float* z, float sigma, int64_t count,
+                                                              float* out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = wrap01(x0[i] + sigma * z[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// P2 (+P1 +P3): fused per-step update
+// ---------------------------------------------------------------------------------------------------------------
+struct PcArgs {
+    SchedDev sched;
+    int use_tables;          // 1: scalars and Q matrices from the tables at the effective index; 0: explicit
+    int mode, index_i;
+    const int32_t* d_index;
+    double atoms_pow;        // number_of_atoms ** (1/spatial_dimension), computed in binary64 like the reference
+    // explicit-operand form (stand-alone P2)
+    const float *q_explicit, *qbar_explicit, *qbar_tm1_explicit;
+    // flags
+    int greedy, one_transition, fixed_lattice, update_types, do_coords, do_lattice;
+    float small_eps;
+    // operands
+    const int64_t* a;
+    const float *x, *l, *logits, *score_x, *score_l;
+    const float *z_coord, *gumbel, *u, *z_lat;
+    mdx_rng_t rng;
+    int64_t B;
+    int N, d, C, nl;
+    int64_t* a_out;
+    float *x_out, *l_out, *p_out;
+    uint32_t* status;
+};
+
+// posterior p(a_{t-1} | a_t, logits) for one atom (utils/d3pm_utils.py:105-150)
+__device__ __forceinline__ void posterior(const float* __restrict__ logits, int a_t, const float* __restrict__ q,
+                                          const float* __restrict__ qbar, const float* __restrict__ qbar_tm1, int C,
+                                          float small_eps, float* p)
+{
+    float e[MDX_MAX_CLASSES];
+    float m = logits[0];
+    for (int c = 1; c < C; ++c) m = (logits[c] > m) ? logits[c] : m;
+    float S = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        e[c] = expf_(logits[c] - m);
+        S = S + e[c];
+    }
+    const float invS = 1.0f / S;
+    float S2 = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        float r = e[c] * invS;
+        r = (r < small_eps) ? small_eps : r;
+        e[c] = r;
+        S2 = S2 + r;
+    }
+    for (int c = 0; c < C; ++c) e[c] = e[c] / S2;
+    float den = 0.0f;
+    for (int j = 0; j < C; ++j) den = den + e[j] * qbar[j * C + a_t];
+    for (int i = 0; i < C; ++i) {
+        float num1 = 0.0f;
+        for (int j = 0; j < C; ++j) num1 = num1 + e[j] * qbar_tm1[j * C + i];
+        const float num2 = q[i * C + a_t];
+        p[i] = (num1 * num2) / den;
+    }
+}
+
+template <int G>
+__device__ __forceinline__ int group_and(int v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v &= __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// G lanes cooperate on one structure; a 64-lane wavefront carries 64/G structures.
+template <int G>
+__global__ __launch_bounds__(kBlock) void pc_step_kernel(PcArgs p)
+{
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t groups_per_grid = ((int64_t)gridDim.x * blockDim.x) / G;
+    const int64_t group0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int N = p.N, C = p.C, d = p.d, M = p.C - 1;
+
+    StepScalars sc;
+    const float *q = p.q_explicit, *qbar = p.qbar_explicit, *qbar_tm1 = p.qbar_tm1_explicit;
+    int one = p.one_transition;
+    int last_predictor_step = 0;
+    uint32_t draw = p.rng.draw_offset;
+    if (p.use_tables) {
+        const int index = (p.d_index ? *p.d_index : 0) + p.index_i;
+        sc = step_scalars(p.sched, p.mode, index, p.atoms_pow);
+        q = p.sched.q + (int64_t)sc.idx * C * C;
+        qbar = p.sched.qbar + (int64_t)sc.idx * C * C;
+        qbar_tm1 = p.sched.qbar_tm1 + (int64_t)sc.idx * C * C;
+        last_predictor_step = (p.mode == MDX_PREDICTOR && sc.idx == 0);
+        if (last_predictor_step) one = 0;                       // generators/langevin_generator.py:601-604
+        draw = (uint32_t)index * p.rng.draw_stride + p.rng.draw_offset;
+    }
+    const uint32_t k0 = (uint32_t)p.rng.seed, k1 = (uint32_t)(p.rng.seed >> 32);
+    const uint32_t call8 = p.rng.call << 8;
+
+    for (int64_t b = group0; b < p.B; b += groups_per_grid) {
+        int all_masked = 1;
+        if (p.update_types && p.greedy) {
+            for (int n = lane; n < N; n += G) all_masked &= (p.a[b * N + n] == M);
+            all_masked = group_and<G>(all_masked);
+        }
+        float best_v = -__builtin_huge_valf();
+        int best_n = 0x7fffffff;
+        int best_prop = 0;
+        for (int n = lane; n < N; n += G) {
+            const int64_t at = b * N + n;
+            if (p.update_types) {
+                const int a_t = (int)p.a[at];
+                float pr[MDX_MAX_CLASSES], gm[MDX_MAX_CLASSES];
+                posterior(p.logits + at * C, a_t, q, qbar, qbar_tm1, C, p.small_eps, pr);
+                if (p.gumbel) {
+                    for (int c = 0; c < C; ++c) gm[c] = p.gumbel[at * C + c];
+                } else {
+                    for (int sub = 0; sub * 4 < C; ++sub) {
+                        const u32x4 r = philox4x32_10((uint32_t)at, call8 | (uint32_t)sub, draw, MDX_TAG_GUMBEL, k0, k1);
+                        for (int l = 0; l < 4 && sub * 4 + l < C; ++l) gm[sub * 4 + l] = gumbel_from_u(u01(r.v[l]));
+                    }
+                }
+                if (p.greedy) {                                  // :382-439
+                    float uu;
+                    if (p.u) uu = p.u[at];
+                    else uu = u01(philox4x32_10((uint32_t)at, call8, draw, MDX_TAG_BINARY, k0, k1).v[0]);
+                    const int unmask = uu > pr[M];
+                    if (!all_masked && unmask && a_t == M) pr[M] = 0.0f;
+                    if (!all_masked)
+                        for (int c = 0; c < C; ++c) gm[c] = 0.0f;
+                }
+                float v_best = 0.0f;
+                int prop = 0;
+                for (int c = 0; c < C; ++c) {                    // :311-315, first maximal index
+                    const float v = logf_(pr[c] + p.small_eps) + gm[c];
+                    if (c == 0 || v > v_best) { v_best = v; prop = c; }
+                    if (p.p_out) p.p_out[at * C + c] = pr[c];
+                }
+                if (one) {                                       // :339-380
+                    const float cand = (prop != a_t) ? v_best : -__builtin_huge_valf();
+                    if (cand > best_v || (cand == best_v && n < best_n)) { best_v = cand; best_n = n; best_prop = prop; }
+                    p.a_out[at] = a_t;
+                } else {
+                    p.a_out[at] = prop;
+                    if (last_predictor_step && prop == M && p.status) atomicOr(p.status, MDX_STATUS_MASK_AT_LAST_STEP);
+                }
+            } else if (p.a_out && p.a_out != p.a) {
+                p.a_out[at] = p.a[at];
+            }
+            if (p.do_coords) {                                   // :194-201
+                float z[4];
+                if (!p.z_coord) {
+                    const u32x4 r = philox4x32_10((uint32_t)at, call8, draw, MDX_TAG_COORD, k0, k1);
+                    box_muller(r.v[0], r.v[1], z[0], z[1]);
+                    if (d > 2) box_muller(r.v[2], r.v[3], z[2], z[3]);
+                }
+                for (int k = 0; k < d; ++k) {
+                    const int64_t e = at * d + k;
+                    const float zz = p.z_coord ? p.z_coord[e] : z[k];
+                    p.x_out[e] = coord_update(p.x[e], p.score_x[e], zz, sc.w, sc.n, sc.sigma);
+                }
+            }
+        }
+        if (p.update_types && one) {
+            // arg-max over the atoms of the structure: larger value wins, ties go to the smaller atom index
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best_v, o, kWave);
+                const int on = __shfl_xor(best_n, o, kWave);
+                const int op = __shfl_xor(best_prop, o, kWave);
+                if (ov > best_v || (ov == best_v && on < best_n)) { best_v = ov; best_n = on; best_prop = op; }
+            }
+            if (lane == 0 && best_n < N) p.a_out[b * N + best_n] = best_prop;
+        }
+        if (p.do_lattice) {                                      // :475-490
+            for (int k = lane; k < p.nl; k += G) {
+                const int64_t e = b * p.nl + k;
+                if (p.fixed_lattice) {
+                    if (p.l_out != p.l) p.l_out[e] = p.l[e];
+                } else {
+                    float zz;
+                    if (p.z_lat) zz = p.z_lat[e];
+                    else {
+                        const u32x4 r = philox4x32_10((uint32_t)b, call8 | (uint32_t)(k >> 2), draw, MDX_TAG_LATTICE, k0, k1);
+                        float z0, z1, z2, z3;
+                        box_muller(r.v[0], r.v[1], z0, z1);
+                        box_muller(r.v[2], r.v[3], z2, z3);
+                        const int kk = k & 3;
+                        zz = kk == 0 ? z0 : (kk == 1 ? z1 : (kk == 2 ? z2 : z3));
+                    }
+                    p.l_out[e] = (p.l[e] + (sc.w * p.score_l[e]) / sc.sigma_n) + sc.n * zz;
+                }
+            }
+        }
+    }
+}
+
+int launch_pc(const PcArgs& a, hipStream_t st)
+{
+    // lanes per structure: smallest power of two >= N, capped at the wavefront
+    int G = 1;
+    while (G < a.N && G < kWave) G <<= 1;
+    const int64_t threads = a.B * G;
+    int64_t blocks = cdiv(threads, kBlock);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks), block(kBlock);
+    switch (G) {
+        case 1: hipLaunchKernelGGL(pc_step_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(pc_step_kernel<2>, grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(pc_step_kernel<4>, grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL(pc_step_kernel<8>, grid, block, 0, st, a); break;
+        case 16: hipLaunchKernelGGL(pc_step_kernel<16>, grid, block, 0, st, a); break;
+        case 32: hipLaunchKernelGGL(pc_step_kernel<32>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(pc_step_kernel<64>, grid, block, 0, st, a); break;
+    }
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// F2 stand-alone and R1
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int noised_atom_type(int a0, const float* __restrict__ qbar, int C, const float* gum_u,
+                                                bool from_u)
+{
+    float best = 0.0f;
+    int arg = 0;
+    for (int c = 0; c < C; ++c) {
+        const float lq = logf_(qbar[a0 * C + c]);
+        const float gn = from_u ? gumbel_from_u(gum_u[c]) : gum_u[c];
+        const float v = lq + gn;
+        if (c == 0 || v > best || (v != v && best == best)) { best = v; arg = c; }
+    }
+    return arg;
+}
+
+__global__ __launch_bounds__(kBlock) void noise_atom_types_kernel(const int64_t* a0, const float* qbar, const float* u,
+                                                                  int64_t n_atoms, int C, int64_t* out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_atoms; i += (int64_t)gridDim.x * blockDim.x) {
+        float uu[MDX_MAX_CLASSES];
+        for (int c = 0; c < C; ++c) uu[c] = u[i * C + c];
+        out[i] = noised_atom_type((int)a0[i], qbar, C, uu, true);
+    }
+}
+
+struct RepaintArgs {
+    SchedDev sched;
+    int index_i;
+    const int32_t* d_index;
+    const float* cx;
+    const int64_t *ca, *cidx;
+    int K;
+    const float *z, *u;
+    mdx_rng_t rng;
+    int64_t B;
+    int N, d, C;
+    float* x;
+    int64_t* a;
+};
+
+__global__ __launch_bounds__(kBlock) void repaint_rows_kernel(RepaintArgs p)
+{
+    const int index = (p.d_index ? *p.d_index : 0) + p.index_i;
+    const int C = p.C, d = p.d;
+    const uint32_t k0 = (uint32_t)p.rng.seed, k1 = (uint32_t)(p.rng.seed >> 32);
+    const uint32_t call8 = p.rng.call << 8;
+    const uint32_t draw = (uint32_t)index * p.rng.draw_stride + p.rng.draw_offset;
+    const int64_t total = p.B * p.K;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / p.K;
+        const int k = (int)(t - b * p.K);
+        const int64_t row = p.cidx[k];
+        const int64_t at = b * p.N + row;
+        const int a0 = (int)p.ca[k];
+        if (index == 0) {                        // constrained_langevin_generator.py:120-123: no noise at t = 0
+            for (int c = 0; c < d; ++c) p.x[at * d + c] = p.cx[k * d + c];
+            p.a[at] = a0;
+            continue;
+        }
+        const int idx = index - 1;               // noising_transform.py:112
+        const float sigma = p.sched.sigma[idx];
+        float z[4];
+        if (!p.z) {
+            const u32x4 r = philox4x32_10((uint32_t)at, call8, draw, MDX_TAG_REPAINT_Z, k0, k1);
+            box_muller(r.v[0], r.v[1], z[0], z[1]);
+            if (d > 2) box_muller(r.v[2], r.v[3], z[2], z[3]);
+        }
+        for (int c = 0; c < d; ++c) {
+            const float zz = p.z ? p.z[at * d + c] : z[c];
+            p.x[at * d + c] = wrap01(p.cx[k * d + c] + sigma * zz);
+        }
+        float uu[MDX_MAX_CLASSES];
+        if (p.u) {
+            for (int c = 0; c < C; ++c) uu[c] = p.u[at * C + c];
+        } else {
+            for (int sub = 0; sub * 4 < C; ++sub) {
+                const u32x4 r = philox4x32_10((uint32_t)at, call8 | (uint32_t)sub, draw, MDX_TAG_REPAINT_U, k0, k1);
+                for (int l = 0; l < 4 && sub * 4 + l < C; ++l) uu[sub * 4 + l] = u01(r.v[l]);
+            }
+        }
+        p.a[at] = noised_atom_type(a0, p.sched.qbar + (int64_t)idx * C * C, C, uu, true);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// N1: radius graph
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kRowsPerBlock = 16;
+
+__device__ __forceinline__ float crossing_distance(const float* cell)
+{
+    const float* a1 = cell; const float* a2 = cell + 3; const float* a3 = cell + 6;
+    const float c12x = a1[1] * a2[2] - a1[2] * a2[1], c12y = a1[2] * a2[0] - a1[0] * a2[2], c12z = a1[0] * a2[1] - a1[1] * a2[0];
+    const float c13x = a1[1] * a3[2] - a1[2] * a3[1], c13y = a1[2] * a3[0] - a1[0] * a3[2], c13z = a1[0] * a3[1] - a1[1] * a3[0];
+    const float c23x = a2[1] * a3[2] - a2[2] * a3[1], c23y = a2[2] * a3[0] - a2[0] * a3[2], c23z = a2[0] * a3[1] - a2[1] * a3[0];
+    const float vol = __builtin_fabsf((c12x * a3[0] + c12y * a3[1]) + c12z * a3[2]);
+    const float n12 = __builtin_sqrtf((c12x * c12x + c12y * c12y) + c12z * c12z);
+    const float n13 = __builtin_sqrtf((c13x * c13x + c13y * c13y) + c13z * c13z);
+    const float n23 = __builtin_sqrtf((c23x * c23x + c23y * c23y) + c23z * c23z);
+    float dmin = vol / n12;
+    const float d2 = vol / n13;
+    if (d2 < dmin) dmin = d2;
+    const float d3 = vol / n23;
+    if (d3 < dmin) dmin = d3;
+    return dmin;
+}
+
+// One workgroup = one (structure, chunk of kRowsPerBlock source rows).  The structure's positions and its 27
+// image vectors are staged in LDS once; each wavefront then owns source rows and sweeps the destinations 64 at
+// a time.  Lane ranks from ballot/scan make the writes dense and ordered by (src, dst, image).
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __restrict__ cart, const float* __restrict__ cell,
+                                                              float rc, int64_t B, int N, int unique, int chunks,
+                                                              int64_t* __restrict__ counts, const int64_t* __restrict__ offsets,
+                                                              int64_t* __restrict__ edges, int32_t* __restrict__ image_out,
+                                                              float* __restrict__ shifts_out, uint32_t* status)
+{
+    extern __shared__ float lds[];
+    float* pos = lds;            // [N][3]
+    float* lv = lds + 3 * N;     // [27][3]
+    const int64_t b = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const float* P = cart + b * N * 3;
+    const float* cl = cell + b * 9;
+    for (int i = threadIdx.x; i < 3 * N; i += blockDim.x) pos[i] = P[i];
+    if (threadIdx.x < 81) {
+        const int l = threadIdx.x / 3, c = threadIdx.x % 3;
+        const float rel[3] = {(float)(l / 9 - 1), (float)((l / 3) % 3 - 1), (float)(l % 3 - 1)};
+        float acc = 0.0f;
+        for (int k = 0; k < 3; ++k) acc = __builtin_fmaf(rel[k], cl[k * 3 + c], acc);
+        lv[threadIdx.x] = acc;
+    }
+    if (!FILL && chunk == 0 && threadIdx.x == 96 && status) {
+        if (!(crossing_distance(cl) > rc)) atomicOr(status, MDX_STATUS_CUTOFF_TOO_LARGE);
+    }
+    __syncthreads();
+    const float rc2 = rc * rc;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int row_end = min(N, (chunk + 1) * kRowsPerBlock);
+    for (int i = chunk * kRowsPerBlock + wave; i < row_end; i += kBlock / kWave) {
+        const float pix = pos[3 * i], piy = pos[3 * i + 1], piz = pos[3 * i + 2];
+        const int64_t row = b * N + i;
+        const int64_t base = FILL ? offsets[row] : 0;
+        int64_t running = 0;
+        for (int j0 = 0; j0 < N; j0 += kWave) {
+            const int j = j0 + lane;
+            uint32_t mask = 0;
+            if (j < N) {
+                const float pjx = pos[3 * j], pjy = pos[3 * j + 1], pjz = pos[3 * j + 2];
+#pragma unroll
+                for (int l = 0; l < 27; ++l) {
+                    const float sx = pjx + lv[3 * l], sy = pjy + lv[3 * l + 1], sz = pjz + lv[3 * l + 2];
+                    const float dx = pix - sx, dy = piy - sy, dz = piz - sz;
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (0.0f < d2 && d2 <= rc2) mask |= (1u << l);
+                }
+            }
+            int cnt = unique ? (mask != 0) : __popc(mask);
+            // exclusive prefix over the lanes
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const int v = __shfl_up(incl, o, kWave);
+                if (lane >= o) incl += v;
+            }
+            const int total = __shfl(incl, kWave - 1, kWave);
+            if (FILL && cnt) {
+                int64_t e = base + running + (incl - cnt);
+                if (unique) {
+                    edges[2 * e] = row;
+                    edges[2 * e + 1] = b * N + j;
+                } else {
+                    uint32_t m = mask;
+                    while (m) {
+                        const int l = __ffs(m) - 1;
+                        m &= m - 1;
+                        edges[2 * e] = i;
+                        edges[2 * e + 1] = j;
+                        image_out[e] = l;
+                        if (shifts_out) {
+                            shifts_out[3 * e] = lv[3 * l];
+                            shifts_out[3 * e + 1] = lv[3 * l + 1];
+                            shifts_out[3 * e + 2] = lv[3 * l + 2];
+                        }
+                        ++e;
+                    }
+                }
+            }
+            running += total;
+        }
+        if (!FILL && lane == 0) counts[row] = running;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RNG fills and math probes
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void rng_fill_kernel(int kind, uint64_t seed, uint32_t call, uint32_t draw, uint32_t tag,
+                                                          int64_t n_items, int width, float* out)
+{
+    const int subs = (width + 3) / 4;
+    const int64_t total = n_items * subs;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t it = t / subs;
+        const int sub = (int)(t - it * subs);
+        const u32x4 r = philox4x32_10((uint32_t)it, (call << 8) | (uint32_t)sub, draw, tag, k0, k1);
+        float v[4];
+        if (kind == 1) {
+            box_muller(r.v[0], r.v[1], v[0], v[1]);
+            box_muller(r.v[2], r.v[3], v[2], v[3]);
+        } else {
+            for (int l = 0; l < 4; ++l) {
+                const float u = u01(r.v[l]);
+                v[l] = (kind == 2) ? gumbel_from_u(u) : u;
+            }
+        }
+        for (int l = 0; l < 4 && sub * 4 + l < width; ++l) out[it * width + sub * 4 + l] = v[l];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void math_probe_kernel(int fn, const float* x, int64_t count, float* y)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        float r;
+        if (fn == 0) r = logf_(v);
+        else if (fn == 1) r = expf_(v);
+        else {
+            float s, c;
+            sincospif_(v, s, c);
+            r = (fn == 2) ? s : c;
+        }
+        y[i] = r;
+    }
+}
+
+inline unsigned flat_grid(int64_t work_items)
+{
+    int64_t blocks = cdiv(work_items, kBlock);
+    if (blocks > 2048) blocks = 2048;   // 256 CUs x 8 resident blocks; the rest is grid-strided
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+int mdx_abi_version(void) { return MDX_ABI_VERSION; }
+
+const char* mdx_status_string(int status)
+{
+    switch (status) {
+        case MDX_OK: return "ok";
+        case MDX_ERR_INVALID_ARG: return "invalid argument";
+        case MDX_ERR_UNSUPPORTED: return "unsupported size or option";
+        case MDX_ERR_HIP: return "HIP runtime error at launch";
+        default: return "unknown status";
+    }
+}
+
+int mdx_noise_schedule_build(int T, int schedule_type, double time_delta, double sigma_min, double sigma_max,
+                             double corrector_step_epsilon, int C, float* time, float* sigma, float* sigma_squared,
+                             float* g, float* g_squared, float* epsilon, float* sqrt_2_epsilon, float* beta,
+                             float* alpha_bar, float* q_matrix, float* q_bar_matrix, float* q_bar_tm1_matrix,
+                             mdx_stream_t stream)
+{
+    if (T < 2 || C < 2 || (schedule_type != 0 && schedule_type != 1)) return MDX_ERR_INVALID_ARG;
+    if (C > 2 * MDX_MAX_CLASSES) return MDX_ERR_UNSUPPORTED;
+    if (!time || !sigma || !sigma_squared || !g || !g_squared || !epsilon || !sqrt_2_epsilon || !beta || !alpha_bar ||
+        !q_matrix || !q_bar_matrix || !q_bar_tm1_matrix)
+        return MDX_ERR_INVALID_ARG;
+    ScheduleArgs a{T, schedule_type, C, time_delta, sigma_min, sigma_max, corrector_step_epsilon, time, sigma,
+                   sigma_squared, g, g_squared, epsilon, sqrt_2_epsilon, beta, alpha_bar, q_matrix, q_bar_matrix,
+                   q_bar_tm1_matrix};
+    hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), a);
+    return launch_status();
+}
+
+int mdx_index_set(int32_t* d_index, int32_t value, mdx_stream_t stream)
+{
+    if (!d_index) return MDX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(index_kernel, dim3(1), dim3(1), 0, as_stream(stream), d_index, value, 0);
+    return launch_status();
+}
+
+int mdx_index_add(int32_t* d_index, int32_t delta, mdx_stream_t stream)
+{
+    if (!d_index) return MDX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(index_kernel, dim3(1), dim3(1), 0, as_stream(stream), d_index, delta, 1);
+    return launch_status();
+}
+
+static int check_index(const mdx_schedule_t* s, int mode, int index_i, const int32_t* d_index)
+{
+    if (!s || (mode != MDX_PREDICTOR && mode != MDX_CORRECTOR)) return MDX_ERR_INVALID_ARG;
+    if (!d_index) {   // with a device-resident index the caller guarantees the range
+        if (mode == MDX_PREDICTOR && (index_i < 1 || index_i > s->total_time_steps)) return MDX_ERR_INVALID_ARG;
+        if (mode == MDX_CORRECTOR && (index_i < 0 || index_i > s->total_time_steps - 1)) return MDX_ERR_INVALID_ARG;
+    }
+    return MDX_OK;
+}
+
+int mdx_fill_time_sigma(const mdx_schedule_t* sched_host, int mode, int index_i, const int32_t* d_index,
+                        float* time_out, float* sigma_out, int64_t batch, mdx_stream_t stream)
+{
+    const int rc = check_index(sched_host, mode, index_i, d_index);
+    if (rc != MDX_OK) return rc;
+    if (!time_out || !sigma_out || batch < 0) return MDX_ERR_INVALID_ARG;
+    if (batch == 0) return MDX_OK;
+    hipLaunchKernelGGL(fill_time_sigma_kernel, dim3(flat_grid(batch)), dim3(kBlock), 0, as_stream(stream),
+                       to_dev(sched_host), mode, index_i, d_index, time_out, sigma_out, batch);
+    return launch_status();
+}
+
+int mdx_relative_coordinates_update(const float* x, const float* s, const float* z, float score_weight,
+                                    float gaussian_noise_weight, float sigma, int64_t count, float* out,
+                                    mdx_stream_t stream)
+{
+    if (count < 0 || (count > 0 && (!x || !s || !z || !out))) return MDX_ERR_INVALID_ARG;
+    if (count == 0) return MDX_OK;
+    if (aligned16(x) && aligned16(s) && aligned16(z) && aligned16(out))
+        hipLaunchKernelGGL(coords_update_kernel<4>, dim3(flat_grid(cdiv(count, 4))), dim3(kBlock), 0, as_stream(stream), x,
+                           s, z, score_weight, gaussian_noise_weight, sigma, count, out);
+    else
+        hipLaunchKernelGGL(coords_update_kernel<1>, dim3(flat_grid(count)), dim3(kBlock), 0, as_stream(stream), x, s, z,
+                           score_weight, gaussian_noise_weight, sigma, count, out);
+    return launch_status();
+}
+
+int mdx_lattice_parameters_update(const float* l, const float* s, const float* z, float score_weight,
+                                  float gaussian_noise_weight, float sigma_n, int64_t count, float* out,
+                                  mdx_stream_t stream)
+{
+    if (count < 0 || (count > 0 && (!l || !s || !z || !out))) return MDX_ERR_INVALID_ARG;
+    if (count == 0) return MDX_OK;
+    hipLaunchKernelGGL(lattice_update_kernel, dim3(flat_grid(count)), dim3(kBlock), 0, as_stream(stream), l, s, z,
+                       score_weight, gaussian_noise_weight, sigma_n, count, out);
+    return launch_status();
+}
+
+int mdx_atom_types_update(const float* logits, const int64_t* atom_types, const float* q, const float* q_bar,
+                          const float* q_bar_tm1, const float* gumbel, const float* u, int64_t batch,
+                          int number_of_atoms, int num_classes, float small_epsilon, int greedy, int one_transition,
+                          int64_t* atom_types_out, float* probabilities_out, mdx_stream_t stream)
+{
+    if (batch < 0 || number_of_atoms < 1) return MDX_ERR_INVALID_ARG;
+    if (num_classes < 2) return MDX_ERR_INVALID_ARG;
+    if (num_classes > MDX_MAX_CLASSES) return MDX_ERR_UNSUPPORTED;
+    if (batch == 0) return MDX_OK;
+    if (!logits || !atom_types || !q || !q_bar || !q_bar_tm1 || !gumbel || !atom_types_out || (greedy && !u))
+        return MDX_ERR_INVALID_ARG;
+    PcArgs a{};
+    a.use_tables = 0;
+    a.q_explicit = q; a.qbar_explicit = q_bar; a.qbar_tm1_explicit = q_bar_tm1;
+    a.greedy = greedy; a.one_transition = one_transition; a.update_types = 1;
+    a.small_eps = small_epsilon;
+    a.a = atom_types; a.logits = logits; a.gumbel = gumbel; a.u = u;
+    a.B = batch; a.N = number_of_atoms; a.C = num_classes; a.d = 3;
+    a.a_out = atom_types_out; a.p_out = probabilities_out;
+    return launch_pc(a, as_stream(stream));
+}
+
+int mdx_pc_step_update(const mdx_schedule_t* sched_host, int mode, int index_i, const int32_t* d_index,
+                       const mdx_pc_flags_t* f, const int64_t* atom_types, const float* x, const float* l,
+                       const float* logits, const float* score_x, const float* score_l, const float* z_coordinates,
+                       const float* gumbel, const float* u, const float* z_lattice, mdx_rng_t rng, int64_t batch,
+                       int number_of_atoms, int spatial_dimension, int64_t* atom_types_out, float* x_out, float* l_out,
+                       uint32_t* status, mdx_stream_t stream)
+{
+    const int rc = check_index(sched_host, mode, index_i, d_index);
+    if (rc != MDX_OK) return rc;
+    if (!f || batch < 0 || number_of_atoms < 1 || spatial_dimension < 1 || spatial_dimension > 3) return MDX_ERR_INVALID_ARG;
+    const int C = sched_host->num_classes;
+    if (C < 2) return MDX_ERR_INVALID_ARG;
+    if (C > MDX_MAX_CLASSES) return MDX_ERR_UNSUPPORTED;
+    if (batch == 0) return MDX_OK;
+    if (!x || !score_x || !x_out || !l || !l_out) return MDX_ERR_INVALID_ARG;
+    if (f->update_atom_types && (!atom_types || !logits || !atom_types_out)) return MDX_ERR_INVALID_ARG;
+    if (!f->use_fixed_lattice_parameters && !score_l) return MDX_ERR_INVALID_ARG;
+    if ((int64_t)batch * number_of_atoms > 0xffffffffLL) return MDX_ERR_UNSUPPORTED;   // 32-bit Philox item index
+    PcArgs a{};
+    a.sched = to_dev(sched_host);
+    a.use_tables = 1;
+    a.mode = mode; a.index_i = index_i; a.d_index = d_index;
+    a.atoms_pow = pow((double)number_of_atoms, 1.0 / (double)spatial_dimension);
+    a.greedy = f->atom_type_greedy_sampling; a.one_transition = f->one_atom_type_transition_per_step;
+    a.fixed_lattice = f->use_fixed_lattice_parameters; a.update_types = f->update_atom_types;
+    a.do_coords = 1; a.do_lattice = 1;
+    a.small_eps = f->small_epsilon;
+    a.a = atom_types; a.x = x; a.l = l; a.logits = logits; a.score_x = score_x; a.score_l = score_l;
+    a.z_coord = z_coordinates; a.gumbel = gumbel; a.u = u; a.z_lat = z_lattice;
+    a.rng = rng;
+    a.B = batch; a.N = number_of_atoms; a.d = spatial_dimension; a.C = C;
+    a.nl = spatial_dimension * (spatial_dimension + 1) / 2;
+    a.a_out = atom_types_out; a.x_out = x_out; a.l_out = l_out; a.p_out = nullptr;
+    a.status = status;
+    return launch_pc(a, as_stream(stream));
+}
+
+int mdx_noise_relative_coordinates(const float* x0, const float* z, float sigma, int64_t count, float* out,
+                                   mdx_stream_t stream)
+{
+    if (count < 0 || (count > 0 && (!x0 || !z || !out))) return MDX_ERR_INVALID_ARG;
+    if (count == 0) return MDX_OK;
+    hipLaunchKernelGGL(noise_coords_kernel, dim3(flat_grid(count)), dim3(kBlock), 0, as_stream(stream), x0, z, sigma,
+                       count, out);
+    return launch_status();
+}
+
+int mdx_noise_atom_types(const int64_t* a0, const float* q_bar, const float* u, int64_t n_atoms, int num_classes,
+                         int64_t* out, mdx_stream_t stream)
+{
+    if (n_atoms < 0 || num_classes < 2) return MDX_ERR_INVALID_ARG;
+    if (num_classes > MDX_MAX_CLASSES) return MDX_ERR_UNSUPPORTED;
+    if (n_atoms == 0) return MDX_OK;
+    if (!a0 || !q_bar || !u || !out) return MDX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(noise_atom_types_kernel, dim3(flat_grid(n_atoms)), dim3(kBlock), 0, as_stream(stream), a0, q_bar,
+                       u, n_atoms, num_classes, out);
+    return launch_status();
+}
+
+int mdx_repaint_constrained_rows(const mdx_schedule_t* sched_host, int index_i, const int32_t* d_index,
+                                 const float* constrained_x, const int64_t* constrained_a,
+                                 const int64_t* constrained_indices, int number_of_constraints, const float* z,
+                                 const float* u, mdx_rng_t rng, int64_t batch, int number_of_atoms,
+                                 int spatial_dimension, float* x_inout, int64_t* a_inout, mdx_stream_t stream)
+{
+    if (!sched_host || batch < 0 || number_of_constraints < 0 || number_of_atoms < 1) return MDX_ERR_INVALID_ARG;
+    if (spatial_dimension < 1 || spatial_dimension > 3 || number_of_constraints > number_of_atoms) return MDX_ERR_INVALID_ARG;
+    if (!d_index && (index_i < 0 || index_i > sched_host->total_time_steps)) return MDX_ERR_INVALID_ARG;
+    if (sched_host->num_classes > MDX_MAX_CLASSES) return MDX_ERR_UNSUPPORTED;
+    if (batch == 0 || number_of_constraints == 0) return MDX_OK;
+    if (!constrained_x || !constrained_a || !constrained_indices || !x_inout || !a_inout) return MDX_ERR_INVALID_ARG;
+    RepaintArgs a{};
+    a.sched = to_dev(sched_host);
+    a.index_i = index_i; a.d_index = d_index;
+    a.cx = constrained_x; a.ca = constrained_a; a.cidx = constrained_indices; a.K = number_of_constraints;
+    a.z = z; a.u = u; a.rng = rng;
+    a.B = batch; a.N = number_of_atoms; a.d = spatial_dimension; a.C = sched_host->num_classes;
+    a.x = x_inout; a.a = a_inout;
+    hipLaunchKernelGGL(repaint_rows_kernel, dim3(flat_grid(batch * number_of_constraints)), dim3(kBlock), 0,
+                       as_stream(stream), a);
+    return launch_status();
+}
+
+static int radius_graph_args_ok(const float* cart, const float* cell, float rc, int64_t batch, int N)
+{
+    if (batch < 0 || N < 1 || !(rc > 0.0f)) return MDX_ERR_INVALID_ARG;
+    if (N > 5000) return MDX_ERR_UNSUPPORTED;    // structure tile (12 B per atom) kept under the 64 KiB default dynamic-LDS limit
+    if (batch > 0 && (!cart || !cell)) return MDX_ERR_INVALID_ARG;
+    return MDX_OK;
+}
+
+int mdx_radius_graph_count(const float* cart, const float* cell, float rc, int64_t batch, int N, int unique,
+                           int64_t* counts, uint32_t* status, mdx_stream_t stream)
+{
+    const int ok = radius_graph_args_ok(cart, cell, rc, batch, N);
+    if (ok != MDX_OK) return ok;
+    if (batch == 0) return MDX_OK;
+    if (!counts) return MDX_ERR_INVALID_ARG;
+    const int chunks = (int)cdiv(N, kRowsPerBlock);
+    const size_t lds = sizeof(float) * (3 * (size_t)N + 81);
+    hipLaunchKernelGGL(radius_graph_kernel<false>, dim3((unsigned)(batch * chunks)), dim3(kBlock), lds, as_stream(stream),
+                       cart, cell, rc, batch, N, unique, chunks, counts, (const int64_t*)nullptr, (int64_t*)nullptr,
+                       (int32_t*)nullptr, (float*)nullptr, status);
+    return launch_status();
+}
+
+int mdx_radius_graph_fill(const float* cart, const float* cell, float rc, int64_t batch, int N, int unique,
+                          const int64_t* offsets, int64_t* edges_out, int32_t* image_out, float* shifts_out,
+                          mdx_stream_t stream)
+{
+    const int ok = radius_graph_args_ok(cart, cell, rc, batch, N);
+    if (ok != MDX_OK) return ok;
+    if (batch == 0) return MDX_OK;
+    if (!offsets || !edges_out || (!unique && !image_out)) return MDX_ERR_INVALID_ARG;
+    const int chunks = (int)cdiv(N, kRowsPerBlock);
+    const size_t lds = sizeof(float) * (3 * (size_t)N + 81);
+    hipLaunchKernelGGL(radius_graph_kernel<true>, dim3((unsigned)(batch * chunks)), dim3(kBlock), lds, as_stream(stream),
+                       cart, cell, rc, batch, N, unique, chunks, (int64_t*)nullptr, offsets, edges_out, image_out,
+                       shifts_out, (uint32_t*)nullptr);
+    return launch_status();
+}
+
+int mdx_rng_fill(int kind, uint64_t seed, uint32_t call, uint32_t draw, uint32_t tag, int64_t n_items, int width,
+                 float* out, mdx_stream_t stream)
+{
+    if (kind < 0 || kind > 2 || n_items < 0 || width < 1 || width > 1024) return MDX_ERR_INVALID_ARG;
+    if (n_items > 0xffffffffLL) return MDX_ERR_UNSUPPORTED;
+    if (n_items == 0) return MDX_OK;
+    if (!out) return MDX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(rng_fill_kernel, dim3(flat_grid(n_items * ((width + 3) / 4))), dim3(kBlock), 0, as_stream(stream),
+                       kind, seed, call, draw, tag, n_items, width, out);
+    return launch_status();
+}
+
+int mdx_math_probe(int fn, const float* x, int64_t count, float* y, mdx_stream_t stream)
+{
+    if (fn < 0 || fn > 3 || count < 0 || (count > 0 && (!x || !y))) return MDX_ERR_INVALID_ARG;
+    if (count == 0) return MDX_OK;
+    hipLaunchKernelGGL(math_probe_kernel, dim3(flat_grid(count)), dim3(kBlock), 0, as_stream(stream), fn, x, count, y);
+    return launch_status();
+}
+
+}  // extern "C"

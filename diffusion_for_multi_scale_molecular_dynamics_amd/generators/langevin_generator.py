@@ -1,0 +1,326 @@
+"""Annealed Langevin / predictor-corrector generator on the MI355X hot path.
+
+Same class name, constructor, step methods and behaviour as the reference's LangevinGenerator
+(src/.../generators/langevin_generator.py:27-831); what differs is where the work runs:
+
+  * the schedule tables are built once on the device (kernel S1) and indexed there;
+  * everything after the score-network forward -- D3PM posterior + greedy/one-transition atom-type draw (P2),
+    coordinate update + periodic wrap (P1), lattice update (P3) -- is ONE fused kernel launch per step
+    (mdx_pc_step_update), with per-structure reductions done by wavefront shuffles;
+  * no per-step host synchronisation: the reference's asserts are collected in a device status word that is read
+    once at the end of sample();
+  * rng_mode="device" removes the per-step CPU draws + PCIe uploads, and use_hip_graph=True replays one captured
+    predictor+correctors iteration T times with the step index living on the device.
+
+There is no CPU fallback: calling this generator with device="cpu" raises.
+"""
+import dataclasses
+from typing import Optional
+
+import torch
+
+from .. import kernels
+from .._hip import MDX_CORRECTOR, MDX_PREDICTOR, STATUS_MASK_AT_LAST_STEP, MdxError, PcFlags, Rng
+from ..models.score_networks.score_network import ScoreNetwork
+from ..namespace import AXL, CARTESIAN_FORCES, NOISE, NOISY_AXL_COMPOSITION, TIME
+from ..noise_schedulers.noise_parameters import NoiseParameters
+from ..noise_schedulers.noise_scheduler import NoiseScheduler
+from ..utils.sample_trajectory import SampleTrajectory
+from .noise_sources import DevicePhiloxNoise, ReferenceOrderNoise
+from .predictor_corrector_axl_generator import PredictorCorrectorAXLGenerator, PredictorCorrectorSamplingParameters
+from .trajectory_initializer import TrajectoryInitializer
+
+
+class LangevinGenerator(PredictorCorrectorAXLGenerator):
+    def __init__(self, noise_parameters: NoiseParameters, sampling_parameters: PredictorCorrectorSamplingParameters,
+                 axl_network: ScoreNetwork, trajectory_initializer: Optional[TrajectoryInitializer] = None):
+        sp = sampling_parameters
+        super().__init__(number_of_discretization_steps=noise_parameters.total_time_steps,
+                         number_of_corrector_steps=sp.number_of_corrector_steps,
+                         spatial_dimension=sp.spatial_dimension, num_atom_types=sp.num_atom_types,
+                         number_of_atoms=sp.number_of_atoms,
+                         use_fixed_lattice_parameters=sp.use_fixed_lattice_parameters,
+                         fixed_lattice_parameters=sp.fixed_lattice_parameters,
+                         trajectory_initializer=trajectory_initializer)
+        self.noise_parameters = noise_parameters
+        self.sampling_parameters = sp
+        self.number_of_atoms = sp.number_of_atoms
+        self.masked_atom_type_index = self.num_classes - 1
+        self.axl_network = axl_network
+        self.small_epsilon = sp.small_epsilon
+        self.one_atom_type_transition_per_step = sp.one_atom_type_transition_per_step
+        self.atom_type_greedy_sampling = sp.atom_type_greedy_sampling
+        self.atom_type_transition_in_corrector = sp.atom_type_transition_in_corrector
+        self.use_fixed_lattice_parameters = sp.use_fixed_lattice_parameters
+        self.fixed_lattice_parameters = sp.fixed_lattice_parameters
+
+        self.record = sp.record_samples
+        self.record_corrector = sp.record_samples_corrector_steps
+        self.record_atom_type_update = sp.record_atom_type_update
+        if self.record_corrector or self.record_atom_type_update:
+            assert self.record, "Corrector steps or atom_type_update can only be recorded if record_samples is True."
+
+        rng_mode = getattr(sp, "rng_mode", "reference")
+        assert rng_mode in ("reference", "device"), f"unknown rng_mode {rng_mode}"
+        self.rng_mode = rng_mode
+        self.use_hip_graph = bool(getattr(sp, "use_hip_graph", False))
+        self._seed = getattr(sp, "seed", None)
+        self._call_counter = 0
+        self.noise_source = ReferenceOrderNoise() if rng_mode == "reference" else None
+
+        self._scheduler = None       # device tables, built on first use for the sampling device
+        self._status = None
+        self._buffers = {}
+        if self.record:
+            self.sample_trajectory_recorder = SampleTrajectory()
+            self.sample_trajectory_recorder.record(key="noise_parameters", entry=dataclasses.asdict(noise_parameters))
+            self.sample_trajectory_recorder.record(key="sampling_parameters",
+                                                   entry={k: v for k, v in dataclasses.asdict(sp).items()})
+
+    # ---------------------------------------------------------------------------------------------------------
+    # device state
+    # ---------------------------------------------------------------------------------------------------------
+    def _prepare(self, device: torch.device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise MdxError(f"LangevinGenerator runs on the GPU hot path only; got device '{device}' "
+                           "(there is no CPU fallback -- use the reference implementation on CPU)")
+        if self._scheduler is None or self._scheduler.tables.device != device:
+            self._scheduler = NoiseScheduler(self.noise_parameters, num_classes=self.num_classes, device=device)
+            self.noise, self.langevin_dynamics = self._scheduler.get_all_sampling_parameters()
+            self._status = torch.zeros(1, dtype=torch.int32, device=device)
+            self._buffers = {}
+            if self.record:
+                self.sample_trajectory_recorder.record(
+                    key="noise", entry=type(self.noise)(*[t.detach().cpu() for t in self.noise]))
+        return self._scheduler.tables
+
+    def _time_sigma(self, batch: int, device):
+        key = ("ts", batch)
+        if key not in self._buffers:
+            self._buffers[key] = (torch.empty(batch, 1, dtype=torch.float32, device=device),
+                                  torch.empty(batch, 1, dtype=torch.float32, device=device))
+        return self._buffers[key]
+
+    def _flags(self, update_atom_types: bool) -> PcFlags:
+        return PcFlags(int(self.atom_type_greedy_sampling), int(self.one_atom_type_transition_per_step),
+                       int(self.use_fixed_lattice_parameters), int(update_atom_types), float(self.small_epsilon))
+
+    def _rng(self, draw_offset: int) -> Rng:
+        src = self.noise_source
+        seed, call = (src.seed, src.call) if getattr(src, "device_rng", False) else (0, 0)
+        return Rng(seed, call, self.number_of_corrector_steps + 1, draw_offset)
+
+    def _begin_call(self, device):
+        """One sample() call = one Philox `call` index; the trajectory initialiser shares the noise source."""
+        if self.rng_mode == "device":
+            seed = self._seed if self._seed is not None else torch.initial_seed()
+            rank = torch.distributed.get_rank() if torch.distributed.is_available() and \
+                torch.distributed.is_initialized() else 0
+            self.noise_source = DevicePhiloxNoise(seed + rank, self._call_counter)
+            self._call_counter += 1
+        if hasattr(self.trajectory_initializer, "noise_source"):
+            self.trajectory_initializer.noise_source = self.noise_source
+
+    # ---------------------------------------------------------------------------------------------------------
+    # reference-compatible draw hooks (CPU generator, reference order); tests may patch them like the reference's
+    # ---------------------------------------------------------------------------------------------------------
+    def _draw_coordinates_gaussian_sample(self, number_of_samples):
+        return self.noise_source.randn(number_of_samples, self.number_of_atoms, self.spatial_dimension)
+
+    def _draw_lattice_gaussian_sample(self, number_of_samples):
+        return self.noise_source.randn(number_of_samples, self.num_lattice_parameters)
+
+    def _draw_gumbel_sample(self, number_of_samples):
+        u = self.noise_source.rand(number_of_samples, self.number_of_atoms, self.num_classes)
+        return -torch.log(-torch.log(u.clip(min=self.small_epsilon)))
+
+    def _draw_binary_sample(self, number_of_samples):
+        return self.noise_source.rand(number_of_samples, self.number_of_atoms)
+
+    # ---------------------------------------------------------------------------------------------------------
+    # network
+    # ---------------------------------------------------------------------------------------------------------
+    def _get_model_predictions(self, composition: AXL, time_tensor: torch.Tensor, sigma_noise_tensor: torch.Tensor,
+                               cartesian_forces: torch.Tensor) -> AXL:
+        batch = {NOISY_AXL_COMPOSITION: composition, TIME: time_tensor, NOISE: sigma_noise_tensor,
+                 CARTESIAN_FORCES: cartesian_forces}
+        return self.axl_network(batch, conditional=False)
+
+    # ---------------------------------------------------------------------------------------------------------
+    # one step = network forward + ONE fused update kernel
+    # ---------------------------------------------------------------------------------------------------------
+    def _step(self, mode: int, composition: AXL, index_i: int, cartesian_forces: torch.Tensor, draw_offset: int,
+              d_index: Optional[torch.Tensor] = None, in_place: bool = False):
+        x = composition.X
+        device = x.device
+        sched = self._prepare(device)
+        batch = x.shape[0]
+        time_t, sigma_t = self._time_sigma(batch, device)
+        kernels.fill_time_sigma(sched, mode, index_i, d_index, time_t, sigma_t)
+        predictions = self._get_model_predictions(composition, time_t, sigma_t, cartesian_forces)
+
+        update_types = mode == MDX_PREDICTOR or self.atom_type_transition_in_corrector
+        z = gumbel = u = z_lattice = None
+        if not getattr(self.noise_source, "device_rng", False):
+            if mode == MDX_PREDICTOR:                                  # langevin_generator.py:280,416,623,633
+                gumbel = self._draw_gumbel_sample(batch)
+                if self.atom_type_greedy_sampling:
+                    u = self._draw_binary_sample(batch)
+                z = self._draw_coordinates_gaussian_sample(batch)
+                z_lattice = self._draw_lattice_gaussian_sample(batch)
+            else:                                                      # :740,761,480-483,779-792
+                z = self._draw_coordinates_gaussian_sample(batch)
+                self._draw_lattice_gaussian_sample(batch)              # drawn by the reference, never used
+                if not self.use_fixed_lattice_parameters:
+                    z_lattice = self._draw_lattice_gaussian_sample(batch)
+                if update_types:
+                    gumbel = self._draw_gumbel_sample(batch)
+                    if self.atom_type_greedy_sampling:
+                        u = self._draw_binary_sample(batch)
+            if self.use_fixed_lattice_parameters:
+                z_lattice = None
+            z, gumbel, u, z_lattice = [None if t is None else t.to(device=device, dtype=torch.float32).contiguous()
+                                       for t in (z, gumbel, u, z_lattice)]
+            if not self.use_fixed_lattice_parameters and z_lattice is None:
+                raise MdxError("internal error: lattice noise missing")
+
+        a_in = composition.A
+        if update_types:
+            a_out = a_in if in_place else torch.empty_like(a_in)
+        else:
+            a_out = a_in
+        x_out = x if in_place else torch.empty_like(x)
+        if self.use_fixed_lattice_parameters or in_place:
+            l_out = composition.L
+        else:
+            l_out = torch.empty_like(composition.L)
+        logits = predictions.A.contiguous() if update_types else None
+        kernels.pc_step_update(sched, mode, index_i, d_index, self._flags(update_types),
+                               a_in if update_types else None, x, composition.L, logits,
+                               predictions.X.contiguous(),
+                               None if self.use_fixed_lattice_parameters else predictions.L.contiguous(),
+                               z, gumbel, u, z_lattice, self._rng(draw_offset),
+                               a_out if update_types else None, x_out, l_out, self._status)
+        return AXL(A=a_out, X=x_out, L=l_out), predictions
+
+    def predictor_step(self, composition_i: AXL, index_i: int, cartesian_forces: torch.Tensor) -> AXL:
+        """composition at time index i -> i-1  (langevin_generator.py:536-645)."""
+        assert 1 <= index_i <= self.number_of_discretization_steps, \
+            "The predictor step can only be invoked for index_i between 1 and the total number of discretization steps."
+        composition_im1, predictions = self._step(MDX_PREDICTOR, composition_i, index_i, cartesian_forces, 0)
+        if self.record:
+            self._record_step("predictor_step", ["composition_i", "composition_im1", "model_predictions_i"],
+                              [composition_i, composition_im1, predictions], index_i)
+        return composition_im1
+
+    def corrector_step(self, composition_i: AXL, index_i: int, cartesian_forces: torch.Tensor,
+                       corrector_number: int = 0) -> AXL:
+        """Langevin corrector at time index i  (langevin_generator.py:693-805)."""
+        assert 0 <= index_i <= self.number_of_discretization_steps - 1, \
+            "The corrector step can only be invoked for index_i between 0 and the total number of " \
+            "discretization steps minus 1."
+        corrected, predictions = self._step(MDX_CORRECTOR, composition_i, index_i, cartesian_forces,
+                                            1 + corrector_number)
+        if self.record_corrector:
+            self._record_step("corrector_step", ["composition_i", "corrected_composition_i", "model_predictions_i"],
+                              [composition_i, corrected, predictions], index_i)
+        return corrected
+
+    def _record_step(self, key, names, axls, index_i):
+        entry = dict(time_step_index=index_i)
+        for name, axl in zip(names, axls):
+            entry[name] = AXL(A=axl.A.detach().cpu(), X=axl.X.detach().cpu(), L=axl.L.detach().cpu())
+        self.sample_trajectory_recorder.record(key=key, entry=entry)
+
+    # ---------------------------------------------------------------------------------------------------------
+    # loops
+    # ---------------------------------------------------------------------------------------------------------
+    def _after_predictor(self, composition: AXL, index_i: int, d_index=None) -> AXL:
+        """Hook for the repaint generator."""
+        return composition
+
+    def sample_from_noisy_composition(self, starting_noisy_composition: AXL, starting_step_index: int,
+                                      ending_step_index: int) -> AXL:
+        assert starting_step_index > ending_step_index, \
+            "It is nonsensical for starting_step_index to be smaller or equal to ending_step_index."
+        assert starting_step_index > 0, "Starting step should be larger than zero."
+        assert ending_step_index >= 0, "ending step should be larger or equal to zero."
+        self._prepare(starting_noisy_composition.X.device)
+        if self.noise_source is None:
+            self._begin_call(starting_noisy_composition.X.device)
+        if self.use_hip_graph and getattr(self.noise_source, "device_rng", False) and not self.record:
+            return self._sample_with_graph(starting_noisy_composition, starting_step_index, ending_step_index)
+        composition = starting_noisy_composition
+        forces = torch.zeros_like(composition.X)
+        for i in range(starting_step_index - 1, max(ending_step_index, 0) - 1, -1):
+            composition = self.predictor_step(composition, i + 1, forces)
+            for m in range(self.number_of_corrector_steps):
+                composition = self.corrector_step(composition, i, forces, m)
+        return composition
+
+    def _iteration_on_device_index(self, comp: AXL, forces: torch.Tensor, d_index: torch.Tensor):
+        """One predictor + M correctors with the loop variable i read from *d_index on the device; in place."""
+        comp, _ = self._step(MDX_PREDICTOR, comp, 1, forces, 0, d_index=d_index, in_place=True)
+        comp = self._after_predictor(comp, 0, d_index=d_index)
+        for m in range(self.number_of_corrector_steps):
+            comp, _ = self._step(MDX_CORRECTOR, comp, 0, forces, 1 + m, d_index=d_index, in_place=True)
+        kernels.index_add(d_index, -1)
+        return comp
+
+    def _sample_with_graph(self, start: AXL, starting_step_index: int, ending_step_index: int) -> AXL:
+        """Capture one iteration into a hipGraph (torch.cuda.CUDAGraph) and replay it; state lives in static
+        buffers, the step index on the device.  The network must be capture-safe (no host syncs)."""
+        device = start.X.device
+        n_iter = starting_step_index - max(ending_step_index, 0)
+        comp = AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
+        forces = torch.zeros_like(comp.X)
+        d_index = torch.zeros(1, dtype=torch.int32, device=device)
+        key = ("graph", comp.X.shape, self.noise_source.seed, self.noise_source.call)
+        # warm-up on a side stream (allocator / BLAS workspaces), then restore the state
+        saved = AXL(A=comp.A.clone(), X=comp.X.clone(), L=comp.L.clone())
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            kernels.index_set(d_index, starting_step_index - 1)
+            for _ in range(2):
+                self._iteration_on_device_index(comp, forces, d_index)
+        torch.cuda.current_stream(device).wait_stream(side)
+        comp.A.copy_(saved.A)
+        comp.X.copy_(saved.X)
+        comp.L.copy_(saved.L)
+        self._status.zero_()
+        graph = torch.cuda.CUDAGraph()
+        kernels.index_set(d_index, starting_step_index - 1)
+        with torch.cuda.graph(graph):
+            self._iteration_on_device_index(comp, forces, d_index)
+        # the capture itself does not execute; replay all iterations
+        for _ in range(n_iter):
+            graph.replay()
+        self._buffers[key] = graph      # keep alive until the next call
+        return comp
+
+    def check_status(self):
+        """Read the device status word once (the only host synchronisation of a sample() call)."""
+        if self._status is None:
+            return
+        word = int(self._status.item())
+        self._status.zero_()
+        if word & STATUS_MASK_AT_LAST_STEP:
+            # the reference asserts inside the last predictor step (langevin_generator.py:616-620)
+            raise AssertionError("There remains MASKED atoms at the last time step: review code, there must be a "
+                                 "bug or invalid input.")
+        net_status = getattr(self.axl_network, "graph_status", None)
+        if net_status is not None:
+            from ..utils.neighbors import _raise_if_cutoff_too_large
+            _raise_if_cutoff_too_large(net_status)
+            net_status.zero_()
+
+    def sample(self, number_of_samples: int, device: torch.device) -> AXL:
+        self._prepare(device)
+        self._begin_call(torch.device(device))
+        composition = super().sample(number_of_samples, device)
+        self.check_status()
+        if self.rng_mode == "device":
+            self.noise_source = None
+        return composition

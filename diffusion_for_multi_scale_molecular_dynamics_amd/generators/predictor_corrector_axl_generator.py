@@ -1,0 +1,84 @@
+"""Predictor-corrector generator skeleton (src/.../generators/predictor_corrector_axl_generator.py:22-204)."""
+from abc import abstractmethod
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from ..namespace import AXL
+from ..utils.basis_transformations import get_number_of_lattice_parameters
+from .axl_generator import AXLGenerator, SamplingParameters
+from .trajectory_initializer import (FullRandomTrajectoryInitializer, TrajectoryInitializer,
+                                     TrajectoryInitializerParameters)
+
+
+@dataclass(kw_only=True)
+class PredictorCorrectorSamplingParameters(SamplingParameters):
+    """Reference fields (:22-30) plus three build-only switches (all default to the reference's behaviour)."""
+
+    algorithm: str = "predictor_corrector"
+    number_of_corrector_steps: int = 1
+    small_epsilon: float = 1e-8
+    one_atom_type_transition_per_step: bool = True
+    atom_type_greedy_sampling: bool = True
+    atom_type_transition_in_corrector: bool = False
+    # --- build-only ---
+    rng_mode: str = "reference"      # "reference": torch CPU generator, reference draw order (parity mode);
+    #                                  "device": counter-based Philox inside the kernels (throughput mode)
+    seed: Optional[int] = None       # device mode: Philox key (rank is added to it); None -> torch.initial_seed()
+    use_hip_graph: bool = False      # device mode: capture one predictor+correctors iteration and replay it
+
+
+class PredictorCorrectorAXLGenerator(AXLGenerator):
+    """for i in T-1..0: predictor(i+1); M x corrector(i)."""
+
+    def __init__(self, number_of_discretization_steps: int, number_of_corrector_steps: int, spatial_dimension: int,
+                 num_atom_types: int, number_of_atoms: int, use_fixed_lattice_parameters: bool = False,
+                 fixed_lattice_parameters: Optional[torch.Tensor] = None,
+                 trajectory_initializer: Optional[TrajectoryInitializer] = None, **kwargs):
+        assert number_of_discretization_steps > 1, "The number of discretization steps should be larger than one"
+        assert number_of_corrector_steps >= 0, "The number of corrector steps should be non-negative"
+        self.number_of_discretization_steps = number_of_discretization_steps
+        self.number_of_corrector_steps = number_of_corrector_steps
+        self.spatial_dimension = spatial_dimension
+        self.num_classes = num_atom_types + 1
+        self.num_lattice_parameters = get_number_of_lattice_parameters(spatial_dimension)
+        if trajectory_initializer is not None:
+            self.trajectory_initializer = trajectory_initializer
+        else:
+            self.trajectory_initializer = FullRandomTrajectoryInitializer(TrajectoryInitializerParameters(
+                spatial_dimension=spatial_dimension, num_atom_types=num_atom_types, number_of_atoms=number_of_atoms,
+                use_fixed_lattice_parameters=use_fixed_lattice_parameters,
+                fixed_lattice_parameters=fixed_lattice_parameters))
+
+    def initialize(self, number_of_samples: int, device: torch.device) -> AXL:
+        return self.trajectory_initializer.initialize(number_of_samples, device)
+
+    def sample(self, number_of_samples: int, device: torch.device) -> AXL:
+        start = self.initialize(number_of_samples, device)
+        first = self.trajectory_initializer.create_start_time_step_index(self.number_of_discretization_steps)
+        last = self.trajectory_initializer.create_end_time_step_index()
+        return self.sample_from_noisy_composition(starting_noisy_composition=start, starting_step_index=first,
+                                                  ending_step_index=last)
+
+    def sample_from_noisy_composition(self, starting_noisy_composition: AXL, starting_step_index: int,
+                                      ending_step_index: int) -> AXL:
+        assert starting_step_index > ending_step_index, \
+            "It is nonsensical for starting_step_index to be smaller or equal to ending_step_index."
+        assert starting_step_index > 0, "Starting step should be larger than zero."
+        assert ending_step_index >= 0, "ending step should be larger or equal to zero."
+        composition = starting_noisy_composition
+        forces = torch.zeros_like(composition.X)
+        for i in range(starting_step_index - 1, max(ending_step_index, 0) - 1, -1):
+            composition = self.predictor_step(composition, i + 1, forces)
+            for _ in range(self.number_of_corrector_steps):
+                composition = self.corrector_step(composition, i, forces)
+        return composition
+
+    @abstractmethod
+    def predictor_step(self, composition_ip1: AXL, ip1: int, cartesian_forces: torch.Tensor) -> AXL:
+        pass
+
+    @abstractmethod
+    def corrector_step(self, composition_i: AXL, i: int, cartesian_forces: torch.Tensor) -> AXL:
+        pass

@@ -1,0 +1,235 @@
+"""Tensor-level wrappers of the C ABI (include/mdx_hip.h).
+
+Each function validates shapes/dtypes, passes raw device pointers + torch's current HIP stream to the shared
+library, and returns torch tensors that PyTorch owns.  Nothing here computes on the CPU.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _hip
+from ._hip import MDX_CORRECTOR, MDX_PREDICTOR, PcFlags, Rng, Schedule, check, lib, ptr, stream_handle
+
+F32, I64, I32 = torch.float32, torch.int64, torch.int32
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# S1
+# ----------------------------------------------------------------------------------------------------------------
+@dataclass
+class DeviceSchedule:
+    """Device-resident schedule tables + the mdx_schedule_t view handed to the kernels."""
+
+    total_time_steps: int
+    num_classes: int
+    sigma_min: float
+    time: torch.Tensor
+    sigma: torch.Tensor
+    sigma_squared: torch.Tensor
+    g: torch.Tensor
+    g_squared: torch.Tensor
+    epsilon: torch.Tensor
+    sqrt_2_epsilon: torch.Tensor
+    beta: torch.Tensor
+    alpha_bar: torch.Tensor
+    q_matrix: torch.Tensor
+    q_bar_matrix: torch.Tensor
+    q_bar_tm1_matrix: torch.Tensor
+
+    def __post_init__(self):
+        self.c_struct = Schedule(self.total_time_steps, self.num_classes, float(self.sigma_min),
+                                 self.time.data_ptr(), self.sigma.data_ptr(), self.g.data_ptr(),
+                                 self.g_squared.data_ptr(), self.epsilon.data_ptr(), self.q_matrix.data_ptr(),
+                                 self.q_bar_matrix.data_ptr(), self.q_bar_tm1_matrix.data_ptr())
+
+    @property
+    def device(self):
+        return self.time.device
+
+
+def noise_schedule_build(total_time_steps: int, schedule_type: str, time_delta: float, sigma_min: float,
+                         sigma_max: float, corrector_step_epsilon: float, num_classes: int,
+                         device: torch.device) -> DeviceSchedule:
+    """S1: build the variance-exploding schedule tables on the device (mdx_noise_schedule_build)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _hip.MdxError(f"schedule tables are built on the GPU; got device {device}")
+    T, Cn = int(total_time_steps), int(num_classes)
+    st = {"exponential": 0, "linear": 1}[schedule_type]
+    with torch.cuda.device(device):
+        vec = [torch.empty(T, dtype=F32, device=device) for _ in range(9)]
+        mats = [torch.empty(T, Cn, Cn, dtype=F32, device=device) for _ in range(3)]
+        rc = lib().mdx_noise_schedule_build(T, st, float(time_delta), float(sigma_min), float(sigma_max),
+                                            float(corrector_step_epsilon), Cn,
+                                            *[C.c_void_p(t.data_ptr()) for t in vec + mats], stream_handle())
+    check(rc, "mdx_noise_schedule_build")
+    time, sigma, sigma2, g, g2, eps, s2e, beta, ab = vec
+    q, qb, qbm = mats
+    return DeviceSchedule(T, Cn, float(sigma_min), time, sigma, sigma2, g, g2, eps, s2e, beta, ab, q, qb, qbm)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# step index / network inputs
+# ----------------------------------------------------------------------------------------------------------------
+def index_set(d_index: torch.Tensor, value: int):
+    check(lib().mdx_index_set(ptr(d_index, I32, "d_index"), int(value), stream_handle()), "mdx_index_set")
+
+
+def index_add(d_index: torch.Tensor, delta: int):
+    check(lib().mdx_index_add(ptr(d_index, I32, "d_index"), int(delta), stream_handle()), "mdx_index_add")
+
+
+def fill_time_sigma(sched: DeviceSchedule, mode: int, index_i: int, d_index: Optional[torch.Tensor],
+                    time_out: torch.Tensor, sigma_out: torch.Tensor):
+    batch = time_out.numel()
+    assert sigma_out.numel() == batch
+    rc = lib().mdx_fill_time_sigma(C.byref(sched.c_struct), mode, int(index_i), ptr(d_index, I32, "d_index"),
+                                   ptr(time_out, F32, "time_out"), ptr(sigma_out, F32, "sigma_out"), batch,
+                                   stream_handle())
+    check(rc, "mdx_fill_time_sigma")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# P1 / P2 / P3 with explicit operands (mirror the reference's private update methods)
+# ----------------------------------------------------------------------------------------------------------------
+def relative_coordinates_update(x, s, z, score_weight: float, gaussian_noise_weight: float, sigma: float, out=None):
+    assert x.shape == s.shape == z.shape
+    out = torch.empty_like(x) if out is None else out
+    rc = lib().mdx_relative_coordinates_update(ptr(x, F32, "x"), ptr(s, F32, "sigma_normalized_scores"),
+                                               ptr(z, F32, "z"), float(score_weight), float(gaussian_noise_weight),
+                                               float(sigma), x.numel(), ptr(out, F32, "out"), stream_handle())
+    check(rc, "mdx_relative_coordinates_update")
+    return out
+
+
+def lattice_parameters_update(l, s, z, score_weight: float, gaussian_noise_weight: float, sigma_n: float, out=None):
+    assert l.shape == s.shape == z.shape
+    out = torch.empty_like(l) if out is None else out
+    rc = lib().mdx_lattice_parameters_update(ptr(l, F32, "l"), ptr(s, F32, "sigma_normalized_scores"),
+                                             ptr(z, F32, "z"), float(score_weight), float(gaussian_noise_weight),
+                                             float(sigma_n), l.numel(), ptr(out, F32, "out"), stream_handle())
+    check(rc, "mdx_lattice_parameters_update")
+    return out
+
+
+def atom_types_update(logits, atom_types, q, q_bar, q_bar_tm1, gumbel, u, small_epsilon: float, greedy: bool,
+                      one_transition: bool, return_probabilities: bool = False):
+    B, N, Cn = logits.shape
+    assert atom_types.shape == (B, N) and gumbel.shape == (B, N, Cn)
+    assert q.shape == q_bar.shape == q_bar_tm1.shape == (Cn, Cn)
+    out = torch.empty_like(atom_types)
+    p_out = torch.empty_like(logits) if return_probabilities else None
+    rc = lib().mdx_atom_types_update(ptr(logits, F32, "logits"), ptr(atom_types, I64, "atom_types"),
+                                     ptr(q, F32, "q"), ptr(q_bar, F32, "q_bar"), ptr(q_bar_tm1, F32, "q_bar_tm1"),
+                                     ptr(gumbel, F32, "gumbel"), ptr(u, F32, "u"), B, N, Cn, float(small_epsilon),
+                                     int(bool(greedy)), int(bool(one_transition)), ptr(out, I64, "out"),
+                                     ptr(p_out, F32, "p_out"), stream_handle())
+    check(rc, "mdx_atom_types_update")
+    return (out, p_out) if return_probabilities else out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# fused per-step update
+# ----------------------------------------------------------------------------------------------------------------
+def pc_step_update(sched: DeviceSchedule, mode: int, index_i: int, d_index: Optional[torch.Tensor], flags: PcFlags,
+                   atom_types, x, l, logits, score_x, score_l, z_coordinates, gumbel, u, z_lattice, rng: Rng,
+                   atom_types_out, x_out, l_out, status: Optional[torch.Tensor]):
+    B, N, d = x.shape
+    rc = lib().mdx_pc_step_update(
+        C.byref(sched.c_struct), int(mode), int(index_i), ptr(d_index, I32, "d_index"), C.byref(flags),
+        ptr(atom_types, I64, "atom_types"), ptr(x, F32, "x"), ptr(l, F32, "l"), ptr(logits, F32, "logits"),
+        ptr(score_x, F32, "score_x"), ptr(score_l, F32, "score_l"), ptr(z_coordinates, F32, "z_coordinates"),
+        ptr(gumbel, F32, "gumbel"), ptr(u, F32, "u"), ptr(z_lattice, F32, "z_lattice"), rng, B, N, d,
+        ptr(atom_types_out, I64, "atom_types_out"), ptr(x_out, F32, "x_out"), ptr(l_out, F32, "l_out"),
+        ptr(status, I32, "status"), stream_handle())
+    check(rc, "mdx_pc_step_update")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# F1 / F2 / R1
+# ----------------------------------------------------------------------------------------------------------------
+def noise_relative_coordinates(x0, z, sigma: float, out=None):
+    assert x0.shape == z.shape
+    out = torch.empty_like(x0) if out is None else out
+    rc = lib().mdx_noise_relative_coordinates(ptr(x0, F32, "x0"), ptr(z, F32, "z"), float(sigma), x0.numel(),
+                                              ptr(out, F32, "out"), stream_handle())
+    check(rc, "mdx_noise_relative_coordinates")
+    return out
+
+
+def noise_atom_types(a0, q_bar, u):
+    Cn = u.shape[-1]
+    assert q_bar.shape == (Cn, Cn) and u.shape[:-1] == a0.shape
+    out = torch.empty_like(a0)
+    rc = lib().mdx_noise_atom_types(ptr(a0, I64, "a0"), ptr(q_bar, F32, "q_bar"), ptr(u, F32, "u"), a0.numel(), Cn,
+                                    ptr(out, I64, "out"), stream_handle())
+    check(rc, "mdx_noise_atom_types")
+    return out
+
+
+def repaint_constrained_rows(sched: DeviceSchedule, index_i: int, d_index, constrained_x, constrained_a,
+                             constrained_indices, z, u, rng: Rng, x_inout, a_inout):
+    B, N, d = x_inout.shape
+    K = constrained_x.shape[0]
+    rc = lib().mdx_repaint_constrained_rows(
+        C.byref(sched.c_struct), int(index_i), ptr(d_index, I32, "d_index"), ptr(constrained_x, F32, "constrained_x"),
+        ptr(constrained_a, I64, "constrained_a"), ptr(constrained_indices, I64, "constrained_indices"), K,
+        ptr(z, F32, "z"), ptr(u, F32, "u"), rng, B, N, d, ptr(x_inout, F32, "x"), ptr(a_inout, I64, "a"),
+        stream_handle())
+    check(rc, "mdx_repaint_constrained_rows")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# N1
+# ----------------------------------------------------------------------------------------------------------------
+def radius_graph(cartesian_positions, basis_vectors, radial_cutoff: float, unique: bool,
+                 status: Optional[torch.Tensor] = None, want_shifts: bool = True):
+    """Two-call radius graph.  Returns dict(counts [B,N], edges [E,2], image [E] | None, shifts [E,3] | None).
+
+    The only host synchronisation is reading E = counts.sum() to size the outputs.
+    """
+    B, N, d = cartesian_positions.shape
+    assert d == 3 and basis_vectors.shape == (B, 3, 3)
+    dev = cartesian_positions.device
+    counts = torch.empty(B, N, dtype=I64, device=dev)
+    L = lib()
+    rc = L.mdx_radius_graph_count(ptr(cartesian_positions, F32, "cartesian_positions"),
+                                  ptr(basis_vectors, F32, "basis_vectors"), float(radial_cutoff), B, N,
+                                  int(bool(unique)), ptr(counts, I64, "counts"), ptr(status, I32, "status"),
+                                  stream_handle())
+    check(rc, "mdx_radius_graph_count")
+    inclusive = torch.cumsum(counts.view(-1), 0)
+    offsets = inclusive - counts.view(-1)
+    E = int(inclusive[-1].item()) if B * N > 0 else 0
+    edges = torch.empty(E, 2, dtype=I64, device=dev)
+    image = None if unique else torch.empty(E, dtype=I32, device=dev)
+    shifts = None if (unique or not want_shifts) else torch.empty(E, 3, dtype=F32, device=dev)
+    if E > 0:
+        rc = L.mdx_radius_graph_fill(ptr(cartesian_positions, F32, "cartesian_positions"),
+                                     ptr(basis_vectors, F32, "basis_vectors"), float(radial_cutoff), B, N,
+                                     int(bool(unique)), ptr(offsets, I64, "offsets"), ptr(edges, I64, "edges"),
+                                     ptr(image, I32, "image"), ptr(shifts, F32, "shifts"), stream_handle())
+        check(rc, "mdx_radius_graph_fill")
+    return dict(counts=counts, edges=edges, image=image, shifts=shifts)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# RNG fills / probes
+# ----------------------------------------------------------------------------------------------------------------
+RNG_UNIFORM, RNG_NORMAL, RNG_GUMBEL = 0, 1, 2
+
+
+def rng_fill(kind: int, seed: int, call: int, draw: int, tag: int, n_items: int, width: int, device) -> torch.Tensor:
+    out = torch.empty(n_items, width, dtype=F32, device=device)
+    rc = lib().mdx_rng_fill(kind, int(seed) & 0xFFFFFFFFFFFFFFFF, int(call), int(draw), int(tag), n_items, width,
+                            ptr(out, F32, "out"), stream_handle())
+    check(rc, "mdx_rng_fill")
+    return out
+
+
+def math_probe(fn: int, x: torch.Tensor) -> torch.Tensor:
+    y = torch.empty_like(x)
+    check(lib().mdx_math_probe(fn, ptr(x, F32, "x"), x.numel(), ptr(y, F32, "y"), stream_handle()), "mdx_math_probe")
+    return y

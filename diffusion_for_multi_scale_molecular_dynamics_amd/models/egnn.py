@@ -1,0 +1,144 @@
+"""E(n)-equivariant graph network used as a score network backbone (PyTorch forward).
+
+Same architecture and parameter names (state_dict keys) as the reference's EGNN / E_GCL
+(src/.../models/egnn.py:20-385; Satorras et al., arXiv:2102.09844), so reference checkpoints load unchanged.
+Written for sorted edge lists (edges grouped by source node, which is what the HIP radius-graph kernel and
+get_edges_batch produce):
+  * segment sums over sorted edges use torch.segment_reduce -- no atomics, run-to-run deterministic;
+  * the first message layer is applied per NODE and gathered per edge (W [h_i | h_j | r] = W_i h_i + W_j h_j + w_r r),
+    which removes the [E, 2H+1] concatenation and 2/5 of the message-MLP FLOPs.
+"""
+from typing import Callable, Optional, Tuple
+
+import torch
+from torch import nn
+
+from ..namespace import AXL
+
+
+def segment_sum_sorted(data: torch.Tensor, degree: torch.Tensor) -> torch.Tensor:
+    """Sum rows of `data` over consecutive segments of lengths `degree` (edges sorted by source node).
+
+    Replaces unsorted_segment_sum (src/.../models/egnn_utils.py:11-38) for sorted edge lists."""
+    return torch.segment_reduce(data, "sum", lengths=degree, axis=0, unsafe=True)
+
+
+class E_GCL(nn.Module):
+    """One equivariant convolution layer (egnn.py:20-289)."""
+
+    def __init__(self, input_size: int, output_size: int, message_n_hidden_dimensions: int,
+                 message_hidden_dimensions_size: int, node_n_hidden_dimensions: int, node_hidden_dimensions_size: int,
+                 coordinate_n_hidden_dimensions: int, coordinate_hidden_dimensions_size: int,
+                 act_fn: Callable = nn.SiLU(), residual: bool = True, attention: bool = False,
+                 normalize: bool = False, coords_agg: str = "mean", message_agg: str = "mean", tanh: bool = False):
+        super().__init__()
+        if coords_agg not in ("mean", "sum"):
+            raise ValueError(f"coords_agg should be mean or sum. Got {coords_agg}")
+        if message_agg not in ("mean", "sum"):
+            raise ValueError(f"message_agg should be mean or sum. Got {message_agg}")
+        self.residual, self.attention, self.normalize, self.tanh = residual, attention, normalize, tanh
+        self.coords_mean = coords_agg == "mean"
+        self.message_mean = message_agg == "mean"
+        self.epsilon = 1e-8
+        self.input_size = input_size
+
+        mh, nh, ch = message_hidden_dimensions_size, node_hidden_dimensions_size, coordinate_hidden_dimensions_size
+        layers = [nn.Linear(2 * input_size + 1, mh), act_fn]
+        for _ in range(message_n_hidden_dimensions):
+            layers += [nn.Linear(mh, mh), act_fn]
+        self.message_mlp = nn.Sequential(*layers)
+
+        layers = [nn.Linear(input_size + mh, nh), act_fn]
+        for _ in range(node_n_hidden_dimensions):
+            layers += [nn.Linear(nh, nh), act_fn]
+        layers.append(nn.Linear(nh, output_size))
+        self.node_mlp = nn.Sequential(*layers)
+
+        layers = [nn.Linear(mh, ch), act_fn]
+        for _ in range(coordinate_n_hidden_dimensions):
+            layers += [nn.Linear(ch, ch), act_fn]
+        layers.append(nn.Linear(ch, 1, bias=False))
+        if tanh:
+            layers.append(nn.Tanh())
+        self.coord_mlp = nn.Sequential(*layers)
+
+        if attention:
+            self.att_mlp = nn.Sequential(nn.Linear(mh, 1), nn.Sigmoid())
+
+    def _messages(self, h: torch.Tensor, row: torch.Tensor, col: torch.Tensor, radial: torch.Tensor) -> torch.Tensor:
+        first = self.message_mlp[0]
+        n_in = self.input_size
+        w = first.weight
+        # node-level projections, gathered per edge
+        proj = torch.nn.functional.linear(h, torch.cat([w[:, :n_in], w[:, n_in:2 * n_in]], dim=0))
+        mh = w.shape[0]
+        pre = proj[:, :mh].index_select(0, row) + proj[:, mh:].index_select(0, col)
+        pre = torch.addcmul(pre + first.bias, radial, w[:, 2 * n_in].unsqueeze(0))
+        out = pre
+        for layer in list(self.message_mlp)[1:]:
+            out = layer(out)
+        if self.attention:
+            out = out * self.att_mlp(out)
+        return out
+
+    def forward(self, h: torch.Tensor, edge_index: torch.Tensor, coord: torch.Tensor,
+                degree: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """h [n_nodes, F]; edge_index [E, 2] sorted by column 0; coord [n_nodes, D]; degree [n_nodes] edge counts."""
+        row, col = edge_index[:, 0], edge_index[:, 1]
+        if degree is None:
+            degree = torch.bincount(row, minlength=h.shape[0])
+        inv_deg = (1.0 / degree.clamp(min=1).to(h.dtype)).unsqueeze(1)
+
+        coord_diff = coord.index_select(0, row) - coord.index_select(0, col)
+        radial = (coord_diff ** 2).sum(dim=1, keepdim=True)
+        if self.normalize:
+            coord_diff = torch.tanh(radial) / torch.sqrt(radial + self.epsilon ** 2) * coord_diff
+
+        messages = self._messages(h, row, col, radial)
+
+        trans = segment_sum_sorted(coord_diff * self.coord_mlp(messages), degree)
+        coord = coord + (trans * inv_deg if self.coords_mean else trans)
+
+        agg = segment_sum_sorted(messages, degree)
+        if self.message_mean:
+            agg = agg * inv_deg
+        out = self.node_mlp(torch.cat([h, agg], dim=1))
+        if self.residual:
+            out = h + out
+        return out, coord
+
+
+class EGNN(nn.Module):
+    """Stack of E_GCL layers with input embedding and node-classification head (egnn.py:292-385)."""
+
+    def __init__(self, input_size: int, num_classes: int, message_n_hidden_dimensions: int,
+                 message_hidden_dimensions_size: int, node_n_hidden_dimensions: int, node_hidden_dimensions_size: int,
+                 coordinate_n_hidden_dimensions: int, coordinate_hidden_dimensions_size: int,
+                 act_fn: Callable = nn.SiLU(), residual: bool = True, attention: bool = False,
+                 normalize: bool = False, tanh: bool = False, coords_agg: str = "mean", message_agg: str = "mean",
+                 n_layers: int = 4):
+        super().__init__()
+        self.n_layers = n_layers
+        self.embedding_in = nn.Linear(input_size, node_hidden_dimensions_size)
+        self.graph_layers = nn.ModuleList([])
+        self.node_classification_layer = nn.Linear(node_hidden_dimensions_size, num_classes)
+        for _ in range(n_layers):
+            self.graph_layers.append(E_GCL(
+                input_size=node_hidden_dimensions_size, output_size=node_hidden_dimensions_size,
+                message_n_hidden_dimensions=message_n_hidden_dimensions,
+                message_hidden_dimensions_size=message_hidden_dimensions_size,
+                node_n_hidden_dimensions=node_n_hidden_dimensions,
+                node_hidden_dimensions_size=node_hidden_dimensions_size,
+                coordinate_n_hidden_dimensions=coordinate_n_hidden_dimensions,
+                coordinate_hidden_dimensions_size=coordinate_hidden_dimensions_size,
+                act_fn=act_fn, residual=residual, attention=attention, normalize=normalize, coords_agg=coords_agg,
+                message_agg=message_agg, tanh=tanh))
+
+    def forward(self, h: torch.Tensor, edges: torch.Tensor, x: torch.Tensor,
+                degree: Optional[torch.Tensor] = None) -> AXL:
+        h = self.embedding_in(h)
+        if degree is None:
+            degree = torch.bincount(edges[:, 0], minlength=h.shape[0])
+        for layer in self.graph_layers:
+            h, x = layer(h, edges, x, degree)
+        return AXL(A=self.node_classification_layer(h), X=x, L=torch.zeros_like(x))

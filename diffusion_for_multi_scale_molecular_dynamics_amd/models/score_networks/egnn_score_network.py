@@ -1,0 +1,160 @@
+"""EGNN score network (plugin of the ScoreNetwork API; PyTorch forward, HIP radius graph).
+
+Same hyper-parameters, parameter names and function as the reference's EGNNScoreNetwork
+(src/.../models/score_networks/egnn_score_network.py:23-303).  With `edges: radial_cutoff` the graph is built by
+the HIP kernel N1 (utils/neighbors.py), including the reference's quirk of searching in a cell clipped to
+2.2 x cutoff with the angles zeroed (:236-240).
+"""
+import itertools
+import math
+from dataclasses import dataclass
+from typing import AnyStr, Callable, Dict, Optional, Union
+
+import torch
+
+from ...namespace import AXL, NOISE, NOISY_AXL_COMPOSITION
+from ...utils import neighbors
+from ..egnn import EGNN
+from .score_network import ScoreNetwork, ScoreNetworkParameters
+
+
+@dataclass(kw_only=True)
+class EGNNScoreNetworkParameters(ScoreNetworkParameters):
+    """Hyper-parameters (:23-45)."""
+
+    architecture: str = "egnn"
+    number_of_bloch_wave_shells: int = 1
+    message_n_hidden_dimensions: int = 1
+    message_hidden_dimensions_size: int = 16
+    node_n_hidden_dimensions: int = 1
+    node_hidden_dimensions_size: int = 32
+    coordinate_n_hidden_dimensions: int = 1
+    coordinate_hidden_dimensions_size: int = 32
+    residual: bool = True
+    attention: bool = False
+    normalize: bool = False
+    tanh: bool = False
+    coords_agg: str = "mean"
+    message_agg: str = "mean"
+    n_layers: int = 4
+    edges: str = "fully_connected"
+    radial_cutoff: Union[float, None] = None
+    drop_duplicate_edges: bool = True
+
+
+def positive_bloch_wave_vectors(number_of_complete_shells: int, spatial_dimension: int) -> torch.Tensor:
+    """Integer reciprocal-lattice vectors of the first shells of the cubic point group, one per +-K pair.
+
+    Same set and order as get_cubic_point_group_positive_normalized_bloch_wave_vectors
+    (src/.../utils/lattice_utils.py:130-177): shells by increasing |K|^2 (degenerate shells all kept), vectors of
+    a shell in descending lexicographic order, the first of each {K, -K} pair retained."""
+    n = 2 * number_of_complete_shells
+    vectors = [v for v in itertools.product(range(-n, n + 1), repeat=spatial_dimension) if any(v)]
+    vectors.sort(key=lambda v: (sum(c * c for c in v), tuple(-c for c in v)))
+    seen, shells, previous_norm = set(), [], 0
+    for v in vectors:
+        if v in seen:
+            continue
+        orbit = set()
+        for perm in itertools.permutations(range(spatial_dimension)):
+            for signs in itertools.product((-1, 1), repeat=spatial_dimension):
+                orbit.add(tuple(signs[k] * v[perm[k]] for k in range(spatial_dimension)))
+        seen |= orbit
+        shells.append(sorted(orbit, reverse=True))
+        norm = sum(c * c for c in v)
+        if len(shells) >= number_of_complete_shells and norm > previous_norm:
+            break
+        previous_norm = norm
+    half = []
+    for shell in shells:
+        known = set()
+        for v in shell:
+            if v in known:
+                continue
+            half.append(v)
+            known |= {v, tuple(-c for c in v)}
+    return torch.tensor(half, dtype=torch.float32)
+
+
+class EGNNScoreNetwork(ScoreNetwork):
+    """EGNN on the torus-uplifted positions (cos K.x, sin K.x), projected back with the Gamma matrices."""
+
+    def __init__(self, hyper_params: EGNNScoreNetworkParameters, edge_builder: Optional[Callable] = None):
+        """edge_builder(relative_coordinates, unit_cell, radial_cutoff) -> (edges [E,2], degree [B*N]) overrides the
+        HIP radius graph; it exists so tests can run this module against the CPU oracle's edge list."""
+        super().__init__(hyper_params)
+        hp = hyper_params
+        self.number_of_features_per_node = self.num_atom_types + 2
+        self.number_of_bloch_wave_shells = hp.number_of_bloch_wave_shells
+        k_vectors = positive_bloch_wave_vectors(hp.number_of_bloch_wave_shells, self.spatial_dimension)
+        self.register_parameter("bloch_wave_reciprocal_lattice_vectors",
+                                torch.nn.Parameter(k_vectors, requires_grad=False))
+        self.register_parameter("projection_matrices",
+                                torch.nn.Parameter(self._projection_matrices(k_vectors), requires_grad=False))
+        assert hp.edges in ("fully_connected", "radial_cutoff"), \
+            f"Edges type should be fully_connected or radial_cutoff. Got {hp.edges}"
+        self.edges = hp.edges
+        self.radial_cutoff = hp.radial_cutoff
+        if self.edges == "fully_connected":
+            assert self.radial_cutoff is None, "Specifying a radial cutoff is inconsistent with edges=fully_connected."
+        else:
+            assert type(self.radial_cutoff) is float, \
+                "A floating point value for the radial cutoff is needed for edges=radial_cutoff."
+        self.drop_duplicate_edges = hp.drop_duplicate_edges
+        self.edge_builder = edge_builder
+        self.graph_status = None      # device word that collects MDX_STATUS_CUTOFF_TOO_LARGE without a sync
+        self.egnn = EGNN(
+            input_size=self.number_of_features_per_node, num_classes=self.num_atom_types + 1,
+            message_n_hidden_dimensions=hp.message_n_hidden_dimensions,
+            message_hidden_dimensions_size=hp.message_hidden_dimensions_size,
+            node_n_hidden_dimensions=hp.node_n_hidden_dimensions,
+            node_hidden_dimensions_size=hp.node_hidden_dimensions_size,
+            coordinate_n_hidden_dimensions=hp.coordinate_n_hidden_dimensions,
+            coordinate_hidden_dimensions_size=hp.coordinate_hidden_dimensions_size,
+            residual=hp.residual, attention=hp.attention, normalize=hp.normalize, tanh=hp.tanh,
+            coords_agg=hp.coords_agg, message_agg=hp.message_agg, n_layers=hp.n_layers)
+
+    @staticmethod
+    def _projection_matrices(k_vectors: torch.Tensor) -> torch.Tensor:
+        """Gamma^alpha = blockdiag_k( K_k[alpha] * [[0,-1],[1,0]] )  (:103-133)"""
+        n_k, d = k_vectors.shape
+        gamma = torch.zeros(d, 2 * n_k, 2 * n_k)
+        for k in range(n_k):
+            gamma[:, 2 * k, 2 * k + 1] = -k_vectors[k]
+            gamma[:, 2 * k + 1, 2 * k] = k_vectors[k]
+        return gamma
+
+    def _build_edges(self, relative_coordinates: torch.Tensor, lattice_parameters: torch.Tensor):
+        bsz, n, d = relative_coordinates.shape
+        if self.edges == "fully_connected":
+            edges = neighbors.get_edges_batch(n, bsz, device=relative_coordinates.device)
+            degree = torch.full((bsz * n,), n - 1, dtype=torch.int64, device=relative_coordinates.device)
+            return edges, degree
+        lengths = lattice_parameters[:, :d].clip(min=2.2 * self.radial_cutoff)   # "avoid box collapse" (:236-239)
+        unit_cell = torch.diag_embed(lengths)
+        if self.edge_builder is not None:
+            return self.edge_builder(relative_coordinates, unit_cell, self.radial_cutoff)
+        assert self.drop_duplicate_edges, "the HIP graph path implements drop_duplicate_edges=True"
+        if self.graph_status is None or self.graph_status.device != relative_coordinates.device:
+            self.graph_status = torch.zeros(1, dtype=torch.int32, device=relative_coordinates.device)
+        return neighbors.get_edges_with_radial_cutoff(relative_coordinates, unit_cell, self.radial_cutoff,
+                                                      status=self.graph_status, return_degree=True)
+
+    def _forward_unchecked(self, batch: Dict[AnyStr, torch.Tensor], conditional: bool = False) -> AXL:
+        comp = batch[NOISY_AXL_COMPOSITION]
+        x = comp.X
+        bsz, n, d = x.shape
+        edges, degree = self._build_edges(x, comp.L)
+
+        flat = x.reshape(bsz * n, d)
+        kr = (2.0 * math.pi * flat) @ self.bloch_wave_reciprocal_lattice_vectors.to(flat).t()   # [nodes, n_k]
+        z = torch.stack([kr.cos(), kr.sin()], dim=2).reshape(bsz * n, -1)                        # (k, two) interleaved
+
+        sigmas = batch[NOISE].to(x.device).repeat_interleave(n, dim=0)
+        one_hot = torch.nn.functional.one_hot(comp.A.reshape(-1).long(), self.num_atom_types + 1).to(x.dtype)
+        h = torch.cat([sigmas, one_hot], dim=1)
+
+        out = self.egnn(h=h, edges=edges, x=z, degree=degree)
+        # S^alpha = z . Gamma^alpha . z_hat   (:283-290)
+        scores = torch.einsum("ni,aij,nj->na", z, self.projection_matrices.to(z), out.X)
+        return AXL(A=out.A.reshape(bsz, n, -1), X=scores.reshape(bsz, n, d), L=torch.zeros_like(comp.L))

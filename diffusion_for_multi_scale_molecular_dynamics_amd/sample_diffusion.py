@@ -1,0 +1,138 @@
+"""Entry point: draw samples with the MI355X hot path (drop-in for src/.../sample_diffusion.py:52-274).
+
+Same flags, YAML surface (`noise:`, `sampling:`, optional `elements:`), and output files (`samples.pt` =
+{"cartesian_positions", "original_axl"}, `trajectories.pt`, `config_backup.yaml`, `console.log`).
+Differences, all additive:
+  * the score network comes from `--checkpoint` (a torch / Lightning checkpoint whose state_dict holds the
+    network under the prefix `axl_network.`) together with the `model: score_network:` block of the config, or is
+    randomly initialised with `--random_init_seed` (synthetic benchmarks);
+  * under `torchrun` (one process per GPU) the sub-batches are sharded over the ranks and gathered once (RCCL);
+    rank 0 writes the files;
+  * LAMMPS energies (`oracle:`) and Orion reporting are outside the hot path and are not evaluated.
+"""
+import argparse
+import logging
+import os
+import shutil
+import socket
+import sys
+from pathlib import Path
+from typing import Any, AnyStr, Dict, Optional
+
+import torch
+import yaml
+
+from .generators.instantiate_generator import instantiate_generator
+from .generators.load_sampling_parameters import load_sampling_parameters
+from .generators.sampling_constraint import read_sampling_constraint
+from .generators.trajectory_initializer import instantiate_trajectory_initializer
+from .models.score_networks.score_network import ScoreNetwork
+from .models.score_networks.score_network_factory import create_score_network, create_score_network_parameters
+from .noise_schedulers.noise_parameters import NoiseParameters
+from .sampling.diffusion_sampling import create_batch_of_samples_sharded
+
+logger = logging.getLogger(__name__)
+
+
+def extract_and_validate_parameters(hyper_params: Dict[AnyStr, Any]):
+    """:168-188"""
+    assert "noise" in hyper_params, "The noise parameters must be defined to draw samples."
+    assert "sampling" in hyper_params, "The sampling parameters must be defined to draw samples."
+    return NoiseParameters(**hyper_params["noise"]), load_sampling_parameters(hyper_params["sampling"])
+
+
+def get_axl_network(checkpoint_path, hyper_params: Dict[AnyStr, Any]) -> ScoreNetwork:
+    """Build the network from `model.score_network` and load `axl_network.*` weights from the checkpoint."""
+    assert "model" in hyper_params and "score_network" in hyper_params["model"], \
+        "the config must contain the `model: score_network:` block that describes the checkpoint's network"
+    network = create_score_network(create_score_network_parameters(hyper_params["model"]["score_network"]))
+    checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    state = checkpoint.get("state_dict", checkpoint)
+    prefix = "axl_network."
+    state = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} or state
+    network.load_state_dict(state)
+    return network.eval()
+
+
+def _init_distributed(device: torch.device):
+    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        return 0, 1, device
+    import torch.distributed as dist
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if device.type == "cuda":
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl" if device.type == "cuda" else "gloo")
+    return dist.get_rank(), dist.get_world_size(), device
+
+
+def main(args: Optional[Any] = None, axl_network: Optional[ScoreNetwork] = None) -> None:
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config", required=True, help="config file with sampling parameters in yaml format.")
+    parser.add_argument("--checkpoint", default=None, help="path to checkpoint model to be loaded.")
+    parser.add_argument("--output", required=True, help="path to outputs - will store files here")
+    parser.add_argument("--path_to_starting_configuration_data_pickle", default=None)
+    parser.add_argument("--path_to_sampling_constraint_data_pickle", default=None)
+    parser.add_argument("--device", default="cuda", help="Device to use. Defaults to cuda.")
+    parser.add_argument("--random_init_seed", type=int, default=None,
+                        help="build the network of `model.score_network` with random weights (synthetic runs)")
+    args = parser.parse_args(args)
+
+    rank, world, device = _init_distributed(torch.device(args.device))
+    os.makedirs(args.output, exist_ok=True)
+    if rank == 0:
+        logging.basicConfig(level=logging.INFO, force=True,
+                            handlers=[logging.StreamHandler(sys.stdout),
+                                      logging.FileHandler(os.path.join(args.output, "console.log"))])
+        shutil.copyfile(args.config, os.path.join(args.output, "config_backup.yaml"))
+    with open(args.config) as fd:
+        hyper_params = yaml.safe_load(fd)
+    logger.info("Sampling Experiment info:\n  Hostname : %s\n  Checkpoint : %s\n  Device   : %s\n  Ranks    : %d",
+                socket.gethostname(), args.checkpoint, device, world)
+
+    noise_parameters, sampling_parameters = extract_and_validate_parameters(hyper_params)
+    if axl_network is None:
+        if args.random_init_seed is not None:
+            torch.manual_seed(args.random_init_seed)
+            axl_network = create_score_network(
+                create_score_network_parameters(hyper_params["model"]["score_network"])).eval()
+        else:
+            assert args.checkpoint is not None and os.path.exists(args.checkpoint), \
+                f"The path {args.checkpoint} does not exist. Cannot go on."
+            axl_network = get_axl_network(args.checkpoint, hyper_params)
+    axl_network = axl_network.to(device)
+    if "force_field" in hyper_params:
+        raise NotImplementedError("force_field augmentation is listed under 'next' in SURVEY.md section 8(f)")
+
+    trajectory_initializer = instantiate_trajectory_initializer(
+        sampling_parameters=sampling_parameters,
+        path_to_starting_configuration_data_pickle=args.path_to_starting_configuration_data_pickle)
+    sampling_constraints = None
+    if args.path_to_sampling_constraint_data_pickle is not None:
+        sampling_constraints = read_sampling_constraint(args.path_to_sampling_constraint_data_pickle)
+    generator = instantiate_generator(sampling_parameters=sampling_parameters, noise_parameters=noise_parameters,
+                                      axl_network=axl_network, trajectory_initializer=trajectory_initializer,
+                                      sampling_constraints=sampling_constraints)
+    create_samples_and_write_to_disk(generator, sampling_parameters, device, args.output, rank)
+
+
+def create_samples_and_write_to_disk(generator, sampling_parameters, device, output_path, rank: int = 0):
+    """:208-270 (energies / Orion reporting excluded)"""
+    logger.info("Generating samples...")
+    with torch.no_grad():
+        samples_batch = create_batch_of_samples_sharded(generator=generator, sampling_parameters=sampling_parameters,
+                                                        device=device)
+    logger.info("Done Generating Samples.")
+    if rank != 0:
+        return
+    output_directory = Path(output_path)
+    with open(output_directory / "samples.pt", "wb") as fd:
+        torch.save(samples_batch, fd)
+    if sampling_parameters.record_samples:
+        generator.sample_trajectory_recorder.write_to_pickle(output_directory / "trajectories.pt")
+    logger.info("Done!")
+
+
+if __name__ == "__main__":
+    main()

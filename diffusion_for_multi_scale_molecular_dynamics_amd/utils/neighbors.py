@@ -1,0 +1,108 @@
+"""Periodic neighbour search on the GPU (HIP kernel N1 behind the reference's function names).
+
+Replaces the KeOps-based implementation of src/.../utils/neighbors.py:36-224 and its consumers
+get_adj_matrix (models/graph_utils.py:10-50) / get_edges_with_radial_cutoff (models/egnn_utils.py:107-144).
+Edge ORDER differs from the reference by design -- (structure, source, destination, image) instead of
+(structure, image, source, k-th nearest) -- both consumers are order-insensitive, and the sorted order is what
+lets the EGNN aggregate without atomics.  The edge SET, shifts and counts are identical.
+"""
+from collections import namedtuple
+from typing import Optional
+
+import torch
+
+from .. import kernels
+from .._hip import STATUS_CUTOFF_TOO_LARGE, MdxError
+
+AdjacencyInfo = namedtuple(
+    "AdjacencyInfo",
+    ["adjacency_matrix", "shifts", "edge_batch_indices", "node_batch_indices", "number_of_edges"],
+)
+
+
+def _new_status(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def _raise_if_cutoff_too_large(status: torch.Tensor):
+    if int(status.item()) & STATUS_CUTOFF_TOO_LARGE:
+        # the reference asserts here (neighbors.py:107-113)
+        raise AssertionError("The radial cutoff is so large that neighbors could be located "
+                             "beyond the first shell of periodic unit cell images.")
+
+
+def get_periodic_adjacency_information(cartesian_positions: torch.Tensor, basis_vectors: torch.Tensor,
+                                       radial_cutoff: float, spatial_dimension: int = 3,
+                                       check_cutoff: bool = True) -> AdjacencyInfo:
+    """All (src, dst, image) edges with 0 < |p_src - (p_dst + image)|^2 <= rc^2  (neighbors.py:36-224)."""
+    assert cartesian_positions.dim() == 3, "Wrong number of dimensions for relative_coordinates"
+    assert basis_vectors.dim() == 3, "Wrong number of dimensions for basis_vectors"
+    batch_size, natom, d = cartesian_positions.shape
+    assert d == spatial_dimension == 3, "the HIP radius-graph kernel is three-dimensional"
+    assert basis_vectors.shape == (batch_size, 3, 3), "Wrong shape for basis vectors"
+    assert radial_cutoff > 0.0, "The radial cutoff should be greater than zero"
+    status = _new_status(cartesian_positions.device) if check_cutoff else None
+    out = kernels.radius_graph(cartesian_positions.contiguous(), basis_vectors.contiguous(), radial_cutoff,
+                               unique=False, status=status)
+    if check_cutoff:
+        _raise_if_cutoff_too_large(status)
+    number_of_edges = out["counts"].sum(dim=1)
+    dev = cartesian_positions.device
+    batch_ids = torch.arange(batch_size, device=dev)
+    return AdjacencyInfo(
+        adjacency_matrix=out["edges"].t(),                  # [2, E] per-structure indices, like the reference
+        shifts=out["shifts"],
+        edge_batch_indices=torch.repeat_interleave(batch_ids, number_of_edges),
+        node_batch_indices=torch.repeat_interleave(batch_ids, natom),
+        number_of_edges=number_of_edges,
+    )
+
+
+def shift_adjacency_matrix_indices_for_graph_batching(adjacency_matrix: torch.Tensor, num_edges: torch.Tensor,
+                                                      number_of_atoms: int) -> torch.Tensor:
+    """neighbors.py:381-390"""
+    shifts = torch.arange(len(num_edges), device=adjacency_matrix.device) * number_of_atoms
+    return adjacency_matrix + torch.repeat_interleave(shifts, num_edges).repeat(2, 1)
+
+
+def get_adj_matrix(positions: torch.Tensor, basis_vectors: torch.Tensor, radial_cutoff: float = 4.0,
+                   spatial_dimension: int = 3):
+    """models/graph_utils.py:10-50"""
+    info = get_periodic_adjacency_information(positions, basis_vectors, radial_cutoff, spatial_dimension)
+    adj = shift_adjacency_matrix_indices_for_graph_batching(info.adjacency_matrix, info.number_of_edges,
+                                                            positions.shape[1])
+    return adj, info.shifts, info.node_batch_indices, info.number_of_edges
+
+
+def get_edges_with_radial_cutoff(relative_coordinates: torch.Tensor, unit_cell: torch.Tensor,
+                                 radial_cutoff: float = 4.0, drop_duplicate_edges: bool = True,
+                                 spatial_dimension: int = 3, status: Optional[torch.Tensor] = None,
+                                 return_degree: bool = False):
+    """[E, 2] int64 batch-global (src, dst) pairs sorted lexicographically (models/egnn_utils.py:107-144).
+
+    With drop_duplicate_edges (the only mode the EGNN uses) one edge is emitted per pair whatever the image --
+    the same set, in the same order, as torch.unique(adj, dim=1) in the reference.  `status`, when given,
+    receives the cutoff-too-large bit instead of a synchronising assert."""
+    cart = torch.matmul(relative_coordinates, unit_cell).contiguous()
+    if drop_duplicate_edges:
+        own = status is None
+        st = _new_status(cart.device) if own else status
+        out = kernels.radius_graph(cart, unit_cell.contiguous(), radial_cutoff, unique=True, status=st)
+        if own:
+            _raise_if_cutoff_too_large(st)
+        if return_degree:
+            return out["edges"], out["counts"].view(-1)
+        return out["edges"]
+    adj, _, _, _ = get_adj_matrix(cart, unit_cell, radial_cutoff, spatial_dimension)
+    return adj.transpose(0, 1)
+
+
+def get_edges_batch(n_nodes: int, batch_size: int, device=None) -> torch.Tensor:
+    """Fully connected edges without self loops, [B n (n-1), 2], sorted by source (models/egnn_utils.py:73-104)."""
+    idx = torch.arange(n_nodes, device=device)
+    src = idx.repeat_interleave(n_nodes)
+    dst = idx.repeat(n_nodes)
+    keep = src != dst
+    pair = torch.stack([src[keep], dst[keep]], dim=1)
+    offsets = (torch.arange(batch_size, device=device) * n_nodes).view(-1, 1, 1)
+    return (pair.unsqueeze(0) + offsets).reshape(-1, 2)

@@ -1,0 +1,206 @@
+/*
+ * mdx_hip.h -- C ABI of the MI355X (gfx950) sampling hot path.
+ *
+ * Drop-in boundary for the per-step work of the reference's predictor-corrector sampler
+ * (mila-iqia/diffusion_for_multi_scale_molecular_dynamics).  The reference is pure PyTorch and has no FFI of
+ * its own; every entry point below names the reference function (file:line, relative to
+ * src/diffusion_for_multi_scale_molecular_dynamics/) whose arithmetic it replaces, and INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add at that call site.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless its name ends in _host.
+ *   - the caller (PyTorch) owns every buffer; the library never allocates, frees or retains a pointer.
+ *   - stateless, re-entrant, stream-ordered: work is enqueued on `stream` (a hipStream_t passed as void*),
+ *     no hidden synchronisation, no globals.  Safe to capture into a hipGraph.
+ *   - return value: MDX_OK or a negative status; no exceptions or aborts cross the ABI.  Conditions the
+ *     reference checks with device-side asserts (cutoff too large, MASK left at the last step) are reported
+ *     through an optional device status word (`status`, OR-ed bits below) that the host reads when it chooses.
+ *   - layouts: A int64 [B,N]; X float32 [B,N,d]; L float32 [B,d(d+1)/2]; logits float32 [B,N,C];
+ *     C = num_atom_types + 1, class C-1 is MASK.  All arrays C-contiguous.
+ *   - arithmetic: IEEE binary32 in the exact operation order documented in DESIGN.md ("MDX arithmetic");
+ *     integer outputs are bit-identical to oracle/mdx_oracle.c on identical inputs.
+ */
+#ifndef MDX_HIP_H
+#define MDX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDX_ABI_VERSION 1
+
+/* status codes */
+#define MDX_OK 0
+#define MDX_ERR_INVALID_ARG (-1)
+#define MDX_ERR_UNSUPPORTED (-2)
+#define MDX_ERR_HIP (-3)
+
+/* bits of the optional device status word */
+#define MDX_STATUS_CUTOFF_TOO_LARGE 1u   /* utils/neighbors.py:107-113 assert               */
+#define MDX_STATUS_MASK_AT_LAST_STEP 2u  /* generators/langevin_generator.py:616-620 assert */
+
+#define MDX_MAX_CLASSES 8      /* C supported by the fused atom-type kernels */
+#define MDX_PREDICTOR 0
+#define MDX_CORRECTOR 1
+
+/* tags of the device-RNG specification ("Device RNG") */
+#define MDX_TAG_COORD 0
+#define MDX_TAG_GUMBEL 1
+#define MDX_TAG_LATTICE 2
+#define MDX_TAG_INIT 3
+#define MDX_TAG_REPAINT_X0 4
+#define MDX_TAG_BINARY 5
+#define MDX_TAG_REPAINT_Z 6
+#define MDX_TAG_REPAINT_U 7
+#define MDX_TAG_INIT_LATTICE 8
+
+#if defined(__GNUC__)
+#define MDX_API __attribute__((visibility("default")))
+#else
+#define MDX_API
+#endif
+
+typedef void* mdx_stream_t;
+
+/* Device-resident schedule tables (S1), uploaded/built once per generator.
+ * Mirrors the Noise / LangevinDynamics namedtuples of noise_schedulers/noise_scheduler.py:348-378. */
+typedef struct mdx_schedule {
+    int32_t total_time_steps;       /* T */
+    int32_t num_classes;            /* C */
+    double sigma_min;               /* NoiseParameters.sigma_min as the Python double it is */
+    const float* time;              /* [T] */
+    const float* sigma;             /* [T] */
+    const float* g;                 /* [T] */
+    const float* g_squared;         /* [T] */
+    const float* epsilon;           /* [T] */
+    const float* q_matrix;          /* [T,C,C] */
+    const float* q_bar_matrix;      /* [T,C,C] */
+    const float* q_bar_tm1_matrix;  /* [T,C,C] */
+} mdx_schedule_t;
+
+/* Counter-based RNG request: used only where the corresponding pre-drawn noise pointer is NULL.
+ * value(item, k) comes from Philox4x32-10 with key = seed and
+ * counter = (item, (call << 8) | k/4, draw, tag); draw = index * draw_stride + draw_offset. */
+typedef struct mdx_rng {
+    uint64_t seed;
+    uint32_t call;          /* index of the sample() call (sub-batch) */
+    uint32_t draw_stride;   /* number_of_corrector_steps + 1 */
+    uint32_t draw_offset;   /* 0 predictor, 1+m for corrector m */
+} mdx_rng_t;
+
+/* Per-step flags of PredictorCorrectorSamplingParameters (generators/predictor_corrector_axl_generator.py:22-30). */
+typedef struct mdx_pc_flags {
+    int32_t atom_type_greedy_sampling;
+    int32_t one_atom_type_transition_per_step;
+    int32_t use_fixed_lattice_parameters;
+    int32_t update_atom_types;      /* predictor: 1; corrector: atom_type_transition_in_corrector */
+    float small_epsilon;
+} mdx_pc_flags_t;
+
+MDX_API int mdx_abi_version(void);
+MDX_API const char* mdx_status_string(int status);
+
+/* S1 -- NoiseScheduler.__init__ (noise_schedulers/noise_scheduler.py:112-267; sigma_calculator.py:72-74,102-104).
+ * schedule_type 0 = exponential, 1 = linear.  Outputs: 9 vectors [T] and 3 tensors [T,C,C]. */
+MDX_API int mdx_noise_schedule_build(int total_time_steps, int schedule_type, double time_delta, double sigma_min,
+                             double sigma_max, double corrector_step_epsilon, int num_classes, float* time,
+                             float* sigma, float* sigma_squared, float* g, float* g_squared, float* epsilon,
+                             float* sqrt_2_epsilon, float* beta, float* alpha_bar, float* q_matrix,
+                             float* q_bar_matrix, float* q_bar_tm1_matrix, mdx_stream_t stream);
+
+/* Step index kept on the device so that one captured graph serves every iteration. */
+MDX_API int mdx_index_set(int32_t* d_index, int32_t value, mdx_stream_t stream);
+MDX_API int mdx_index_add(int32_t* d_index, int32_t delta, mdx_stream_t stream);
+
+/* Score-network inputs TIME / NOISE as [B,1] tensors -- LangevinGenerator._get_model_predictions
+ * (generators/langevin_generator.py:140-143) with the scalars of predictor_step (:559-563) or
+ * corrector_step (:719-729).  index = d_index ? *d_index + index_i : index_i. */
+MDX_API int mdx_fill_time_sigma(const mdx_schedule_t* sched_host, int mode, int index_i, const int32_t* d_index,
+                        float* time_out, float* sigma_out, int64_t batch, mdx_stream_t stream);
+
+/* P1 -- LangevinGenerator._relative_coordinates_update (generators/langevin_generator.py:155-201) +
+ * map_relative_coordinates_to_unit_cell (utils/basis_transformations.py:95-119):
+ * out = wrap((x + (score_weight*s)/sigma) + noise_weight*z), elementwise over `count` floats. */
+MDX_API int mdx_relative_coordinates_update(const float* x, const float* sigma_normalized_scores, const float* z,
+                                    float score_weight, float gaussian_noise_weight, float sigma, int64_t count,
+                                    float* out, mdx_stream_t stream);
+
+/* P3 -- LangevinGenerator._lattice_parameters_update (generators/langevin_generator.py:485-490). */
+MDX_API int mdx_lattice_parameters_update(const float* l, const float* sigma_normalized_scores, const float* z,
+                                  float score_weight, float gaussian_noise_weight, float sigma_n, int64_t count,
+                                  float* out, mdx_stream_t stream);
+
+/* P2 -- LangevinGenerator._atom_types_update (generators/langevin_generator.py:247-439) with
+ * get_probability_at_previous_time_step / get_probability_from_logits (utils/d3pm_utils.py:64-150).
+ * q, q_bar, q_bar_tm1: [C,C] of the current step.  gumbel [B,N,C]; u [B,N] (read only if greedy).
+ * probabilities_out (nullable) [B,N,C]: the transition probabilities after the greedy adjustment. */
+MDX_API int mdx_atom_types_update(const float* logits, const int64_t* atom_types, const float* q, const float* q_bar,
+                          const float* q_bar_tm1, const float* gumbel, const float* u, int64_t batch,
+                          int number_of_atoms, int num_classes, float small_epsilon, int greedy,
+                          int one_transition, int64_t* atom_types_out, float* probabilities_out,
+                          mdx_stream_t stream);
+
+/* Fused per-step update: P2 + P1 + P3 of LangevinGenerator.predictor_step (:536-645) or P1 + P3 (+P2) of
+ * corrector_step (:693-805) in ONE launch, scalars taken from the device-resident tables.
+ * Pre-drawn noise (reference-RNG parity mode): z_coordinates [B,N,d], gumbel [B,N,C], u [B,N], z_lattice [B,nl];
+ * any NULL pointer switches that draw to the device RNG (rng).  Outputs may alias inputs.
+ * status (nullable): MDX_STATUS_MASK_AT_LAST_STEP is OR-ed in when index 1 leaves a MASK. */
+MDX_API int mdx_pc_step_update(const mdx_schedule_t* sched_host, int mode, int index_i, const int32_t* d_index,
+                       const mdx_pc_flags_t* flags_host, const int64_t* atom_types, const float* x, const float* l,
+                       const float* logits, const float* score_x, const float* score_l, const float* z_coordinates,
+                       const float* gumbel, const float* u, const float* z_lattice, mdx_rng_t rng, int64_t batch,
+                       int number_of_atoms, int spatial_dimension, int64_t* atom_types_out, float* x_out,
+                       float* l_out, uint32_t* status, mdx_stream_t stream);
+
+/* F1 -- RelativeCoordinatesNoiser.get_noisy_relative_coordinates_sample
+ * (noisers/relative_coordinates_noiser.py:33-67): out = wrap(x0 + sigma*z). */
+MDX_API int mdx_noise_relative_coordinates(const float* x0, const float* z, float sigma, int64_t count, float* out,
+                                   mdx_stream_t stream);
+
+/* F2 -- AtomTypesNoiser.get_noisy_atom_types_sample (noisers/atom_types_noiser.py:30-60) with
+ * compute_q_at_given_a0 (utils/d3pm_utils.py:23-39): a_t = argmax_c(log(Qbar[a0][c]) - log(-log u_c)). */
+MDX_API int mdx_noise_atom_types(const int64_t* a0, const float* q_bar, const float* u, int64_t n_atoms, int num_classes,
+                         int64_t* out, mdx_stream_t stream);
+
+/* R1 -- ConstrainedLangevinGenerator._repaint_composition (generators/constrained_langevin_generator.py:136-163):
+ * for each sample and each constrained row k: forward-noise the known (x_k, a_k) to time index `index_i`
+ * (NoisingTransform.transform_given_time_index, data/diffusion/noising_transform.py:98-200; identity when
+ * index_i == 0) and overwrite row constrained_indices[k] of X and A in place.
+ * z [B,N,d] and u [B,N,C] are the FULL-size draws the reference makes (only constrained rows are read);
+ * NULL switches to the device RNG. */
+MDX_API int mdx_repaint_constrained_rows(const mdx_schedule_t* sched_host, int index_i, const int32_t* d_index,
+                                 const float* constrained_x, const int64_t* constrained_a,
+                                 const int64_t* constrained_indices, int number_of_constraints, const float* z,
+                                 const float* u, mdx_rng_t rng, int64_t batch, int number_of_atoms,
+                                 int spatial_dimension, float* x_inout, int64_t* a_inout, mdx_stream_t stream);
+
+/* N1 -- get_periodic_adjacency_information (utils/neighbors.py:36-224) and the EGNN consumer
+ * get_edges_with_radial_cutoff (models/egnn_utils.py:107-144).  Two-call protocol:
+ *   1. mdx_radius_graph_count  -> counts[B*N] (edges per source atom)
+ *   2. caller: offsets = exclusive_scan(counts), E = sum(counts); allocates outputs
+ *   3. mdx_radius_graph_fill   -> edges, ordered by (structure, source, destination[, image])
+ * unique = 1: one edge per (src,dst) pair whatever the image (torch.unique(dim=1) of the reference), edges
+ *             [E,2] int64 with batch-global node indices (b*N + i); image_out unused.
+ * unique = 0: one edge per (src,dst,image); edges [E,2] with per-structure indices, image_out[E] in 0..26
+ *             (itertools.product(-1,0,1) order, utils/lattice_utils.py:10-29), shifts_out [E,3] (nullable). */
+MDX_API int mdx_radius_graph_count(const float* cartesian_positions, const float* basis_vectors, float radial_cutoff,
+                           int64_t batch, int number_of_atoms, int unique, int64_t* counts, uint32_t* status,
+                           mdx_stream_t stream);
+MDX_API int mdx_radius_graph_fill(const float* cartesian_positions, const float* basis_vectors, float radial_cutoff,
+                          int64_t batch, int number_of_atoms, int unique, const int64_t* offsets,
+                          int64_t* edges_out, int32_t* image_out, float* shifts_out, mdx_stream_t stream);
+
+/* Device-RNG draws as stand-alone fills (trajectory initialisation, tests of the RNG specification).
+ * kind 0 = uniform (0,1), 1 = standard normal, 2 = Gumbel(0,1).  out [n_items, width]. */
+MDX_API int mdx_rng_fill(int kind, uint64_t seed, uint32_t call, uint32_t draw, uint32_t tag, int64_t n_items, int width,
+                 float* out, mdx_stream_t stream);
+
+/* MDX arithmetic probes (tests only): y = f(x) elementwise; fn 0 logf, 1 expf, 2 sinpi, 3 cospi. */
+MDX_API int mdx_math_probe(int fn, const float* x, int64_t count, float* y, mdx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDX_HIP_H */

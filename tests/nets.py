@@ -1,0 +1,62 @@
+"""Score networks used by the tests (product torch modules + the reference tests' echo network)."""
+import numpy as np
+import torch
+
+from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import (
+    EGNNScoreNetwork, EGNNScoreNetworkParameters)
+from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.mlp_score_network import (
+    MLPScoreNetwork, MLPScoreNetworkParameters)
+from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.score_network import (
+    ScoreNetwork, ScoreNetworkParameters)
+from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import AXL, NOISY_AXL_COMPOSITION
+
+
+class FakeAXLNetwork(ScoreNetwork):
+    """Echo network of the reference's generator tests (tests/generators/conftest.py:14-26):
+    A = one-hot(a), X = x, L = l."""
+
+    def _forward_unchecked(self, batch, conditional=False):
+        comp = batch[NOISY_AXL_COMPOSITION]
+        return AXL(A=torch.nn.functional.one_hot(comp.A.long(), self.num_atom_types + 1).to(comp.X.dtype),
+                   X=comp.X.clone(), L=comp.L.clone())
+
+
+def fake_net(num_atom_types, d=3):
+    return FakeAXLNetwork(ScoreNetworkParameters(architecture="dummy", spatial_dimension=d,
+                                                 num_atom_types=num_atom_types))
+
+
+def mlp_net(number_of_atoms, num_atom_types, hidden=64, n_hidden=3, seed=None):
+    if seed is not None:
+        torch.manual_seed(seed)
+    return MLPScoreNetwork(MLPScoreNetworkParameters(
+        number_of_atoms=number_of_atoms, num_atom_types=num_atom_types, n_hidden_dimensions=n_hidden,
+        hidden_dimensions_size=hidden, relative_coordinates_embedding_dimensions_size=32,
+        noise_embedding_dimensions_size=16, time_embedding_dimensions_size=16, atom_type_embedding_dimensions_size=1,
+        lattice_parameters_embedding_dimensions_size=1)).eval()
+
+
+def egnn_net(num_atom_types, edges, rc, hidden=32, n_layers=2, n_hidden=2, edge_builder=None, seed=None):
+    if seed is not None:
+        torch.manual_seed(seed)
+    return EGNNScoreNetwork(EGNNScoreNetworkParameters(
+        num_atom_types=num_atom_types, n_layers=n_layers, coordinate_hidden_dimensions_size=hidden,
+        coordinate_n_hidden_dimensions=n_hidden, message_hidden_dimensions_size=hidden,
+        message_n_hidden_dimensions=n_hidden, node_hidden_dimensions_size=hidden, node_n_hidden_dimensions=n_hidden,
+        edges=edges, radial_cutoff=rc), edge_builder=edge_builder).eval()
+
+
+def load_fixture_weights(net, fixture):
+    state = {k[4:]: torch.from_numpy(np.asarray(fixture[k])) for k in fixture.files if k.startswith("net/")}
+    net.load_state_dict(state)
+    return net
+
+
+def oracle_edge_builder(relative_coordinates, unit_cell, radial_cutoff):
+    """CPU edge list from the oracle's radius graph, so the product's EGNN module can run on CPU tensors in tests."""
+    from oracle import mdx_oracle as O
+    cart = torch.matmul(relative_coordinates, unit_cell).cpu().numpy()
+    r = O.radius_graph(cart, unit_cell.cpu().numpy(), radial_cutoff, unique=True)
+    dev = relative_coordinates.device
+    return (torch.from_numpy(np.stack([r["src"], r["dst"]], 1)).to(dev),
+            torch.from_numpy(r["counts"].reshape(-1)).to(dev))

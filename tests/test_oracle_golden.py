@@ -1,0 +1,197 @@
+"""CPU tests: the oracle (oracle/) against the golden vectors produced by the reference itself.
+
+This is what pins the oracle.  Tolerances, where not exact, are stated at the assert together with their cause.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import nets
+from conftest import load_golden, torus_rel_l2, ulp_diff
+from oracle import reference_sampler as RS
+
+
+def test_philox_known_answer(oracle):
+    # Random123 known-answer vector for philox4x32-10, zero counter and key
+    assert list(oracle.philox(0, 0, 0, 0, 0, 0)) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    # and the all-ones vector
+    assert list(oracle.philox(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF)) == \
+        [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+
+
+def test_math_sequences_accuracy(oracle):
+    rng = np.random.default_rng(0)
+    x = np.exp(rng.uniform(-60, 60, 5000)).astype(np.float32)
+    ref = np.log(x.astype(np.float64))
+    assert (np.abs(oracle.logf(x) - ref) <= 1.0 * np.spacing(np.abs(ref).astype(np.float32))).all()   # < 1 ulp
+    x = rng.uniform(-80, 20, 5000).astype(np.float32)
+    ref = np.exp(x.astype(np.float64))
+    assert (np.abs(oracle.expf(x) - ref) <= 1.0 * np.spacing(ref.astype(np.float32))).all()
+    v = rng.uniform(0, 2, 5000).astype(np.float32)
+    sc = oracle.sincospif(v)
+    assert np.abs(sc[:, 0] - np.sin(np.pi * v.astype(np.float64))).max() < 2e-7
+    assert np.abs(sc[:, 1] - np.cos(np.pi * v.astype(np.float64))).max() < 2e-7
+    assert oracle.logf(np.float32(0.0)) == -np.inf and oracle.expf(np.float32(-np.inf)) == 0.0
+
+
+def test_schedule_tables(oracle):
+    g = load_golden("schedules.npz")
+    for name in g["names"]:
+        T, st, td, smin, smax, ce, C = g[f"{name}/params"]
+        s = oracle.noise_schedule(int(T), ["exponential", "linear"][int(st)], td, smin, smax, ce, int(C))
+        for key in ("time", "beta", "alpha_bar", "q_matrix", "q_bar_matrix", "q_bar_tm1_matrix"):
+            assert np.array_equal(s[key], g[f"{name}/{key}"]), (name, key)        # bit-exact
+        if int(st) == 1:    # linear sigma(t): only +,* -> bit-exact, and so are sigma^2, g^2, epsilon
+            for key in ("sigma", "sigma_squared", "g_squared", "epsilon"):
+                assert np.array_equal(s[key], g[f"{name}/{key}"]), (name, key)
+        # exponential sigma(t): the reference's fp32 pow (Sleef, 1 ulp) vs the oracle's correctly rounded pow
+        assert ulp_diff(s["sigma"], g[f"{name}/sigma"]).max() <= 2, name
+        # g^2 = sigma_i^2 - sigma_{i-1}^2 amplifies that by the cancellation (relative step ~1e-2): <= 2e-5 relative
+        np.testing.assert_allclose(s["g_squared"], g[f"{name}/g_squared"], rtol=2e-5, atol=0)
+        np.testing.assert_allclose(s["epsilon"], g[f"{name}/epsilon"], rtol=2e-6, atol=0)
+        # sqrt: IEEE-correct in the oracle; torch's AVX512 sqrt is faithfully (not correctly) rounded -> 1 ulp
+        np.testing.assert_allclose(s["g"], g[f"{name}/g"], rtol=1.1e-5, atol=0)
+        np.testing.assert_allclose(s["sqrt_2_epsilon"], g[f"{name}/sqrt_2_epsilon"], rtol=2e-6, atol=0)
+
+
+def test_coordinates_lattice_and_wrap(oracle):
+    g = load_golden("p1_coordinates.npz")
+    for k in range(len(g["scalars"])):
+        w, n, sig = g["scalars"][k]
+        assert np.array_equal(oracle.coordinates_update(g["x"], g["s"], g["z"], w, n, sig), g["x_out"][k])
+    assert np.array_equal(oracle.wrap(g["wrap_in"]), g["wrap_out"])
+    assert oracle.wrap(np.float32(-1e-8)) == 0.0          # tests/utils/test_basis_transformations.py:76-110
+    g = load_golden("p3_lattice.npz")
+    for k in range(len(g["scalars"])):
+        w, n, sig, sigma_n = g["scalars"][k]
+        sn = np.float32(sig) / np.float32(float(g["n_atoms"]) ** (1 / 3))
+        assert sn == np.float32(sigma_n)
+        assert np.array_equal(oracle.lattice_update(g["l"], g["s"], g["z"], w, n, sn), g["l_out"][k])
+
+
+def test_atom_types_update(oracle):
+    g = load_golden("p2_atom_types.npz")
+    total = 0
+    for name in g["names"]:
+        greedy, one, idx, T = g[f"{name}/flags"]
+        a, p, gm = oracle.atom_types_update(g[f"{name}/logits"], g[f"{name}/a"], g[f"{name}/q"], g[f"{name}/qbar"],
+                                            g[f"{name}/qbar_tm1"], g[f"{name}/gumbel"], g[f"{name}/u"], 1e-8, greedy,
+                                            one, True)
+        assert np.array_equal(a, g[f"{name}/a_out"]), name                 # atom types: exact
+        assert np.array_equal(gm, g[f"{name}/gumbel_used"]), name
+        d = ulp_diff(p, g[f"{name}/p"])
+        if name.startswith("C2_"):
+            assert d.max() == 0, name                                      # one atom type: softmax is exact
+        assert d.max() <= 4, name                                          # exp inside softmax (Sleef vs MDX): <= 4 ulp
+        total += a.size
+    assert total == 3456
+
+
+def test_noisers(oracle):
+    g = load_golden("noisers.npz")
+    for b in range(g["f1_x0"].shape[0]):
+        assert np.array_equal(oracle.noise_coordinates(g["f1_x0"][b], g["f1_z"][b], g["f1_sigma"][b, 0, 0]),
+                              g["f1_xt"][b])
+    for nm in g["f2_names"]:
+        assert np.array_equal(oracle.noise_atom_types(g[f"{nm}/a0"], g[f"{nm}/qbar"], g[f"{nm}/u"]), g[f"{nm}/at"])
+
+
+def test_radius_graph(oracle):
+    g = load_golden("neighbors.npz")
+    for name in g["names"]:
+        cart, cell, rc = g[f"{name}/cart"], g[f"{name}/cell"], float(g[f"{name}/rc"])
+        B, N, _ = cart.shape
+        full = oracle.radius_graph(cart, cell, rc, unique=False)
+        eb = np.repeat(np.arange(B), full["counts"].sum(1))
+        lv = np.stack([oracle.image_vectors(cell[b]) for b in range(B)])
+        shifts = lv[eb, full["image"]]
+        mine = np.stack([eb, full["src"], full["dst"]], 1)
+        key = np.lexsort((shifts[:, 2], shifts[:, 1], shifts[:, 0], mine[:, 2], mine[:, 1], mine[:, 0]))
+        gold = np.concatenate([g[f"{name}/edge_batch_sorted"][:, None], g[f"{name}/adj_sorted"].T], 1)
+        assert np.array_equal(mine[key], gold), name                          # same edge multiset
+        assert np.array_equal(shifts[key], g[f"{name}/shifts_sorted"]), name  # same shifts, bitwise
+        assert np.array_equal(full["counts"].sum(1), g[f"{name}/number_of_edges"])
+        uq = oracle.radius_graph(cart, cell, rc, unique=True)
+        assert np.array_equal(np.stack([uq["src"], uq["dst"]], 1), g[f"{name}/unique_edges"]), name
+
+
+def test_radius_graph_cutoff_too_large(oracle):
+    cart = np.random.default_rng(0).random((1, 4, 3), dtype=np.float32) * 4
+    cell = np.diag([4.0, 4.0, 4.0]).astype(np.float32)[None]
+    with pytest.raises(oracle.CutoffTooLarge):
+        oracle.radius_graph(cart, cell, 4.5, unique=True)
+
+
+def _run_oracle_trajectory(name, table, constraint_from=None):
+    g = load_golden(name + ".npz")
+    noise_kw, sampling_kw, netf = table[name]
+    npar, spar = cases.as_objects(noise_kw, sampling_kw)
+    net = nets.fake_net(spar.num_atom_types) if netf is None else nets.load_fixture_weights(
+        netf(nets.oracle_edge_builder), g)
+    constraint = None
+    if constraint_from:
+        constraint = dict(constrained_relative_coordinates=g["constrained_relative_coordinates"],
+                          constrained_atom_types=g["constrained_atom_types"],
+                          constrained_indices=g["constrained_indices"])
+    replay = RS.ReplayNoise(g)
+    gen = RS.OracleLangevinGenerator(npar, spar, net, constraint=constraint, noise=replay)
+    gen.record = True
+    out = gen.sample(int(g["batch"]))
+    assert replay.exhausted(), "the oracle consumed fewer draws than the reference"
+    return g, gen, out
+
+
+@pytest.mark.parametrize("name", list(cases.TRAJECTORIES))
+def test_whole_trajectories(oracle, name):
+    g, gen, out = _run_oracle_trajectory(name, cases.TRAJECTORIES)
+    assert np.array_equal(out.A, g["final_A"])                                   # atom types: exact
+    # coordinates: tolerance of north_star (1e-5 rel-L2 on the torus); observed ~1e-7
+    assert torus_rel_l2(out.X, g["final_X"]) < 1e-5
+    np.testing.assert_allclose(out.L, g["final_L"], rtol=1e-5, atol=1e-6)
+    # step by step against the reference's own recorder
+    preds = [r for r in gen.records if r[0] == "predictor"]
+    assert [r[1] for r in preds] == list(g["pred_index"])
+    for k, (_, _, comp_i, comp_im1, pred) in enumerate(preds):
+        assert np.array_equal(comp_im1.A, g["pred_composition_im1_A"][k]), (name, k)
+        assert torus_rel_l2(comp_im1.X, g["pred_composition_im1_X"][k]) < 1e-5
+    corrs = [r for r in gen.records if r[0] == "corrector"]
+    if "corr_index" in g.files:
+        assert [r[1] for r in corrs] == list(g["corr_index"])
+        for k, (_, _, comp_i, corrected, pred) in enumerate(corrs):
+            assert np.array_equal(corrected.A, g["corr_corrected_composition_i_A"][k])
+            assert torus_rel_l2(corrected.X, g["corr_corrected_composition_i_X"][k]) < 1e-5
+
+
+@pytest.mark.parametrize("name", list(cases.REPAINT))
+def test_repaint_trajectories(oracle, name):
+    g, gen, out = _run_oracle_trajectory(name, cases.REPAINT, constraint_from=True)
+    assert np.array_equal(out.A, g["final_A"])
+    assert torus_rel_l2(out.X, g["final_X"]) < 1e-5
+    idx = g["constrained_indices"]
+    assert np.array_equal(out.X[:, idx], np.broadcast_to(g["constrained_relative_coordinates"], out.X[:, idx].shape))
+    assert np.array_equal(out.A[:, idx], np.broadcast_to(g["constrained_atom_types"], out.A[:, idx].shape))
+    for k, (_, _, _, comp_im1, _) in enumerate([r for r in gen.records if r[0] == "predictor"]):
+        # the reference records the raw predictor output, before repainting
+        assert np.array_equal(comp_im1.A, g["pred_composition_im1_A"][k])
+
+
+def test_batch_of_samples(oracle):
+    g = load_golden("batch_of_samples.npz")
+    npar, spar = cases.as_objects(cases.noise_ns(6), cases.sampling_ns(8, 1))
+    gen = RS.OracleLangevinGenerator(npar, spar, nets.fake_net(1), noise=RS.ReplayNoise(g))
+    batch = RS.create_batch_of_samples(gen, 7, 3)
+    assert np.array_equal(batch["original_axl"].A, g["A"])
+    assert torus_rel_l2(batch["original_axl"].X, g["X"]) < 1e-5
+    np.testing.assert_allclose(batch["cartesian_positions"], g["cartesian_positions"], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(batch["original_axl"].L, g["L"])
+
+
+def test_philox_mode_is_order_free_and_reproducible(oracle):
+    npar, spar = cases.as_objects(cases.noise_ns(5), cases.sampling_ns(8, 2, M=2))
+    a = RS.OracleLangevinGenerator(npar, spar, nets.fake_net(2), noise=RS.PhiloxNoise(7, 0)).sample(4)
+    b = RS.OracleLangevinGenerator(npar, spar, nets.fake_net(2), noise=RS.PhiloxNoise(7, 0)).sample(4)
+    c = RS.OracleLangevinGenerator(npar, spar, nets.fake_net(2), noise=RS.PhiloxNoise(7, 1)).sample(4)
+    assert np.array_equal(a.X, b.X) and np.array_equal(a.A, b.A)
+    assert not np.array_equal(a.X, c.X)
+    assert (a.A != 2).all() and (a.X >= 0).all() and (a.X < 1).all()
