@@ -1,0 +1,308 @@
+"""GPU parity tests of the generators (the HIP path behind the reference's generator API).
+
+  * reference-RNG mode, draws replayed from the golden fixtures -> final and per-step compositions against the
+    reference's own recorded trajectories (A exact; X <= 1e-5 rel-L2 on the torus, the tolerance of north_star);
+  * the same runs against the CPU oracle: with the echo network (whose forward is exact on both sides) every
+    float must be BIT-IDENTICAL; with real networks the GPU/CPU forward differs by ~1e-6 and the tolerance applies;
+  * device-RNG (Philox) mode against the oracle evaluating the same specification; graph replay == eager;
+  * BASELINE-size runs checked through size-independent properties.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import nets
+from conftest import load_golden, torus_rel_l2
+from oracle import reference_sampler as RS
+
+pytestmark = pytest.mark.gpu
+
+
+def _pkg():
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.constrained_langevin_generator import \
+        ConstrainedLangevinGenerator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.noise_sources import ReferenceOrderNoise
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.predictor_corrector_axl_generator import \
+        PredictorCorrectorSamplingParameters
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.sampling_constraint import SamplingConstraint
+    from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters
+    return dict(Langevin=LangevinGenerator, Constrained=ConstrainedLangevinGenerator, RefNoise=ReferenceOrderNoise,
+                Sampling=PredictorCorrectorSamplingParameters, Constraint=SamplingConstraint, Noise=NoiseParameters)
+
+
+def _replayed(fixture):
+    P = _pkg()
+
+    class Replayed(P["RefNoise"]):
+        def __init__(self, g):
+            self.inner = RS.ReplayNoise(g)
+
+        def rand(self, *shape):
+            shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else shape
+            return torch.from_numpy(self.inner.rand(*shape))
+
+        def randn(self, *shape):
+            shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else shape
+            return torch.from_numpy(self.inner.randn(*shape))
+
+    return Replayed(fixture)
+
+
+def _build(name, table, cuda, fixture=None, constraint=None, **extra):
+    import warnings
+    P = _pkg()
+    noise_kw, sampling_kw, netf = table[name]
+    skw = dict(sampling_kw)
+    skw.update(extra)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar, spar = P["Noise"](**noise_kw), P["Sampling"](**skw)
+    if netf is None:
+        net_gpu, net_cpu = nets.fake_net(spar.num_atom_types), nets.fake_net(spar.num_atom_types)
+    else:
+        net_gpu = netf(None)
+        net_cpu = netf(nets.oracle_edge_builder)
+        if fixture is not None:
+            nets.load_fixture_weights(net_gpu, fixture)
+        net_cpu.load_state_dict(net_gpu.state_dict())
+    net_gpu = net_gpu.to(cuda)
+    if constraint is not None:
+        gen = P["Constrained"](npar, spar, net_gpu, constraint)
+    else:
+        gen = P["Langevin"](npar, spar, net_gpu)
+    return gen, npar, spar, net_cpu
+
+
+def _np(axl):
+    return RS.AXL(A=axl.A.cpu().numpy(), X=axl.X.cpu().numpy(), L=axl.L.cpu().numpy())
+
+
+@pytest.mark.parametrize("name", list(cases.TRAJECTORIES))
+def test_reference_mode_against_golden_and_oracle(cuda, name):
+    g = load_golden(name + ".npz")
+    gen, npar, spar, net_cpu = _build(name, cases.TRAJECTORIES, cuda, fixture=g, record_samples=True,
+                                      record_samples_corrector_steps=True)
+    gen.noise_source = _replayed(g)
+    with torch.no_grad():
+        out = _np(gen.sample(int(g["batch"]), cuda))
+    assert gen.noise_source.inner.exhausted()
+    # against the reference
+    assert np.array_equal(out.A, g["final_A"])
+    assert torus_rel_l2(out.X, g["final_X"]) < 1e-5
+    np.testing.assert_allclose(out.L, g["final_L"], rtol=1e-5, atol=1e-6)
+    rec = gen.sample_trajectory_recorder._internal_data
+    assert [e["time_step_index"] for e in rec["predictor_step"]] == list(g["pred_index"])
+    for k, e in enumerate(rec["predictor_step"]):
+        assert np.array_equal(e["composition_im1"].A.numpy(), g["pred_composition_im1_A"][k])
+        assert torus_rel_l2(e["composition_im1"].X.numpy(), g["pred_composition_im1_X"][k]) < 1e-5
+        # the network outputs recorded by the reference (GPU forward vs its CPU forward)
+        np.testing.assert_allclose(e["model_predictions_i"].X.numpy(), g["pred_model_predictions_i_X"][k],
+                                   rtol=2e-4, atol=2e-5)
+    if "corr_index" in g.files:
+        assert [e["time_step_index"] for e in rec["corrector_step"]] == list(g["corr_index"])
+    # against the oracle on the same draws
+    ora = RS.OracleLangevinGenerator(npar, spar, net_cpu, noise=RS.ReplayNoise(g)).sample(int(g["batch"]))
+    assert np.array_equal(out.A, ora.A)
+    if cases.TRAJECTORIES[name][2] is None:      # echo network: exact forward on both sides => bit-identical floats
+        assert np.array_equal(out.X.view(np.int32), ora.X.view(np.int32))
+        assert np.array_equal(out.L.view(np.int32), ora.L.view(np.int32))
+    else:
+        assert torus_rel_l2(out.X, ora.X) < 1e-5
+
+
+@pytest.mark.parametrize("name", list(cases.REPAINT))
+def test_repaint_reference_mode(cuda, name):
+    P = _pkg()
+    g = load_golden(name + ".npz")
+    nat = cases.REPAINT[name][1]["num_atom_types"]
+    constraint = P["Constraint"](elements=["Si", "Ge"][:nat],
+                                 constrained_relative_coordinates=torch.from_numpy(g["constrained_relative_coordinates"]),
+                                 constrained_atom_types=torch.from_numpy(g["constrained_atom_types"]),
+                                 constrained_indices=torch.from_numpy(g["constrained_indices"]))
+    gen, npar, spar, net_cpu = _build(name, cases.REPAINT, cuda, fixture=g, constraint=constraint)
+    gen.noise_source = _replayed(g)
+    with torch.no_grad():
+        out = _np(gen.sample(int(g["batch"]), cuda))
+    assert gen.noise_source.inner.exhausted()
+    assert np.array_equal(out.A, g["final_A"])
+    assert torus_rel_l2(out.X, g["final_X"]) < 1e-5
+    idx = g["constrained_indices"]
+    assert np.array_equal(out.X[:, idx], np.broadcast_to(g["constrained_relative_coordinates"], out.X[:, idx].shape))
+    assert np.array_equal(out.A[:, idx], np.broadcast_to(g["constrained_atom_types"], out.A[:, idx].shape))
+
+
+DEVICE_CASES = ["traj_fake_c2", "traj_fake_c3_m2", "traj_fake_c5_nogreedy", "traj_fake_c5_test",
+                "traj_fake_free_lattice", "traj_mlp_c1", "traj_mlp_c3", "traj_egnn_fc", "traj_egnn_rc"]
+
+
+@pytest.mark.parametrize("name", DEVICE_CASES)
+def test_device_rng_mode_against_oracle(cuda, name):
+    seed, batch = 20250815, 6
+    gen, npar, spar, net_cpu = _build(name, cases.TRAJECTORIES, cuda, rng_mode="device", seed=seed)
+    with torch.no_grad():
+        first = _np(gen.sample(batch, cuda))
+        second = _np(gen.sample(batch, cuda))          # second call -> Philox call index 1
+    for call, out in enumerate((first, second)):
+        ora = RS.OracleLangevinGenerator(npar, spar, net_cpu, noise=RS.PhiloxNoise(seed, call)).sample(batch)
+        assert np.array_equal(out.A, ora.A), (name, call)
+        if cases.TRAJECTORIES[name][2] is None:
+            assert np.array_equal(out.X.view(np.int32), ora.X.view(np.int32))
+            assert np.array_equal(out.L.view(np.int32), ora.L.view(np.int32))
+        else:
+            assert torus_rel_l2(out.X, ora.X) < 1e-5
+        assert (out.A != spar.num_atom_types).all()
+    assert not np.array_equal(first.X, second.X)
+
+
+@pytest.mark.parametrize("name", ["traj_repaint_fake", "traj_repaint_mlp"])
+def test_repaint_device_rng_against_oracle(cuda, name):
+    P = _pkg()
+    rng = np.random.default_rng(3)
+    nat = cases.REPAINT[name][1]["num_atom_types"]
+    cx = rng.random((4, 3), dtype=np.float32)
+    ca = rng.integers(0, nat, 4)
+    cidx = np.array([5, 0, 2, 7])
+    constraint = P["Constraint"](elements=["Si", "Ge"][:nat], constrained_relative_coordinates=torch.from_numpy(cx),
+                                 constrained_atom_types=torch.from_numpy(ca), constrained_indices=torch.from_numpy(cidx))
+    gen, npar, spar, net_cpu = _build(name, cases.REPAINT, cuda, constraint=constraint, rng_mode="device", seed=11)
+    with torch.no_grad():
+        out = _np(gen.sample(5, cuda))
+    ora = RS.OracleLangevinGenerator(npar, spar, net_cpu, noise=RS.PhiloxNoise(11, 0),
+                                     constraint=dict(constrained_relative_coordinates=cx, constrained_atom_types=ca,
+                                                     constrained_indices=cidx)).sample(5)
+    assert np.array_equal(out.A, ora.A)
+    if cases.REPAINT[name][2] is None:
+        assert np.array_equal(out.X.view(np.int32), ora.X.view(np.int32))
+    else:
+        assert torus_rel_l2(out.X, ora.X) < 1e-5
+    assert np.array_equal(out.X[:, cidx], np.broadcast_to(cx, (5, 4, 3)))
+
+
+@pytest.mark.parametrize("name", ["traj_fake_c3_m2", "traj_mlp_c1", "traj_mlp_c3"])
+def test_graph_replay_equals_eager(cuda, name):
+    outs = []
+    for use_graph in (False, True):
+        gen, *_ = _build(name, cases.TRAJECTORIES, cuda, rng_mode="device", seed=5, use_hip_graph=use_graph)
+        torch.manual_seed(1)
+        with torch.no_grad():
+            outs.append(_np(gen.sample(32, cuda)))
+    assert np.array_equal(outs[0].A, outs[1].A)
+    assert np.array_equal(outs[0].X.view(np.int32), outs[1].X.view(np.int32))   # same kernels, same draws
+
+
+def test_graph_replay_repaint(cuda):
+    P = _pkg()
+    constraint = P["Constraint"](elements=["Si"], constrained_relative_coordinates=torch.rand(3, 3),
+                                 constrained_atom_types=torch.zeros(3, dtype=torch.long))
+    outs = []
+    for use_graph in (False, True):
+        gen, *_ = _build("traj_repaint_mlp", cases.REPAINT, cuda, constraint=constraint, rng_mode="device", seed=9,
+                         use_hip_graph=use_graph)
+        with torch.no_grad():
+            outs.append(_np(gen.sample(16, cuda)))
+    assert np.array_equal(outs[0].A, outs[1].A)
+    assert np.array_equal(outs[0].X.view(np.int32), outs[1].X.view(np.int32))
+
+
+def test_batch_driver_against_golden(cuda):
+    from diffusion_for_multi_scale_molecular_dynamics_amd.sampling.diffusion_sampling import create_batch_of_samples
+    g = load_golden("batch_of_samples.npz")
+    P = _pkg()
+    npar = P["Noise"](**cases.noise_ns(6))
+    spar = P["Sampling"](**dict(cases.sampling_ns(8, 1), number_of_samples=7, sample_batchsize=3))
+    gen = P["Langevin"](npar, spar, nets.fake_net(1).to(cuda))
+    gen.noise_source = _replayed(g)
+    with torch.no_grad():
+        batch = create_batch_of_samples(gen, spar, cuda)
+    assert np.array_equal(batch["original_axl"].A.cpu().numpy(), g["A"])
+    assert torus_rel_l2(batch["original_axl"].X.cpu().numpy(), g["X"]) < 1e-5
+    np.testing.assert_allclose(batch["cartesian_positions"].cpu().numpy(), g["cartesian_positions"], rtol=1e-5, atol=1e-5)
+
+
+def test_last_step_mask_is_reported(cuda):
+    """A network that only ever predicts MASK-compatible garbage: all logits -inf is invalid input; the reference
+    asserts at the last step, the build raises after the single end-of-run status read."""
+    P = _pkg()
+
+    class NanNet(nets.FakeAXLNetwork):
+        def _forward_unchecked(self, batch, conditional=False):
+            out = super()._forward_unchecked(batch, conditional)
+            return RS.AXL(A=torch.full_like(out.A, float("nan")), X=out.X, L=out.L)
+
+    npar = P["Noise"](**cases.noise_ns(3))
+    spar = P["Sampling"](**cases.sampling_ns(4, 1, greedy=False, one=False), rng_mode="device", seed=1)
+    net = NanNet(nets.ScoreNetworkParameters(architecture="dummy", num_atom_types=1)).to(cuda)
+    gen = P["Langevin"](npar, spar, net)
+    with pytest.raises(AssertionError, match="MASKED atoms"):
+        gen.sample(2, cuda)
+
+
+@pytest.mark.parametrize("config", ["C2", "C4"])
+def test_baseline_size_properties(cuda, config):
+    """BASELINE-size batches (few steps): invariants that do not need the oracle at full size."""
+    P = _pkg()
+    if config == "C2":      # Si 1x1x1, MLP, B=1024
+        B, N, nat, M = 1024, 8, 1, 1
+        net = nets.mlp_net(N, nat, seed=1234)
+        noise_kw = cases.noise_ns(12, sigma_min=1e-4, sigma_max=0.25)
+        skw = cases.sampling_ns(N, nat, M=M)
+    else:                   # SiGe 2x2x2 shard, EGNN radial cutoff, two atom types, B=512 (reduced width/steps)
+        B, N, nat, M = 512, 64, 2, 2
+        net = nets.egnn_net(nat, "radial_cutoff", 7.5, hidden=32, seed=1234)
+        noise_kw = cases.noise_ns(4, **cases.LIN)
+        skw = cases.sampling_ns(N, nat, M=M, cell=[11.084] * 3)
+    gen = P["Langevin"](P["Noise"](**noise_kw), P["Sampling"](**skw, rng_mode="device", seed=77), net.to(cuda))
+    with torch.no_grad():
+        a = gen.sample(B, cuda)
+        b = gen.sample(B, cuda)
+    for out in (a, b):
+        assert out.X.shape == (B, N, 3) and out.A.shape == (B, N)
+        assert bool(((out.X >= 0) & (out.X < 1)).all())
+        assert bool(((out.A >= 0) & (out.A < nat)).all())            # fully unmasked
+        assert bool(torch.isfinite(out.X).all())
+    assert not torch.equal(a.X, b.X)
+    # same seed, fresh generator => same stream (counter-based RNG: a pure function of (seed, call, step, atom))
+    gen2 = P["Langevin"](P["Noise"](**noise_kw), P["Sampling"](**skw, rng_mode="device", seed=77), net.to(cuda))
+    with torch.no_grad():
+        a2 = gen2.sample(B, cuda)
+    assert torch.equal(a.A, a2.A)
+    if config == "C2":
+        assert torch.equal(a.X, a2.X)
+
+
+def test_cli_end_to_end(cuda, tmp_path):
+    """Counterpart of the reference's tests/test_sample_diffusion.py:197-237 on the GPU path."""
+    import yaml
+    from diffusion_for_multi_scale_molecular_dynamics_amd import sample_diffusion
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.sampling_constraint import (
+        SamplingConstraint, write_sampling_constraint)
+    cfg = dict(noise=dict(total_time_steps=10, sigma_min=1e-4, sigma_max=0.25),
+               sampling=dict(algorithm="predictor_corrector", spatial_dimension=3, number_of_atoms=8,
+                             number_of_samples=12, sample_batchsize=5, num_atom_types=1,
+                             number_of_corrector_steps=1, record_samples=True, use_fixed_lattice_parameters=True,
+                             cell_dimensions=[5.43, 5.43, 5.43]),
+               elements=["Si"],
+               model=dict(score_network=dict(architecture="mlp", number_of_atoms=8, num_atom_types=1,
+                                             n_hidden_dimensions=2, hidden_dimensions_size=16,
+                                             relative_coordinates_embedding_dimensions_size=8,
+                                             noise_embedding_dimensions_size=4, time_embedding_dimensions_size=4,
+                                             atom_type_embedding_dimensions_size=1,
+                                             lattice_parameters_embedding_dimensions_size=1)))
+    (tmp_path / "config.yaml").write_text(yaml.safe_dump(cfg))
+    constraint = SamplingConstraint(elements=["Si"], constrained_relative_coordinates=torch.rand(3, 3),
+                                    constrained_atom_types=torch.zeros(3, dtype=torch.long))
+    write_sampling_constraint(constraint, tmp_path / "constraint.pkl")
+    for sub, extra in (("plain", []), ("repaint", ["--path_to_sampling_constraint_data_pickle",
+                                                   str(tmp_path / "constraint.pkl")])):
+        out = tmp_path / sub
+        sample_diffusion.main(["--config", str(tmp_path / "config.yaml"), "--output", str(out), "--device", "cuda",
+                               "--random_init_seed", "3"] + extra)
+        samples = torch.load(out / "samples.pt", weights_only=False)
+        assert samples["cartesian_positions"].shape == (12, 8, 3)
+        assert samples["original_axl"].A.shape == (12, 8) and samples["original_axl"].L.shape == (12, 6)
+        assert (out / "trajectories.pt").exists() and (out / "config_backup.yaml").exists()
+        if sub == "repaint":
+            x = samples["original_axl"].X[:, :3].cpu()
+            assert torch.equal(x, constraint.constrained_relative_coordinates.expand(12, 3, 3))

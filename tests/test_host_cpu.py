@@ -1,0 +1,231 @@
+"""CPU tests of the host side: ABI surface, loud failure without a GPU, config/factory logic, sharded driver."""
+import os
+import re
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import nets
+from conftest import ROOT, load_golden
+
+PKG = "diffusion_for_multi_scale_molecular_dynamics_amd"
+
+
+def test_library_exports_every_declared_symbol():
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip
+    _hip.build()
+    header = open(os.path.join(ROOT, "include", "mdx_hip.h")).read()
+    declared = re.findall(r"MDX_API\s+(?:const\s+char\*|int)\s+(mdx_[a-z0-9_]+)\s*\(", header)
+    assert len(declared) >= 17 and sorted(declared) == sorted(_hip.ABI_SYMBOLS)
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", _hip.LIB_PATH], text=True)
+    for sym in declared:
+        assert re.search(rf"\sT\s{sym}\b", exported), f"{sym} is declared in include/mdx_hip.h but not exported"
+    lib = _hip.lib()                      # loads without a GPU; no compute call is made here
+    assert lib.mdx_abi_version() == 1
+    assert lib.mdx_status_string(-2).decode() == "unsupported size or option"
+    # the shared object carries gfx950 code
+    assert b"gfx950" in open(_hip.LIB_PATH, "rb").read()
+
+
+def test_no_cpu_fallback():
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.predictor_corrector_axl_generator import \
+        PredictorCorrectorSamplingParameters
+    from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters
+    x = torch.rand(4, 3)
+    with pytest.raises(_hip.MdxError, match="no CPU fallback"):
+        kernels.relative_coordinates_update(x, x, x, 0.1, 0.1, 0.1)
+    gen = LangevinGenerator(NoiseParameters(total_time_steps=3),
+                            PredictorCorrectorSamplingParameters(**cases.sampling_ns(4, 1)), nets.fake_net(1))
+    with pytest.raises(_hip.MdxError, match="GPU hot path only"):
+        gen.sample(2, torch.device("cpu"))
+    with pytest.raises(_hip.MdxError):
+        kernels.noise_schedule_build(10, "linear", 1e-5, 1e-3, 0.5, 2e-5, 2, "cpu")
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: no module of the product package may import or load it."""
+    pkg_dir = os.path.join(ROOT, PKG)
+    pattern = re.compile(r"^\s*(from|import)\s+[\w.]*oracle|mdx_oracle|libmdx_oracle", re.M)
+    for base, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                assert not pattern.search(open(os.path.join(base, f)).read()), f"{f} refers to the oracle"
+
+
+def test_parameters_and_factories(tmp_path):
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.constrained_langevin_generator import \
+        ConstrainedLangevinGenerator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.instantiate_generator import instantiate_generator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.load_sampling_parameters import \
+        load_sampling_parameters
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.sampling_constraint import (
+        SamplingConstraint, read_sampling_constraint, write_sampling_constraint)
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.trajectory_initializer import (
+        FullRandomTrajectoryInitializer, StartFromGivenConfigurationTrajectoryInitializer,
+        instantiate_trajectory_initializer)
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import AXL
+    from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters
+
+    with pytest.raises(AssertionError):
+        NoiseParameters(total_time_steps=10, schedule_type="cosine")
+    sp = load_sampling_parameters(dict(cases.sampling_ns(8, 1), cell_dimensions=[5.43, 5.43, 5.43]))
+    assert sp.number_of_corrector_steps == 1 and sp.small_epsilon == 1e-8 and sp.rng_mode == "reference"
+    assert torch.equal(sp.fixed_lattice_parameters, torch.tensor([5.43, 5.43, 5.43, 0, 0, 0]))
+    with pytest.raises(AssertionError):
+        load_sampling_parameters(dict(cases.sampling_ns(8, 1), algorithm="euler"))
+    with pytest.raises(NotImplementedError):
+        load_sampling_parameters(dict(cases.sampling_ns(8, 1), algorithm="ode"))
+    with pytest.raises(AssertionError):          # fixed lattice without cell dimensions
+        load_sampling_parameters(dict(cases.sampling_ns(8, 1), cell_dimensions=None))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        load_sampling_parameters(cases.sampling_ns(8, 1, fixed=False))
+        assert any("experimental" in str(x.message) for x in w)
+
+    init = instantiate_trajectory_initializer(sp)
+    assert isinstance(init, FullRandomTrajectoryInitializer)
+    comp = init.initialize(5, torch.device("cpu"))
+    assert (comp.A == 1).all() and comp.X.shape == (5, 8, 3) and ((comp.X >= 0) & (comp.X < 1)).all()
+    assert torch.equal(comp.L, sp.fixed_lattice_parameters.repeat(5, 1))
+    assert init.create_start_time_step_index(17) == 17 and init.create_end_time_step_index() == 0
+
+    start = dict(noisy_axl=AXL(A=torch.zeros(2, 8, dtype=torch.long), X=torch.rand(2, 8, 3), L=torch.rand(2, 6)),
+                 start_time_step_index=4)
+    torch.save(start, tmp_path / "start.pkl")
+    init2 = instantiate_trajectory_initializer(sp, str(tmp_path / "start.pkl"))
+    assert isinstance(init2, StartFromGivenConfigurationTrajectoryInitializer)
+    assert init2.create_start_time_step_index(100) == 4
+    assert torch.equal(init2.initialize(2, torch.device("cpu")).X, start["noisy_axl"].X)
+    with pytest.raises(AssertionError):
+        init2.initialize(3, torch.device("cpu"))
+
+    c = SamplingConstraint(elements=["Si"], constrained_relative_coordinates=torch.rand(3, 3),
+                           constrained_atom_types=torch.zeros(3, dtype=torch.long))
+    write_sampling_constraint(c, tmp_path / "c.pkl")
+    c2 = read_sampling_constraint(tmp_path / "c.pkl")
+    assert torch.equal(c.constrained_relative_coordinates, c2.constrained_relative_coordinates)
+    with pytest.raises(AssertionError):
+        SamplingConstraint(elements=["Si"], constrained_relative_coordinates=torch.rand(3, 3),
+                           constrained_atom_types=torch.ones(3, dtype=torch.long))
+    with pytest.raises(AssertionError):
+        SamplingConstraint(elements=["Si"], constrained_relative_coordinates=torch.rand(3, 3).double(),
+                           constrained_atom_types=torch.zeros(3, dtype=torch.long))
+
+    npar = NoiseParameters(total_time_steps=5)
+    gen = instantiate_generator(sp, npar, nets.fake_net(1), init)
+    assert type(gen) is LangevinGenerator
+    gen = instantiate_generator(sp, npar, nets.fake_net(1), init, sampling_constraints=c)
+    assert type(gen) is ConstrainedLangevinGenerator and torch.equal(gen.constraint_indices, torch.arange(3))
+    with pytest.raises(AssertionError):          # more constraints than atoms
+        big = SamplingConstraint(elements=["Si"], constrained_relative_coordinates=torch.rand(9, 3),
+                                 constrained_atom_types=torch.zeros(9, dtype=torch.long))
+        instantiate_generator(sp, npar, nets.fake_net(1), init, sampling_constraints=big)
+    with pytest.raises(AssertionError):          # T = 1 is refused like in the reference
+        LangevinGenerator(NoiseParameters(total_time_steps=1), sp, nets.fake_net(1))
+
+
+def test_score_networks_against_reference_forward():
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
+                                                                              NOISY_AXL_COMPOSITION, TIME)
+    for name, net in (("net_mlp_c1", nets.mlp_net(8, 1)), ("net_mlp_c3", nets.mlp_net(8, 2)),
+                      ("net_egnn_fc", nets.egnn_net(1, "fully_connected", None)),
+                      ("net_egnn_rc", nets.egnn_net(2, "radial_cutoff", 7.5, edge_builder=nets.oracle_edge_builder))):
+        g = load_golden(name + ".npz")
+        nets.load_fixture_weights(net, g)
+        batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.from_numpy(g["A"]), X=torch.from_numpy(g["X"]),
+                                            L=torch.from_numpy(g["L"])),
+                 TIME: torch.from_numpy(g["time"]), NOISE: torch.from_numpy(g["noise"]),
+                 CARTESIAN_FORCES: torch.zeros(g["X"].shape)}
+        with torch.no_grad():
+            out = net(batch, conditional=False)
+        assert torch.isinf(out.A[..., -1]).all() and (out.A[..., -1] < 0).all()       # MASK logit forced to -inf
+        np.testing.assert_allclose(out.X.numpy(), g["out_X"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(out.A.numpy()[..., :-1], g["out_A"][..., :-1], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(out.L.numpy(), g["out_L"], rtol=1e-4, atol=1e-6)
+
+
+def test_bloch_vectors_and_edges_batch():
+    from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import \
+        positive_bloch_wave_vectors
+    from diffusion_for_multi_scale_molecular_dynamics_amd.utils.neighbors import get_edges_batch
+    assert torch.equal(positive_bloch_wave_vectors(1, 3), torch.eye(3))
+    k2 = positive_bloch_wave_vectors(2, 3)
+    assert k2.shape == (9, 3) and torch.equal(k2[:3], torch.eye(3)) and ((k2[3:] ** 2).sum(1) == 2).all()
+    e = get_edges_batch(4, 3)
+    assert e.shape == (3 * 4 * 3, 2) and (e[:, 0] != e[:, 1]).all() and (e[:, 0] // 4 == e[:, 1] // 4).all()
+    key = e[:, 0] * 100 + e[:, 1]
+    assert (key[1:] > key[:-1]).all()
+
+
+def test_sample_trajectory_round_trip(tmp_path):
+    from diffusion_for_multi_scale_molecular_dynamics_amd.utils.sample_trajectory import SampleTrajectory
+    rec = SampleTrajectory()
+    rec.record("noise_parameters", dict(total_time_steps=3))
+    rec.record("predictor_step", dict(time_step_index=3))
+    rec.record("predictor_step", dict(time_step_index=2))
+    rec.write_to_pickle(tmp_path / "t.pt")
+    data = torch.load(tmp_path / "t.pt", weights_only=False)
+    assert data["noise_parameters"] == dict(total_time_steps=3)          # single entries are unwrapped
+    assert [e["time_step_index"] for e in data["predictor_step"]] == [3, 2]
+
+
+def test_split_and_shard_bookkeeping():
+    from diffusion_for_multi_scale_molecular_dynamics_amd.sampling.diffusion_sampling import shard_of_rank, split_sizes
+    assert split_sizes(16, None) == [16] and split_sizes(16, 2) == [2] * 8 and split_sizes(7, 3) == [3, 3, 1]
+    sizes = split_sizes(23, 4)
+    got = sorted(sum((shard_of_rank(sizes, r, 4) for r in range(4)), []))
+    assert got == list(enumerate(sizes))
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from types import SimpleNamespace
+from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import AXL
+from diffusion_for_multi_scale_molecular_dynamics_amd.sampling.diffusion_sampling import (
+    create_batch_of_samples, create_batch_of_samples_sharded)
+
+class DummyGenerator:
+    # like the reference's tests/sampling/test_diffusion_sampling.py DummyGenerator: deterministic per call index
+    def __init__(self): self.calls = []
+    def sample(self, n, device):
+        k = len(self.calls); self.calls.append(n)
+        g = torch.Generator().manual_seed(1000 + n)      # content depends on the sub-batch size only
+        return AXL(A=torch.randint(0, 2, (n, 4), generator=g), X=torch.rand(n, 4, 3, generator=g),
+                   L=torch.rand(n, 6, generator=g))
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+sp = SimpleNamespace(number_of_samples=11, sample_batchsize=2, number_of_atoms=4, spatial_dimension=3)
+gen = DummyGenerator()
+out = create_batch_of_samples_sharded(gen, sp, torch.device("cpu"))
+single = create_batch_of_samples(DummyGenerator(), sp, torch.device("cpu"))
+assert out["original_axl"].A.shape == (11, 4) and out["cartesian_positions"].shape == (11, 4, 3)
+assert torch.equal(out["original_axl"].A, single["original_axl"].A)
+assert torch.equal(out["original_axl"].X, single["original_axl"].X)
+assert torch.equal(out["cartesian_positions"], single["cartesian_positions"])
+assert (out["original_axl"].L[:, 3:] == 0).all()
+assert sum(gen.calls) == sum(n for k, n in enumerate([2, 2, 2, 2, 2, 1]) if k % world == rank)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_driver_gloo_world_size_2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o
