@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X sampling hot path: sampled structures / second for a T-step predictor-corrector run.
+
+    python bench.py --gpus N --steps K --warmup W [--workload C2|C3|C4|C5]
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" is one sampler iteration -- score-network forward + fused predictor update, then M x (forward + fused
+corrector update) -- over one batch of synthetic structures resident in HBM.  K steps are timed between
+barrier + synchronize pairs, the MAX over ranks is taken, and the whole-job throughput is derived for the
+workload's full trajectory:  value = structures / (T * ms_per_step + gather_ms).
+Workloads: C2 = BASELINE configs[1] (Si 1x1x1, MLP, T=1000, M=1, B=1024 per GPU) is the
+default; C3/C4/C5 are the EGNN radius-graph configurations.  Weak scaling: every rank samples its own batch with
+Philox seed base+rank; the only collective is one all-gather of the final compositions.
+
+The JSON line also carries
+  roofline      the dominant hand-written kernel of the workload: algorithmic bytes per launch / average launch
+                duration measured here with HIP events on the stream the kernel runs on, against 8 TB/s;
+  cpu_baseline  the CPU oracle (oracle/, a restatement of the reference pinned to its golden vectors; kind "port")
+                timed on this host's cores over a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from diffusion_for_multi_scale_molecular_dynamics_amd import kernels  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics_amd._hip import MDX_PREDICTOR, Rng  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics_amd.generators.constrained_langevin_generator import \
+    ConstrainedLangevinGenerator  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import (  # noqa: E402
+    IterationLoop, LangevinGenerator)
+from diffusion_for_multi_scale_molecular_dynamics_amd.generators.predictor_corrector_axl_generator import \
+    PredictorCorrectorSamplingParameters  # noqa: E402
+from diffusion_for_multi_scale_molecular_dynamics_amd.generators.sampling_constraint import SamplingConstraint  # noqa
+from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import (  # noqa: E402
+    EGNNScoreNetwork, EGNNScoreNetworkParameters)
+from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.mlp_score_network import (  # noqa: E402
+    MLPScoreNetwork, MLPScoreNetworkParameters)
+from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters  # noqa
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BASE_SEED = 20250815
+NET_SEED = 1234
+
+
+def mlp_template(num_atom_types, n_atoms):
+    # configuration_templates/diffusion_config_files/config_diffusion_mlp.yaml:41-53 with N=8, d=3
+    return MLPScoreNetwork(MLPScoreNetworkParameters(
+        number_of_atoms=n_atoms, num_atom_types=num_atom_types, n_hidden_dimensions=3, hidden_dimensions_size=64,
+        relative_coordinates_embedding_dimensions_size=32, noise_embedding_dimensions_size=16,
+        time_embedding_dimensions_size=16, atom_type_embedding_dimensions_size=1,
+        lattice_parameters_embedding_dimensions_size=1, condition_embedding_size=64))
+
+
+def egnn_experiment(num_atom_types, edge_builder=None):
+    # experiments/.../Si_2x2x2/config_diffusion_egnn.yaml:44-60
+    return EGNNScoreNetwork(EGNNScoreNetworkParameters(
+        num_atom_types=num_atom_types, n_layers=4, coordinate_hidden_dimensions_size=256,
+        coordinate_n_hidden_dimensions=4, message_hidden_dimensions_size=256, message_n_hidden_dimensions=4,
+        node_hidden_dimensions_size=256, node_n_hidden_dimensions=4, coords_agg="mean", message_agg="mean",
+        attention=False, normalize=False, residual=True, tanh=False, edges="radial_cutoff", radial_cutoff=7.5),
+        edge_builder=edge_builder)
+
+
+LINEAR = dict(sigma_min=1e-4, sigma_max=0.2, schedule_type="linear", corrector_step_epsilon=2.5e-8)
+WORKLOADS = {
+    "C2": dict(desc="Si_diffusion_1x1x1, MLP score net, 1000-step predictor-corrector, batch=1024 per GPU",
+               n_atoms=8, num_atom_types=1, cell=5.43, net="mlp", batch=1024, M=1, greedy=True, one=True,
+               noise=dict(total_time_steps=1000, sigma_min=1e-4, sigma_max=0.25, schedule_type="exponential"),
+               graph=True, dominant="pc_step_kernel"),
+    "C3": dict(desc="Si_diffusion_2x2x2, EGNN (4x256, rc 7.5) score net, 1000 steps, batch=512 per GPU",
+               n_atoms=64, num_atom_types=1, cell=10.86, net="egnn", batch=512, M=2, greedy=False, one=False,
+               noise=dict(total_time_steps=1000, **LINEAR), graph=False, dominant="radius_graph_kernel"),
+    "C4": dict(desc="SiGe_diffusion_2x2x2 (two atom types), EGNN, 1000 steps, batch=512 per GPU",
+               n_atoms=64, num_atom_types=2, cell=11.084, net="egnn", batch=512, M=2, greedy=True, one=True,
+               noise=dict(total_time_steps=1000, **LINEAR), graph=False, dominant="radius_graph_kernel"),
+    "C5": dict(desc="Si_diffusion_3x3x3 repaint (108 of 216 atoms pinned), EGNN, 2000 steps, batch=256 per GPU",
+               n_atoms=216, num_atom_types=1, cell=16.29, net="egnn", batch=256, M=2, greedy=False, one=False,
+               noise=dict(total_time_steps=2000, **LINEAR), graph=False, dominant="radius_graph_kernel",
+               repaint=108),
+}
+
+
+def diamond_sites(n_cells):
+    """Ideal diamond-cubic fractional coordinates of an n x n x n supercell (8 atoms per cell)."""
+    base = torch.tensor([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0],
+                         [.25, .25, .25], [.25, .75, .75], [.75, .25, .75], [.75, .75, .25]])
+    cells = torch.cartesian_prod(*[torch.arange(n_cells)] * 3).float()
+    return ((cells[:, None, :] + base[None]) / n_cells).reshape(-1, 3)
+
+
+def build_generator(w, device, rank, batch, use_graph, edge_builder=None):
+    torch.manual_seed(NET_SEED)
+    net = (mlp_template(w["num_atom_types"], w["n_atoms"]) if w["net"] == "mlp"
+           else egnn_experiment(w["num_atom_types"], edge_builder)).eval().to(device)
+    noise = NoiseParameters(**w["noise"])
+    sampling = PredictorCorrectorSamplingParameters(
+        number_of_atoms=w["n_atoms"], num_atom_types=w["num_atom_types"], number_of_samples=batch,
+        number_of_corrector_steps=w["M"], atom_type_greedy_sampling=w["greedy"],
+        one_atom_type_transition_per_step=w["one"], use_fixed_lattice_parameters=True,
+        cell_dimensions=[w["cell"]] * 3, rng_mode="device", seed=BASE_SEED, use_hip_graph=use_graph)
+    if "repaint" in w:
+        k = w["repaint"]
+        constraint = SamplingConstraint(elements=["Si"], constrained_relative_coordinates=diamond_sites(3)[:k].clone(),
+                                        constrained_atom_types=torch.zeros(k, dtype=torch.long))
+        gen = ConstrainedLangevinGenerator(noise, sampling, net, constraint)
+    else:
+        gen = LangevinGenerator(noise, sampling, net)
+    return gen, noise, sampling, net
+
+
+def time_launches(launch, device, launches):
+    """Average GPU-side duration of `launch`: `launches` back-to-back launches are captured into one hipGraph (so the
+    host's ctypes call overhead is out of the picture) and the replay is bracketed by HIP events on its stream.
+    The figure includes the ~1.5 us same-stream dependency boundary between consecutive kernels."""
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize(device)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(launches):
+            launch()
+    graph.replay()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    start.record()
+    graph.replay()
+    stop.record()
+    torch.cuda.synchronize(device)
+    return start.elapsed_time(stop) / launches
+
+
+def time_update_kernel(gen, batch, w, device, launches=200):
+    """Average duration of one fused predictor-update launch (P2 + P1), HIP events on the launch stream."""
+    n, c = w["n_atoms"], w["num_atom_types"] + 1
+    sched = gen._prepare(device)
+    a = torch.full((batch, n), c - 1, dtype=torch.int64, device=device)
+    x = torch.rand(batch, n, 3, device=device)
+    lat = torch.tensor([w["cell"]] * 3 + [0.0] * 3, device=device).repeat(batch, 1)
+    logits = torch.randn(batch, n, c, device=device)
+    logits[..., -1] = -torch.inf
+    score = torch.randn(batch, n, 3, device=device)
+    a_out, x_out = torch.empty_like(a), torch.empty_like(x)
+    status = torch.zeros(1, dtype=torch.int32, device=device)
+    flags = gen._flags(True)
+    rng = Rng(BASE_SEED, 0, w["M"] + 1, 0)
+    T = w["noise"]["total_time_steps"]
+
+    def launch():
+        kernels.pc_step_update(sched, MDX_PREDICTOR, T // 2, None, flags, a, x, lat, logits, score, None, None, None,
+                               None, None, rng, a_out, x_out, lat, status)
+    ms = time_launches(launch, device, launches)
+    bytes_per_launch = batch * n * (52 + 4 * c)         # predictor, device RNG
+    return dict(kernel="pc_step_kernel (fused P2+P1 predictor update)", ms=ms, bytes=bytes_per_launch)
+
+
+def time_radius_graph(batch, w, device, launches=50):
+    """Average duration of one radius-graph fill launch (N1) at the workload's size."""
+    n = w["n_atoms"]
+    box = max(w["cell"], 2.2 * 7.5)
+    x = torch.rand(batch, n, 3, device=device)
+    cell = torch.diag(torch.tensor([box] * 3)).repeat(batch, 1, 1).to(device)
+    cart = (x @ cell).contiguous()
+    out = kernels.radius_graph(cart, cell, 7.5, unique=True)
+    counts = out["counts"].view(-1)
+    offsets = (torch.cumsum(counts, 0) - counts).contiguous()
+    edges = torch.empty_like(out["edges"])
+    from diffusion_for_multi_scale_molecular_dynamics_amd._hip import check, lib, ptr, stream_handle
+
+    def launch():
+        check(lib().mdx_radius_graph_fill(ptr(cart, torch.float32, "c"), ptr(cell, torch.float32, "b"), 7.5, batch, n, 1,
+                                          ptr(offsets, torch.int64, "o"), ptr(edges, torch.int64, "e"), None, None,
+                                          stream_handle()), "fill")
+    ms = time_launches(launch, device, launches)
+    n_edges = int(edges.shape[0])
+    bytes_per_launch = batch * n * (12 + 8) + 16 * n_edges    # read X + offsets, write 16 B per edge
+    return dict(kernel="radius_graph_kernel<fill> (N1)", ms=ms, bytes=bytes_per_launch,
+                edges_per_atom=n_edges / (batch * n))
+
+
+def cpu_baseline(w, name, budget_s=15.0):
+    """The CPU oracle on this host's cores over a bounded sample of the same workload."""
+    import nets as test_nets
+    from oracle import mdx_oracle
+    cores = min(16, len(os.sched_getaffinity(0)))      # a 1-GPU box's CPU share; more threads only oversubscribe
+    torch.set_num_threads(cores)
+    from oracle.reference_sampler import OracleLangevinGenerator, PhiloxNoise
+    mdx_oracle.build()
+    batch = w["batch"] if w["net"] == "mlp" else 16
+    gen, noise, sampling, net = build_generator(w, torch.device("cpu"), 0, batch, False,
+                                                edge_builder=test_nets.oracle_edge_builder)
+    constraint = None
+    if "repaint" in w:
+        k = w["repaint"]
+        constraint = dict(constrained_relative_coordinates=diamond_sites(3)[:k].numpy(),
+                          constrained_atom_types=torch.zeros(k, dtype=torch.long).numpy(), constrained_indices=None)
+    ora = OracleLangevinGenerator(noise, sampling, net, constraint=constraint, noise=PhiloxNoise(BASE_SEED, 0))
+    comp = ora.initialize(batch)
+    T = noise.total_time_steps
+
+    def run(i0, count):
+        nonlocal comp
+        t0 = time.perf_counter()
+        for i in range(i0, i0 - count, -1):
+            comp = ora.predictor_step(comp, i + 1)
+            for m in range(sampling.number_of_corrector_steps):
+                comp = ora.corrector_step(comp, i, m)
+        return time.perf_counter() - t0
+
+    probe = 2 if w["net"] == "egnn" else 10
+    t_probe = run(T - 1, probe)
+    per_iter = t_probe / probe
+    count = int(max(1, min(T - probe, budget_s / per_iter)))
+    elapsed = run(T - 1 - probe, count)
+    per_iter = elapsed / count
+    value = batch / (T * per_iter)
+    return dict(value=value, unit="structures/s", cores=cores, kind="port",
+                sample=f"{count} of {T} iterations of workload {name} at batch {batch} "
+                       f"({elapsed:.1f} s, {per_iter * 1e3:.2f} ms/iteration), extrapolated to the {T}-step job")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the iteration into a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    w = WORKLOADS[args.workload]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py measures the GPU hot path: no GPU is visible (there is no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    batch = args.batch or w["batch"]
+    T = w["noise"]["total_time_steps"]
+    mlp = w["net"] == "mlp"
+    steps = args.steps if args.steps is not None else (200 if mlp else 3)
+    warmup = args.warmup if args.warmup is not None else (20 if mlp else 1)
+    use_graph = w["graph"] and not args.no_graph
+    assert steps + warmup <= T
+
+    gen, noise, sampling, net = build_generator(w, device, rank, batch, use_graph)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    with torch.no_grad():
+        gen._prepare(device)
+        gen._begin_call(device)                      # Philox seed = BASE_SEED + rank
+        start = gen.initialize(batch, device)
+        loop = IterationLoop(gen, start, T, use_graph=use_graph)
+        loop.advance(warmup)
+        barrier()
+        t0 = time.perf_counter()
+        loop.advance(steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # the single collective of the job: gather of the final compositions
+        comp = loop.composition
+        gather_ms = 0.0
+        if dist is not None:
+            outs = [torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=device) for t in comp]
+            barrier()
+            g0 = time.perf_counter()
+            for o, t in zip(outs, comp):
+                dist.all_gather_into_tensor(o, t.contiguous())
+            barrier()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+        gen.check_status()
+        if dist is not None:
+            t = torch.tensor([elapsed, gather_ms], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, gather_ms = float(t[0]), float(t[1])
+        ms_per_step = elapsed * 1e3 / steps
+        value = (batch * world) / ((T * ms_per_step + gather_ms) * 1e-3)
+
+        roofline = None
+        if rank == 0:
+            m = time_update_kernel(gen, batch, w, device) if w["dominant"] == "pc_step_kernel" else \
+                time_radius_graph(batch, w, device)
+            achieved = m["bytes"] / (m["ms"] * 1e-3) / 1e9
+            roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, kernel=m["kernel"],
+                            avg_launch_us=round(m["ms"] * 1e3, 3), algorithmic_bytes_per_launch=m["bytes"])
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    result = {
+        "metric": "sampled structures/sec (%d-step predictor-corrector SDE sampling)" % T,
+        "value": round(value, 4), "unit": "structures/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (random-init score network, uniform-random initial structures)",
+        "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": batch, "global_batch": batch * world,
+                   "number_of_atoms": w["n_atoms"], "total_time_steps": T, "corrector_steps": w["M"],
+                   "rng": "device Philox4x32-10", "hip_graph": bool(use_graph), "gather_ms": round(gather_ms, 4),
+                   "parallelism": f"independent batches x{world}, one all-gather at the end"},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(w, args.workload)
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

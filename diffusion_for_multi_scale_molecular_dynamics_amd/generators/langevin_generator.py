@@ -269,36 +269,10 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         return comp
 
     def _sample_with_graph(self, start: AXL, starting_step_index: int, ending_step_index: int) -> AXL:
-        """Capture one iteration into a hipGraph (torch.cuda.CUDAGraph) and replay it; state lives in static
-        buffers, the step index on the device.  The network must be capture-safe (no host syncs)."""
-        device = start.X.device
-        n_iter = starting_step_index - max(ending_step_index, 0)
-        comp = AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
-        forces = torch.zeros_like(comp.X)
-        d_index = torch.zeros(1, dtype=torch.int32, device=device)
-        key = ("graph", comp.X.shape, self.noise_source.seed, self.noise_source.call)
-        # warm-up on a side stream (allocator / BLAS workspaces), then restore the state
-        saved = AXL(A=comp.A.clone(), X=comp.X.clone(), L=comp.L.clone())
-        side = torch.cuda.Stream(device=device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            kernels.index_set(d_index, starting_step_index - 1)
-            for _ in range(2):
-                self._iteration_on_device_index(comp, forces, d_index)
-        torch.cuda.current_stream(device).wait_stream(side)
-        comp.A.copy_(saved.A)
-        comp.X.copy_(saved.X)
-        comp.L.copy_(saved.L)
-        self._status.zero_()
-        graph = torch.cuda.CUDAGraph()
-        kernels.index_set(d_index, starting_step_index - 1)
-        with torch.cuda.graph(graph):
-            self._iteration_on_device_index(comp, forces, d_index)
-        # the capture itself does not execute; replay all iterations
-        for _ in range(n_iter):
-            graph.replay()
-        self._buffers[key] = graph      # keep alive until the next call
-        return comp
+        loop = IterationLoop(self, start, starting_step_index, use_graph=True)
+        loop.advance(starting_step_index - max(ending_step_index, 0))
+        self._buffers["graph_loop"] = loop      # keep the graph alive until the next call
+        return loop.composition
 
     def check_status(self):
         """Read the device status word once (the only host synchronisation of a sample() call)."""
@@ -324,3 +298,51 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         if self.rng_mode == "device":
             self.noise_source = None
         return composition
+
+
+class IterationLoop:
+    """The sampler's loop with its state resident on the device: composition in static buffers, loop variable i in
+    a device word that every kernel reads.  With use_graph the (predictor + M correctors + index decrement)
+    iteration is captured ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed; the score network must then be
+    capture-safe (no host synchronisation).  Used by LangevinGenerator.sample and by bench.py."""
+
+    def __init__(self, generator: LangevinGenerator, start: AXL, starting_step_index: int, use_graph: bool):
+        gen = self.generator = generator
+        device = start.X.device
+        gen._prepare(device)
+        assert getattr(gen.noise_source, "device_rng", False), "the device-resident loop needs rng_mode='device'"
+        self.composition = AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
+        self.forces = torch.zeros_like(self.composition.X)
+        self.d_index = torch.zeros(1, dtype=torch.int32, device=device)
+        self.remaining = starting_step_index
+        self.graph = None
+        if use_graph:
+            comp = self.composition
+            saved = AXL(A=comp.A.clone(), X=comp.X.clone(), L=comp.L.clone())
+            # warm-up on a side stream (allocator, BLAS workspaces), then restore the state
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                kernels.index_set(self.d_index, starting_step_index - 1)
+                for _ in range(2):
+                    gen._iteration_on_device_index(comp, self.forces, self.d_index)
+            torch.cuda.current_stream(device).wait_stream(side)
+            comp.A.copy_(saved.A)
+            comp.X.copy_(saved.X)
+            comp.L.copy_(saved.L)
+            gen._status.zero_()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                gen._iteration_on_device_index(comp, self.forces, self.d_index)
+        kernels.index_set(self.d_index, starting_step_index - 1)
+
+    def advance(self, iterations: int):
+        """Run `iterations` sampler iterations (asynchronously on the current stream)."""
+        assert iterations <= self.remaining, "cannot step past time index 0"
+        if self.graph is not None:
+            for _ in range(iterations):
+                self.graph.replay()
+        else:
+            for _ in range(iterations):
+                self.generator._iteration_on_device_index(self.composition, self.forces, self.d_index)
+        self.remaining -= iterations
