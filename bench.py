@@ -116,6 +116,48 @@ def build_generator(w, device, rank, batch, use_graph, edge_builder=None):
     return gen, noise, sampling, net
 
 
+class FusedLoop:
+    """The sampler loop as launches of the persistent fused kernel (mdx_mlp_pc_sample): advance(n) = one launch."""
+
+    def __init__(self, gen, start, starting_step_index):
+        self.gen = gen
+        self.composition = type(start)(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
+        self.remaining = starting_step_index
+        self.sched = gen._prepare(start.X.device)
+        self.pack = gen.fused_pack(start.X.device)
+
+    def advance(self, iterations):
+        g, c = self.gen, self.composition
+        kernels.mlp_pc_sample(self.sched, self.pack, g._flags(True), g.number_of_corrector_steps,
+                              g.atom_type_transition_in_corrector, self.remaining, iterations, g._rng(0), c.A, c.X, c.L,
+                              g._status)
+        self.remaining -= iterations
+
+
+def time_fused_kernel(gen, loop, batch, w, device, iterations=100):
+    """Duration of the persistent kernel per sampler iteration (HIP events around one launch of `iterations`)."""
+    n, c, m = w["n_atoms"], w["num_atom_types"] + 1, w["M"]
+    comp = type(loop.composition)(*[t.clone() for t in loop.composition])
+    T = w["noise"]["total_time_steps"]
+
+    def launch():
+        kernels.mlp_pc_sample(loop.sched, loop.pack, gen._flags(True), m, False, T // 2 + iterations, iterations,
+                              gen._rng(0), comp.A, comp.X, comp.L, gen._status)
+    launch()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    start.record()
+    launch()
+    stop.record()
+    torch.cuda.synchronize(device)
+    ms = start.elapsed_time(stop)
+    # the bytes the un-fused algorithm moves per iteration (SURVEY 8d): predictor 52+4C, each corrector 36 B/atom;
+    # the persistent kernel keeps them in LDS and touches HBM only at the ends of the launch
+    bytes_per_launch = batch * n * ((52 + 4 * c) + 36 * m) * iterations
+    return dict(kernel=f"mlp_pc_sample_kernel (persistent: {iterations} iterations of MLP forward + fused update per launch)",
+                ms=ms, bytes=bytes_per_launch)
+
+
 def time_launches(launch, device, launches):
     """Average GPU-side duration of `launch`: `launches` back-to-back launches are captured into one hipGraph (so the
     host's ctypes call overhead is out of the picture) and the replay is bracketed by HIP events on its stream.
@@ -234,6 +276,9 @@ def main():
     ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the iteration into a hipGraph")
+    ap.add_argument("--forward", choices=["fused", "pytorch"], default=None,
+                    help="score-network forward: 'pytorch' (plugin API, any network) or 'fused' (MLP only: network "
+                         "forward + update in one persistent HIP kernel); default: fused for MLP workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -256,10 +301,13 @@ def main():
     mlp = w["net"] == "mlp"
     steps = args.steps if args.steps is not None else (200 if mlp else 3)
     warmup = args.warmup if args.warmup is not None else (20 if mlp else 1)
-    use_graph = w["graph"] and not args.no_graph
+    forward = args.forward or ("fused" if mlp else "pytorch")
+    assert forward == "pytorch" or mlp, "the fused forward exists for the MLP score network only"
+    use_graph = w["graph"] and not args.no_graph and forward == "pytorch"
     assert steps + warmup <= T
 
     gen, noise, sampling, net = build_generator(w, device, rank, batch, use_graph)
+    gen.fused_score_network = forward == "fused"
 
     def barrier():
         if dist is not None:
@@ -270,7 +318,7 @@ def main():
         gen._prepare(device)
         gen._begin_call(device)                      # Philox seed = BASE_SEED + rank
         start = gen.initialize(batch, device)
-        loop = IterationLoop(gen, start, T, use_graph=use_graph)
+        loop = FusedLoop(gen, start, T) if forward == "fused" else IterationLoop(gen, start, T, use_graph=use_graph)
         loop.advance(warmup)
         barrier()
         t0 = time.perf_counter()
@@ -298,8 +346,12 @@ def main():
 
         roofline = None
         if rank == 0:
-            m = time_update_kernel(gen, batch, w, device) if w["dominant"] == "pc_step_kernel" else \
-                time_radius_graph(batch, w, device)
+            if forward == "fused":
+                m = time_fused_kernel(gen, loop, batch, w, device)
+            elif w["dominant"] == "pc_step_kernel":
+                m = time_update_kernel(gen, batch, w, device)
+            else:
+                m = time_radius_graph(batch, w, device)
             achieved = m["bytes"] / (m["ms"] * 1e-3) / 1e9
             roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, kernel=m["kernel"],
@@ -317,7 +369,9 @@ def main():
         "dtype": "f32", "data": "synthetic (random-init score network, uniform-random initial structures)",
         "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": batch, "global_batch": batch * world,
                    "number_of_atoms": w["n_atoms"], "total_time_steps": T, "corrector_steps": w["M"],
-                   "rng": "device Philox4x32-10", "hip_graph": bool(use_graph), "gather_ms": round(gather_ms, 4),
+                   "rng": "device Philox4x32-10", "hip_graph": bool(use_graph),
+                   "score_network_forward": "fused HIP (one persistent kernel per launch of K iterations)"
+                   if forward == "fused" else "PyTorch-ROCm module (plugin API)", "gather_ms": round(gather_ms, 4),
                    "parallelism": f"independent batches x{world}, one all-gather at the end"},
         "roofline": roofline,
     }

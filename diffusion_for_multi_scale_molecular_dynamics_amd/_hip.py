@@ -24,9 +24,10 @@ ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
-    "mdx_repaint_constrained_rows", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_rng_fill",
-    "mdx_math_probe",
+    "mdx_repaint_constrained_rows", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_mlp_forward",
+    "mdx_mlp_pc_sample", "mdx_rng_fill", "mdx_math_probe",
 )
+MLP_MAX_HIDDEN = 8
 
 
 class MdxError(RuntimeError):
@@ -52,6 +53,16 @@ class PcFlags(C.Structure):
     _fields_ = [("atom_type_greedy_sampling", C.c_int32), ("one_atom_type_transition_per_step", C.c_int32),
                 ("use_fixed_lattice_parameters", C.c_int32), ("update_atom_types", C.c_int32),
                 ("small_epsilon", C.c_float)]
+
+
+class Mlp(C.Structure):
+    """mdx_mlp_t"""
+    _fields_ = [(n, C.c_int32) for n in ("number_of_atoms", "spatial_dimension", "num_classes", "hidden_size",
+                                         "n_hidden", "e_coordinates", "e_noise", "e_time", "e_atom_type", "e_lattice")] + \
+        [(n, C.c_void_p) for n in ("w_coordinates_t", "b_coordinates", "w_noise_t", "b_noise", "w_time_t", "b_time",
+                                   "w_atom_type_t", "b_atom_type", "w_lattice_t", "b_lattice")] + \
+        [("w_hidden_t", C.c_void_p * 8), ("b_hidden", C.c_void_p * 8)] + \
+        [(n, C.c_void_p) for n in ("w_out_a_t", "b_out_a", "w_out_x_t", "b_out_x", "w_out_l_t", "b_out_l")]
 
 
 def build(force=False):
@@ -116,6 +127,11 @@ def _declare(L):
     L.mdx_radius_graph_count.argtypes = [vp, vp, f32, i64, i32, i32, vp, vp, vp]
     L.mdx_radius_graph_fill.restype = i32
     L.mdx_radius_graph_fill.argtypes = [vp, vp, f32, i64, i32, i32, vp, vp, vp, vp, vp]
+    L.mdx_mlp_forward.restype = i32
+    L.mdx_mlp_forward.argtypes = [C.POINTER(Mlp), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
+    L.mdx_mlp_pc_sample.restype = i32
+    L.mdx_mlp_pc_sample.argtypes = [C.POINTER(Schedule), C.POINTER(Mlp), C.POINTER(PcFlags), i32, i32, i32, i32, Rng, i64,
+                                    vp, vp, vp, vp, vp]
     L.mdx_rng_fill.restype = i32
     L.mdx_rng_fill.argtypes = [i32, u64, u32, u32, u32, i64, i32, vp, vp]
     L.mdx_math_probe.restype = i32

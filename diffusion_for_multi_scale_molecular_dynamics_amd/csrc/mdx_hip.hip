@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "../../include/mdx_hip.h"
 #include "mdx_math.hpp"
@@ -317,6 +318,154 @@ __device__ __forceinline__ int group_and(int v)
     return v;
 }
 
+// Per-step, wave-uniform data of one update
+struct PcStep {
+    StepScalars sc;
+    const float *q, *qbar, *qbar_tm1;
+    int one, last_predictor_step;
+    uint32_t draw, k0, k1, call8;
+};
+
+// Pointers of ONE structure (already offset to it); item0 = global index of its atom 0 in the Philox stream.
+struct PcView {
+    const int64_t* a;
+    const float *x, *l, *logits, *score_x, *score_l, *z_coord, *gumbel, *u, *z_lat;
+    int64_t* a_out;
+    float *x_out, *l_out, *p_out;
+    int64_t item0, b;
+};
+
+__device__ __forceinline__ PcStep make_step(const PcArgs& p)
+{
+    PcStep st;
+    const int C = p.C;
+    st.q = p.q_explicit; st.qbar = p.qbar_explicit; st.qbar_tm1 = p.qbar_tm1_explicit;
+    st.one = p.one_transition;
+    st.last_predictor_step = 0;
+    st.draw = p.rng.draw_offset;
+    if (p.use_tables) {
+        const int index = (p.d_index ? *p.d_index : 0) + p.index_i;
+        st.sc = step_scalars(p.sched, p.mode, index, p.atoms_pow);
+        st.q = p.sched.q + (int64_t)st.sc.idx * C * C;
+        st.qbar = p.sched.qbar + (int64_t)st.sc.idx * C * C;
+        st.qbar_tm1 = p.sched.qbar_tm1 + (int64_t)st.sc.idx * C * C;
+        st.last_predictor_step = (p.mode == MDX_PREDICTOR && st.sc.idx == 0);
+        if (st.last_predictor_step) st.one = 0;                 // generators/langevin_generator.py:601-604
+        st.draw = (uint32_t)index * p.rng.draw_stride + p.rng.draw_offset;
+    }
+    st.k0 = (uint32_t)p.rng.seed;
+    st.k1 = (uint32_t)(p.rng.seed >> 32);
+    st.call8 = p.rng.call << 8;
+    return st;
+}
+
+// The update of one structure by the G lanes of its group (P2, P1, P3).  Used by pc_step_kernel on global memory and
+// by the fused MLP sampler kernel on its LDS-resident state: one body, one arithmetic.
+template <int G>
+__device__ __forceinline__ void pc_update_structure(const PcArgs& p, const PcStep& st, const PcView& v, int lane)
+{
+    const int N = p.N, C = p.C, d = p.d, M = p.C - 1;
+    const StepScalars& sc = st.sc;
+    const int one = st.one;
+    int all_masked = 1;
+    if (p.update_types && p.greedy) {
+        for (int n = lane; n < N; n += G) all_masked &= (v.a[n] == M);
+        all_masked = group_and<G>(all_masked);
+    }
+    float best_v = -__builtin_huge_valf();
+    int best_n = 0x7fffffff;
+    int best_prop = 0;
+    for (int n = lane; n < N; n += G) {
+        const uint32_t item = (uint32_t)(v.item0 + n);
+        if (p.update_types) {
+            const int a_t = (int)v.a[n];
+            float pr[MDX_MAX_CLASSES], gm[MDX_MAX_CLASSES];
+            posterior(v.logits + n * C, a_t, st.q, st.qbar, st.qbar_tm1, C, p.small_eps, pr);
+            if (v.gumbel) {
+                for (int c = 0; c < C; ++c) gm[c] = v.gumbel[n * C + c];
+            } else {
+                for (int sub = 0; sub * 4 < C; ++sub) {
+                    const u32x4 r = philox4x32_10(item, st.call8 | (uint32_t)sub, st.draw, MDX_TAG_GUMBEL, st.k0, st.k1);
+                    for (int l = 0; l < 4 && sub * 4 + l < C; ++l) gm[sub * 4 + l] = gumbel_from_u(u01(r.v[l]));
+                }
+            }
+            if (p.greedy) {                                      // :382-439
+                float uu;
+                if (v.u) uu = v.u[n];
+                else uu = u01(philox4x32_10(item, st.call8, st.draw, MDX_TAG_BINARY, st.k0, st.k1).v[0]);
+                const int unmask = uu > pr[M];
+                if (!all_masked && unmask && a_t == M) pr[M] = 0.0f;
+                if (!all_masked)
+                    for (int c = 0; c < C; ++c) gm[c] = 0.0f;
+            }
+            float v_best = 0.0f;
+            int prop = 0;
+            for (int c = 0; c < C; ++c) {                        // :311-315, first maximal index
+                const float val = logf_(pr[c] + p.small_eps) + gm[c];
+                if (c == 0 || val > v_best) { v_best = val; prop = c; }
+                if (v.p_out) v.p_out[n * C + c] = pr[c];
+            }
+            if (one) {                                           // :339-380
+                const float cand = (prop != a_t) ? v_best : -__builtin_huge_valf();
+                if (cand > best_v || (cand == best_v && n < best_n)) { best_v = cand; best_n = n; best_prop = prop; }
+                v.a_out[n] = a_t;
+            } else {
+                v.a_out[n] = prop;
+                if (st.last_predictor_step && prop == M && p.status) atomicOr(p.status, MDX_STATUS_MASK_AT_LAST_STEP);
+            }
+        } else if (v.a_out && v.a_out != v.a) {
+            v.a_out[n] = v.a[n];
+        }
+        if (p.do_coords) {                                       // :194-201
+            float z[4];
+            if (!v.z_coord) {
+                const u32x4 r = philox4x32_10(item, st.call8, st.draw, MDX_TAG_COORD, st.k0, st.k1);
+                box_muller(r.v[0], r.v[1], z[0], z[1]);
+                if (d > 2) box_muller(r.v[2], r.v[3], z[2], z[3]);
+            }
+            for (int k = 0; k < d; ++k) {
+                const int e = n * d + k;
+                const float zz = v.z_coord ? v.z_coord[e] : z[k];
+                v.x_out[e] = coord_update(v.x[e], v.score_x[e], zz, sc.w, sc.n, sc.sigma);
+            }
+        }
+    }
+    if (p.update_types && one) {
+        // arg-max over the atoms of the structure: larger value wins, ties go to the smaller atom index
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best_v, o, kWave);
+            const int on = __shfl_xor(best_n, o, kWave);
+            const int op = __shfl_xor(best_prop, o, kWave);
+            if (ov > best_v || (ov == best_v && on < best_n)) { best_v = ov; best_n = on; best_prop = op; }
+        }
+        if (lane == 0 && best_n < N) v.a_out[best_n] = best_prop;
+    }
+    if (p.do_lattice) {                                          // :475-490
+        for (int k = lane; k < p.nl; k += G) {
+            if (p.fixed_lattice) {
+                if (v.l_out != v.l) v.l_out[k] = v.l[k];
+            } else {
+                float zz;
+                if (v.z_lat) zz = v.z_lat[k];
+                else {
+                    const u32x4 r = philox4x32_10((uint32_t)v.b, st.call8 | (uint32_t)(k >> 2), st.draw, MDX_TAG_LATTICE,
+                                                  st.k0, st.k1);
+                    float z0, z1, z2, z3;
+                    box_muller(r.v[0], r.v[1], z0, z1);
+                    box_muller(r.v[2], r.v[3], z2, z3);
+                    const int kk = k & 3;
+                    zz = kk == 0 ? z0 : (kk == 1 ? z1 : (kk == 2 ? z2 : z3));
+                }
+                v.l_out[k] = (v.l[k] + (sc.w * v.score_l[k]) / sc.sigma_n) + sc.n * zz;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ const float* off(const float* p, int64_t o) { return p ? p + o : nullptr; }
+__device__ __forceinline__ float* off(float* p, int64_t o) { return p ? p + o : nullptr; }
+
 // G lanes cooperate on one structure; a 64-lane wavefront carries 64/G structures.
 template <int G>
 __global__ __launch_bounds__(kBlock) void pc_step_kernel(PcArgs p)
@@ -324,121 +473,21 @@ __global__ __launch_bounds__(kBlock) void pc_step_kernel(PcArgs p)
     const int lane = threadIdx.x & (G - 1);
     const int64_t groups_per_grid = ((int64_t)gridDim.x * blockDim.x) / G;
     const int64_t group0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int N = p.N, C = p.C, d = p.d, M = p.C - 1;
-
-    StepScalars sc;
-    const float *q = p.q_explicit, *qbar = p.qbar_explicit, *qbar_tm1 = p.qbar_tm1_explicit;
-    int one = p.one_transition;
-    int last_predictor_step = 0;
-    uint32_t draw = p.rng.draw_offset;
-    if (p.use_tables) {
-        const int index = (p.d_index ? *p.d_index : 0) + p.index_i;
-        sc = step_scalars(p.sched, p.mode, index, p.atoms_pow);
-        q = p.sched.q + (int64_t)sc.idx * C * C;
-        qbar = p.sched.qbar + (int64_t)sc.idx * C * C;
-        qbar_tm1 = p.sched.qbar_tm1 + (int64_t)sc.idx * C * C;
-        last_predictor_step = (p.mode == MDX_PREDICTOR && sc.idx == 0);
-        if (last_predictor_step) one = 0;                       // generators/langevin_generator.py:601-604
-        draw = (uint32_t)index * p.rng.draw_stride + p.rng.draw_offset;
-    }
-    const uint32_t k0 = (uint32_t)p.rng.seed, k1 = (uint32_t)(p.rng.seed >> 32);
-    const uint32_t call8 = p.rng.call << 8;
-
+    const int N = p.N, C = p.C, d = p.d;
+    const PcStep st = make_step(p);
     for (int64_t b = group0; b < p.B; b += groups_per_grid) {
-        int all_masked = 1;
-        if (p.update_types && p.greedy) {
-            for (int n = lane; n < N; n += G) all_masked &= (p.a[b * N + n] == M);
-            all_masked = group_and<G>(all_masked);
-        }
-        float best_v = -__builtin_huge_valf();
-        int best_n = 0x7fffffff;
-        int best_prop = 0;
-        for (int n = lane; n < N; n += G) {
-            const int64_t at = b * N + n;
-            if (p.update_types) {
-                const int a_t = (int)p.a[at];
-                float pr[MDX_MAX_CLASSES], gm[MDX_MAX_CLASSES];
-                posterior(p.logits + at * C, a_t, q, qbar, qbar_tm1, C, p.small_eps, pr);
-                if (p.gumbel) {
-                    for (int c = 0; c < C; ++c) gm[c] = p.gumbel[at * C + c];
-                } else {
-                    for (int sub = 0; sub * 4 < C; ++sub) {
-                        const u32x4 r = philox4x32_10((uint32_t)at, call8 | (uint32_t)sub, draw, MDX_TAG_GUMBEL, k0, k1);
-                        for (int l = 0; l < 4 && sub * 4 + l < C; ++l) gm[sub * 4 + l] = gumbel_from_u(u01(r.v[l]));
-                    }
-                }
-                if (p.greedy) {                                  // :382-439
-                    float uu;
-                    if (p.u) uu = p.u[at];
-                    else uu = u01(philox4x32_10((uint32_t)at, call8, draw, MDX_TAG_BINARY, k0, k1).v[0]);
-                    const int unmask = uu > pr[M];
-                    if (!all_masked && unmask && a_t == M) pr[M] = 0.0f;
-                    if (!all_masked)
-                        for (int c = 0; c < C; ++c) gm[c] = 0.0f;
-                }
-                float v_best = 0.0f;
-                int prop = 0;
-                for (int c = 0; c < C; ++c) {                    // :311-315, first maximal index
-                    const float v = logf_(pr[c] + p.small_eps) + gm[c];
-                    if (c == 0 || v > v_best) { v_best = v; prop = c; }
-                    if (p.p_out) p.p_out[at * C + c] = pr[c];
-                }
-                if (one) {                                       // :339-380
-                    const float cand = (prop != a_t) ? v_best : -__builtin_huge_valf();
-                    if (cand > best_v || (cand == best_v && n < best_n)) { best_v = cand; best_n = n; best_prop = prop; }
-                    p.a_out[at] = a_t;
-                } else {
-                    p.a_out[at] = prop;
-                    if (last_predictor_step && prop == M && p.status) atomicOr(p.status, MDX_STATUS_MASK_AT_LAST_STEP);
-                }
-            } else if (p.a_out && p.a_out != p.a) {
-                p.a_out[at] = p.a[at];
-            }
-            if (p.do_coords) {                                   // :194-201
-                float z[4];
-                if (!p.z_coord) {
-                    const u32x4 r = philox4x32_10((uint32_t)at, call8, draw, MDX_TAG_COORD, k0, k1);
-                    box_muller(r.v[0], r.v[1], z[0], z[1]);
-                    if (d > 2) box_muller(r.v[2], r.v[3], z[2], z[3]);
-                }
-                for (int k = 0; k < d; ++k) {
-                    const int64_t e = at * d + k;
-                    const float zz = p.z_coord ? p.z_coord[e] : z[k];
-                    p.x_out[e] = coord_update(p.x[e], p.score_x[e], zz, sc.w, sc.n, sc.sigma);
-                }
-            }
-        }
-        if (p.update_types && one) {
-            // arg-max over the atoms of the structure: larger value wins, ties go to the smaller atom index
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(best_v, o, kWave);
-                const int on = __shfl_xor(best_n, o, kWave);
-                const int op = __shfl_xor(best_prop, o, kWave);
-                if (ov > best_v || (ov == best_v && on < best_n)) { best_v = ov; best_n = on; best_prop = op; }
-            }
-            if (lane == 0 && best_n < N) p.a_out[b * N + best_n] = best_prop;
-        }
-        if (p.do_lattice) {                                      // :475-490
-            for (int k = lane; k < p.nl; k += G) {
-                const int64_t e = b * p.nl + k;
-                if (p.fixed_lattice) {
-                    if (p.l_out != p.l) p.l_out[e] = p.l[e];
-                } else {
-                    float zz;
-                    if (p.z_lat) zz = p.z_lat[e];
-                    else {
-                        const u32x4 r = philox4x32_10((uint32_t)b, call8 | (uint32_t)(k >> 2), draw, MDX_TAG_LATTICE, k0, k1);
-                        float z0, z1, z2, z3;
-                        box_muller(r.v[0], r.v[1], z0, z1);
-                        box_muller(r.v[2], r.v[3], z2, z3);
-                        const int kk = k & 3;
-                        zz = kk == 0 ? z0 : (kk == 1 ? z1 : (kk == 2 ? z2 : z3));
-                    }
-                    p.l_out[e] = (p.l[e] + (sc.w * p.score_l[e]) / sc.sigma_n) + sc.n * zz;
-                }
-            }
-        }
+        PcView v;
+        const int64_t a0 = b * N;
+        v.a = p.a ? p.a + a0 : nullptr;
+        v.x = off(p.x, a0 * d); v.l = off(p.l, b * p.nl);
+        v.logits = off(p.logits, a0 * C); v.score_x = off(p.score_x, a0 * d); v.score_l = off(p.score_l, b * p.nl);
+        v.z_coord = off(p.z_coord, a0 * d); v.gumbel = off(p.gumbel, a0 * C); v.u = off(p.u, a0);
+        v.z_lat = off(p.z_lat, b * p.nl);
+        v.a_out = p.a_out ? p.a_out + a0 : nullptr;
+        v.x_out = off(p.x_out, a0 * d); v.l_out = off(p.l_out, b * p.nl); v.p_out = off(p.p_out, a0 * C);
+        v.item0 = a0;
+        v.b = b;
+        pc_update_structure<G>(p, st, v, lane);
     }
 }
 
@@ -462,6 +511,373 @@ int launch_pc(const PcArgs& a, hipStream_t st)
         default: hipLaunchKernelGGL(pc_step_kernel<64>, grid, block, 0, st, a); break;
     }
     return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused MLP score network + persistent sampler (one wavefront = one structure)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kMlpWaves = 4;                    // wavefronts (= structures) per workgroup, sharing one weight copy
+
+// Explicit LDS pointers: with generic pointers hipcc emits flat_load, whose waits (vmcnt(0) AND lgkmcnt(0)) serialise
+// the layer loops; address_space(3) pointers give ds_read_b128 with counted lgkmcnt waits.
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) const float lds_cf;
+typedef __attribute__((address_space(3))) int64_t lds_i64;
+typedef __attribute__((address_space(3))) const int64_t lds_ci64;
+typedef float lds_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const lds_f4 lds_cf4;
+
+// LDS exchanges between the lanes of ONE wavefront need no s_barrier (a wave's LDS operations execute in issue
+// order); this only stops the compiler from moving memory operations across the hand-off.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// out[j] = bias[j] + sum_k in[k] * W[k][j]; lanes are output neurons, the input vector is broadcast from LDS four
+// values at a time.  Four interleaved partial sums (k mod 4) shorten the dependent fmaf chain; they are added as
+// ((s0+s1)+(s2+s3))+bias.  QUAD = true: the weights are the LDS image layout [k/4][j][k%4] (one 16-byte read per
+// four k, rows zero-padded to a multiple of four); QUAD = false: plain transposed [k][j] in global memory.
+template <bool QUAD, typename WP>
+__device__ __forceinline__ void linear_wave(WP wt, WP bias, lds_cf* in, int in_dim, int out_dim, lds_f* out, int lane,
+                                            bool silu_out)
+{
+    const int k4 = in_dim >> 2;
+    lds_cf4* in4 = (lds_cf4*)in;
+    for (int j = lane; j < out_dim; j += kWave) {
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        if constexpr (QUAD) {
+            lds_cf4* w = (lds_cf4*)wt + j;
+            const int kq = (in_dim + 3) >> 2;
+#pragma unroll 4
+            for (int q = 0; q < kq; ++q) {
+                const lds_f4 wv = w[q * out_dim];
+                const lds_f4 v = in4[q];                                           // input padded with zeros
+                s0 = __builtin_fmaf(wv.x, v.x, s0);
+                s1 = __builtin_fmaf(wv.y, v.y, s1);
+                s2 = __builtin_fmaf(wv.z, v.z, s2);
+                s3 = __builtin_fmaf(wv.w, v.w, s3);
+            }
+        } else {
+            WP w = wt + j;
+#pragma unroll 2
+            for (int q = 0; q < k4; ++q) {
+                const lds_f4 v = in4[q];
+                s0 = __builtin_fmaf(w[(4 * q + 0) * out_dim], v.x, s0);
+                s1 = __builtin_fmaf(w[(4 * q + 1) * out_dim], v.y, s1);
+                s2 = __builtin_fmaf(w[(4 * q + 2) * out_dim], v.z, s2);
+                s3 = __builtin_fmaf(w[(4 * q + 3) * out_dim], v.w, s3);
+            }
+            for (int k = 4 * k4; k < in_dim; ++k) {
+                const float t = __builtin_fmaf(w[k * out_dim], in[k], 0.0f);
+                if ((k & 3) == 0) s0 += t; else if ((k & 3) == 1) s1 += t; else if ((k & 3) == 2) s2 += t; else s3 += t;
+            }
+        }
+        float acc = ((s0 + s1) + (s2 + s3)) + bias[j];
+        if (silu_out) acc = acc / (1.0f + expf_(-acc));      // SiLU
+        out[j] = acc;
+    }
+}
+
+// Offsets (in floats) of every parameter tensor inside one packed weight image, in the order they are staged.
+struct MlpOffsets {
+    int wc, bc, wn, bn, wt, bt, wa, ba, wl, bl, wh[MDX_MLP_MAX_HIDDEN], bh[MDX_MLP_MAX_HIDDEN], woa, boa, wox, box, wol, bol,
+        total, in0;
+};
+
+__host__ __device__ inline MlpOffsets mlp_offsets(const mdx_mlp_t& m)
+{
+    const int N = m.number_of_atoms, d = m.spatial_dimension, C = m.num_classes, nl = d * (d + 1) / 2, H = m.hidden_size;
+    MlpOffsets o;
+    int t = 0;
+    auto take = [&t](int n) { const int at = t; t += (n + 3) & ~3; return at; };     // 16-byte aligned pieces
+    o.in0 = m.e_coordinates + m.e_noise + m.e_time + N * m.e_atom_type + m.e_lattice;
+    auto quad = [](int k, int n) { return ((k + 3) & ~3) * n; };                     // [k/4][n][4] image of a [k][n] matrix
+    o.wc = take(quad(2 * N * d, m.e_coordinates)); o.bc = take(m.e_coordinates);
+    o.wn = take(m.e_noise); o.bn = take(m.e_noise);
+    o.wt = take(m.e_time); o.bt = take(m.e_time);
+    o.wa = take(C * m.e_atom_type); o.ba = take(m.e_atom_type);
+    o.wl = take(nl * m.e_lattice); o.bl = take(m.e_lattice);
+    for (int k = 0; k < m.n_hidden; ++k) {
+        o.wh[k] = take(quad(k == 0 ? o.in0 : H, H));
+        o.bh[k] = take(H);
+    }
+    // the three heads are staged as ONE [H][N C + N d + nl] matrix (one layer loop instead of three); woa/boa name it
+    o.woa = take(quad(H, N * C + N * d + nl)); o.boa = take(N * C + N * d + nl);
+    o.wox = o.woa; o.box = o.boa; o.wol = o.woa; o.bol = o.boa;
+    o.total = t;
+    return o;
+}
+
+// The network's parameters as plain pointers (either the caller's global tensors or the LDS image)
+template <typename P>
+struct MlpWeightsT {
+    P wc, bc, wn, bn, wt, bt, wa, ba, wl, bl, wh[MDX_MLP_MAX_HIDDEN], bh[MDX_MLP_MAX_HIDDEN], woa, boa, wox, box, wol, bol;
+};
+typedef MlpWeightsT<const float*> MlpWeights;
+typedef MlpWeightsT<lds_cf*> MlpWeightsLds;
+
+__device__ __forceinline__ MlpWeights weights_global(const mdx_mlp_t& m)
+{
+    MlpWeights w;
+    w.wc = m.w_coordinates_t; w.bc = m.b_coordinates; w.wn = m.w_noise_t; w.bn = m.b_noise;
+    w.wt = m.w_time_t; w.bt = m.b_time; w.wa = m.w_atom_type_t; w.ba = m.b_atom_type;
+    w.wl = m.w_lattice_t; w.bl = m.b_lattice;
+    for (int k = 0; k < m.n_hidden; ++k) { w.wh[k] = m.w_hidden_t[k]; w.bh[k] = m.b_hidden[k]; }
+    w.woa = m.w_out_a_t; w.boa = m.b_out_a; w.wox = m.w_out_x_t; w.box = m.b_out_x; w.wol = m.w_out_l_t; w.bol = m.b_out_l;
+    return w;
+}
+
+// Copy every parameter tensor into the workgroup's LDS image (all threads of the block) and point at the copies.
+__device__ __forceinline__ MlpWeightsLds weights_to_lds(const mdx_mlp_t& m, const MlpOffsets& o, lds_f* img)
+{
+    const int N = m.number_of_atoms, d = m.spatial_dimension, C = m.num_classes, nl = d * (d + 1) / 2, H = m.hidden_size;
+    auto copy = [&](const float* src, int at, int n) {
+        for (int e = threadIdx.x; e < n; e += blockDim.x) img[at + e] = src[e];
+        return (lds_cf*)(img + at);
+    };
+    // [k][n] (global, transposed Linear weight) -> [k/4][n][k%4] with zero rows up to a multiple of four
+    auto copy_quad = [&](const float* src, int at, int k_dim, int n) {
+        const int kp = (k_dim + 3) & ~3;
+        for (int e = threadIdx.x; e < kp * n; e += blockDim.x) {
+            const int q = e / (4 * n), r = e - q * 4 * n, j = r >> 2, c = r & 3, k = 4 * q + c;
+            img[at + e] = k < k_dim ? src[k * n + j] : 0.0f;
+        }
+        return (lds_cf*)(img + at);
+    };
+    MlpWeightsLds w;
+    w.wc = copy_quad(m.w_coordinates_t, o.wc, 2 * N * d, m.e_coordinates); w.bc = copy(m.b_coordinates, o.bc, m.e_coordinates);
+    w.wn = copy(m.w_noise_t, o.wn, m.e_noise); w.bn = copy(m.b_noise, o.bn, m.e_noise);
+    w.wt = copy(m.w_time_t, o.wt, m.e_time); w.bt = copy(m.b_time, o.bt, m.e_time);
+    w.wa = copy(m.w_atom_type_t, o.wa, C * m.e_atom_type); w.ba = copy(m.b_atom_type, o.ba, m.e_atom_type);
+    w.wl = copy(m.w_lattice_t, o.wl, nl * m.e_lattice); w.bl = copy(m.b_lattice, o.bl, m.e_lattice);
+    for (int k = 0; k < m.n_hidden; ++k) {
+        w.wh[k] = copy_quad(m.w_hidden_t[k], o.wh[k], k == 0 ? o.in0 : H, H);
+        w.bh[k] = copy(m.b_hidden[k], o.bh[k], H);
+    }
+    {   // merged heads: columns [0, NC) logits, [NC, NC+Nd) score_x, [NC+Nd, ..) score_l
+        const int nt = N * C + N * d + nl, kp = (H + 3) & ~3;
+        for (int e = threadIdx.x; e < kp * nt; e += blockDim.x) {
+            const int q = e / (4 * nt), r = e - q * 4 * nt, j = r >> 2, c = r & 3, k = 4 * q + c;
+            float val = 0.0f;
+            if (k < H) {
+                if (j < N * C) val = m.w_out_a_t[k * N * C + j];
+                else if (j < N * C + N * d) val = m.w_out_x_t[k * N * d + (j - N * C)];
+                else val = m.w_out_l_t[k * nl + (j - N * C - N * d)];
+            }
+            img[o.woa + e] = val;
+        }
+        for (int j = threadIdx.x; j < nt; j += blockDim.x)
+            img[o.boa + j] = j < N * C ? m.b_out_a[j] : (j < N * C + N * d ? m.b_out_x[j - N * C] : m.b_out_l[j - N * C - N * d]);
+        w.woa = (lds_cf*)(img + o.woa); w.boa = (lds_cf*)(img + o.boa);
+        w.wox = w.woa; w.box = w.boa; w.wol = w.woa; w.bol = w.boa;
+    }
+    return w;
+}
+
+// MLPScoreNetwork forward for ONE structure by one wavefront (mlp_score_network.py:281-370).
+// buf_a / buf_b: this wavefront's LDS scratch of mlp_scratch_floats() floats each.
+template <bool QUAD, typename W>
+__device__ __forceinline__ void mlp_forward_wave(const mdx_mlp_t& m, const W& w, int lane, lds_cf* x, lds_ci64* a, lds_cf* l,
+                                                 float time, float sigma, lds_f* buf_a, lds_f* buf_b, lds_f* logits,
+                                                 lds_f* score_x, lds_f* score_l)
+{
+    const int N = m.number_of_atoms, d = m.spatial_dimension, C = m.num_classes, nl = d * (d + 1) / 2;
+    const int nd = N * d;
+    // (cos 2 pi x | sin 2 pi x), all cosines first (:299-305)
+    for (int e = lane; e < nd; e += kWave) {
+        float sn, cs;
+        sincospif_(2.0f * x[e], sn, cs);
+        buf_a[e] = cs;
+        buf_a[nd + e] = sn;
+    }
+    if (lane < 4) buf_a[2 * nd + lane] = 0.0f;               // zero padding read by the four-wide layer loop
+    wave_sync();
+    // input of the first hidden layer: [coordinates | noise | time | atom types (N x e_atom_type) | lattice]
+    int o = 0;
+    linear_wave<QUAD>(w.wc, w.bc, buf_a, 2 * nd, m.e_coordinates, buf_b + o, lane, false);
+    o += m.e_coordinates;
+    for (int j = lane; j < m.e_noise; j += kWave) buf_b[o + j] = __builtin_fmaf(w.wn[j], sigma, w.bn[j]);
+    o += m.e_noise;
+    for (int j = lane; j < m.e_time; j += kWave) buf_b[o + j] = __builtin_fmaf(w.wt[j], time, w.bt[j]);
+    o += m.e_time;
+    for (int t = lane; t < N * m.e_atom_type; t += kWave) {      // Linear(one_hot(a)) = W[:, a] + b
+        const int n = t / m.e_atom_type, e = t - n * m.e_atom_type;
+        buf_b[o + t] = w.wa[(int)a[n] * m.e_atom_type + e] + w.ba[e];
+    }
+    o += N * m.e_atom_type;
+    for (int j = lane; j < m.e_lattice; j += kWave) {
+        float acc = w.bl[j];
+        for (int k = 0; k < nl; ++k) acc = __builtin_fmaf(w.wl[k * m.e_lattice + j], l[k], acc);
+        buf_b[o + j] = acc;
+    }
+    o += m.e_lattice;
+    if (lane < 4) buf_b[o + lane] = 0.0f;
+    wave_sync();
+    // hidden stack: SiLU between layers, none after the last (:337-344)
+    lds_f* in = buf_b;
+    lds_f* out = buf_a;
+    int in_dim = o;
+    for (int k = 0; k < m.n_hidden; ++k) {
+        linear_wave<QUAD>(w.wh[k], w.bh[k], in, in_dim, m.hidden_size, out, lane, k + 1 < m.n_hidden);
+        if (lane < 4) out[m.hidden_size + lane] = 0.0f;
+        wave_sync();
+        lds_f* t = in; in = out; out = t;
+        in_dim = m.hidden_size;
+    }
+    // heads; MASK logit forced to -inf (score_network.py:183-185)
+    if constexpr (QUAD) {       // merged heads image; logits | score_x | score_l are contiguous in the wavefront's LDS
+        linear_wave<QUAD>(w.woa, w.boa, in, in_dim, N * C + nd + nl, logits, lane, false);
+    } else {
+        linear_wave<QUAD>(w.woa, w.boa, in, in_dim, N * C, logits, lane, false);
+        linear_wave<QUAD>(w.wox, w.box, in, in_dim, nd, score_x, lane, false);
+        linear_wave<QUAD>(w.wol, w.bol, in, in_dim, nl, score_l, lane, false);
+    }
+    wave_sync();
+    for (int n = lane; n < N; n += kWave) logits[n * C + C - 1] = -__builtin_huge_valf();
+    wave_sync();
+}
+
+__host__ __device__ inline int mlp_scratch_floats(const mdx_mlp_t& m)
+{
+    const int N = m.number_of_atoms, d = m.spatial_dimension;
+    const int in0 = m.e_coordinates + m.e_noise + m.e_time + N * m.e_atom_type + m.e_lattice;
+    int mx = 2 * N * d;
+    if (in0 > mx) mx = in0;
+    if (m.hidden_size > mx) mx = m.hidden_size;
+    return ((mx + 3) & ~3) + 4;                              // + zero padding for the four-wide layer loop
+}
+
+// floats of LDS one wavefront needs besides the shared weight image
+__host__ __device__ inline int mlp_wave_floats(const mdx_mlp_t& m)
+{
+    const int N = m.number_of_atoms, d = m.spatial_dimension, C = m.num_classes, nl = d * (d + 1) / 2;
+    const int f = 2 * mlp_scratch_floats(m) + 2 * N + N * d + ((nl + 3) & ~3) + N * C + N * d + nl;
+    return (f + 3) & ~3;
+}
+
+// LDS per wavefront: [buf_a S][buf_b S][a: N int64][x: N d][l: nl pad 4][logits: N C][score_x: N d][score_l: nl]
+struct MlpWaveLds {
+    lds_f *buf_a, *buf_b, *x, *l, *logits, *sx, *sl;
+    lds_i64* a;
+};
+
+__device__ __forceinline__ MlpWaveLds carve_wave_lds(const mdx_mlp_t& m, lds_f* base)
+{
+    const int N = m.number_of_atoms, d = m.spatial_dimension, C = m.num_classes, nl = d * (d + 1) / 2;
+    const int S = mlp_scratch_floats(m);
+    MlpWaveLds r;
+    r.buf_a = base;
+    r.buf_b = base + S;
+    r.a = (lds_i64*)(base + 2 * S);                 // 8-byte aligned: every piece is a multiple of 4 floats
+    r.x = base + 2 * S + 2 * N;
+    r.l = r.x + N * d;
+    r.logits = r.l + ((nl + 3) & ~3);
+    r.sx = r.logits + N * C;
+    r.sl = r.sx + N * d;
+    return r;
+}
+
+template <bool LDS_WEIGHTS>
+__global__ __launch_bounds__(kMlpWaves* kWave) void mlp_forward_kernel(mdx_mlp_t m, const int64_t* a, const float* x,
+                                                                       const float* l, const float* time,
+                                                                       const float* sigma, int64_t batch, float* logits,
+                                                                       float* score_x, float* score_l)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    lds_f* lds = (lds_f*)lds_raw;
+    const int N = m.number_of_atoms, d = m.spatial_dimension, C = m.num_classes, nl = d * (d + 1) / 2;
+    const MlpOffsets off = mlp_offsets(m);
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    auto run = [&](const auto& w, lds_f* scratch) {
+        const MlpWaveLds r = carve_wave_lds(m, scratch + wave * mlp_wave_floats(m));
+        for (int64_t b = (int64_t)blockIdx.x * kMlpWaves + wave; b < batch; b += (int64_t)gridDim.x * kMlpWaves) {
+            for (int e = lane; e < N; e += kWave) r.a[e] = a[b * N + e];
+            for (int e = lane; e < N * d; e += kWave) r.x[e] = x[b * N * d + e];
+            for (int e = lane; e < nl; e += kWave) r.l[e] = l[b * nl + e];
+            wave_sync();
+            mlp_forward_wave<LDS_WEIGHTS>(m, w, lane, r.x, r.a, r.l, time[b], sigma[b], r.buf_a, r.buf_b, r.logits, r.sx, r.sl);
+            for (int e = lane; e < N * C; e += kWave) logits[b * N * C + e] = r.logits[e];
+            for (int e = lane; e < N * d; e += kWave) score_x[b * N * d + e] = r.sx[e];
+            for (int e = lane; e < nl; e += kWave) score_l[b * nl + e] = r.sl[e];
+            wave_sync();
+        }
+    };
+    if constexpr (LDS_WEIGHTS) {
+        const MlpWeightsLds w = weights_to_lds(m, off, lds);
+        __syncthreads();
+        run(w, lds + off.total);
+    } else {
+        run(weights_global(m), lds);
+    }
+}
+
+struct MlpSampleArgs {
+    PcArgs pc;               // flags, schedule, rng, dims (pointers unused)
+    mdx_mlp_t mlp;
+    int M, types_in_corrector, start_index, n_iterations;
+    int diag_skip;           // diagnostic builds of the timing breakdown only (MDX_DIAG_SKIP): 1 = no forward, 2 = no update
+    int64_t* a;
+    float *x, *l;
+};
+
+// One wavefront per structure, kMlpWaves structures per workgroup sharing one LDS image of the network's weights.
+// The composition, the activations and the network outputs of a structure stay in its wavefront's LDS region for
+// the whole trajectory segment; HBM is touched at the two ends only.  G = lanes that cooperate in the update.
+template <int G, bool LDS_WEIGHTS>
+__global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSampleArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    lds_f* lds = (lds_f*)lds_raw;
+    const mdx_mlp_t& m = p.mlp;
+    const int N = m.number_of_atoms, d = m.spatial_dimension, nl = d * (d + 1) / 2;
+    const MlpOffsets off = mlp_offsets(m);
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    auto run = [&](const auto& w, lds_f* scratch) {
+        const MlpWaveLds r = carve_wave_lds(m, scratch + wave * mlp_wave_floats(m));
+        for (int64_t b = (int64_t)blockIdx.x * kMlpWaves + wave; b < p.pc.B; b += (int64_t)gridDim.x * kMlpWaves) {
+            for (int e = lane; e < N; e += kWave) r.a[e] = p.a[b * N + e];
+            for (int e = lane; e < N * d; e += kWave) r.x[e] = p.x[b * N * d + e];
+            for (int e = lane; e < nl; e += kWave) r.l[e] = p.l[b * nl + e];
+            wave_sync();
+            PcView v;     // the update body addresses the same LDS through generic pointers (a handful of accesses)
+            v.a = (const int64_t*)r.a; v.x = (const float*)r.x; v.l = (const float*)r.l;
+            v.logits = (const float*)r.logits; v.score_x = (const float*)r.sx; v.score_l = (const float*)r.sl;
+            v.z_coord = nullptr; v.gumbel = nullptr; v.u = nullptr; v.z_lat = nullptr;
+            v.a_out = (int64_t*)r.a; v.x_out = (float*)r.x; v.l_out = (float*)r.l; v.p_out = nullptr;
+            v.item0 = b * N;
+            v.b = b;
+            for (int it = 0; it < p.n_iterations; ++it) {
+                const int i = p.start_index - 1 - it;               // loop variable of the reference (:147)
+                for (int sub = 0; sub <= p.M; ++sub) {
+                    PcArgs a = p.pc;
+                    a.mode = sub == 0 ? MDX_PREDICTOR : MDX_CORRECTOR;
+                    a.index_i = sub == 0 ? i + 1 : i;
+                    a.d_index = nullptr;
+                    a.rng.draw_offset = (uint32_t)sub;
+                    a.update_types = sub == 0 ? 1 : p.types_in_corrector;
+                    const PcStep st = make_step(a);
+                    if (!(p.diag_skip & 1))
+                        mlp_forward_wave<LDS_WEIGHTS>(m, w, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b,
+                                                      r.logits, r.sx, r.sl);
+                    if (lane < G && !(p.diag_skip & 2)) pc_update_structure<G>(a, st, v, lane);
+                    wave_sync();
+                }
+            }
+            for (int e = lane; e < N; e += kWave) p.a[b * N + e] = r.a[e];
+            for (int e = lane; e < N * d; e += kWave) p.x[b * N * d + e] = r.x[e];
+            for (int e = lane; e < nl; e += kWave) p.l[b * nl + e] = r.l[e];
+            wave_sync();
+        }
+    };
+    if constexpr (LDS_WEIGHTS) {
+        const MlpWeightsLds w = weights_to_lds(m, off, lds);
+        __syncthreads();
+        run(w, lds + off.total);
+    } else {
+        run(weights_global(m), lds);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -601,6 +1017,14 @@ __global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __res
     if (!FILL && chunk == 0 && threadIdx.x == 96 && status) {
         if (!(crossing_distance(cl) > rc)) atomicOr(status, MDX_STATUS_CUTOFF_TOO_LARGE);
     }
+    // Orthorhombic cell with rc <= L_min / 2.2 (always true on the EGNN path, which clips the cell to 2.2 rc):
+    // an image within rc has every component |delta_k| <= rc <= 0.4546 L_k, so it is THE nearest image and the
+    // other 26 cannot qualify.  One image is then evaluated -- with the same expression, hence the same bits.
+    const bool ortho = cl[1] == 0.0f && cl[2] == 0.0f && cl[3] == 0.0f && cl[5] == 0.0f && cl[6] == 0.0f &&
+                       cl[7] == 0.0f && cl[0] > 0.0f && cl[4] > 0.0f && cl[8] > 0.0f &&
+                       rc * 2.2f <= fminf(cl[0], fminf(cl[4], cl[8]));
+    const float inv_lx = ortho ? 1.0f / cl[0] : 0.0f, inv_ly = ortho ? 1.0f / cl[4] : 0.0f,
+                inv_lz = ortho ? 1.0f / cl[8] : 0.0f;
     __syncthreads();
     const float rc2 = rc * rc;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
@@ -613,7 +1037,17 @@ __global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __res
         for (int j0 = 0; j0 < N; j0 += kWave) {
             const int j = j0 + lane;
             uint32_t mask = 0;
-            if (j < N) {
+            if (j < N && ortho) {
+                const float pjx = pos[3 * j], pjy = pos[3 * j + 1], pjz = pos[3 * j + 2];
+                const int nx = max(-1, min(1, (int)__builtin_rintf((pix - pjx) * inv_lx)));
+                const int ny = max(-1, min(1, (int)__builtin_rintf((piy - pjy) * inv_ly)));
+                const int nz = max(-1, min(1, (int)__builtin_rintf((piz - pjz) * inv_lz)));
+                // image vector of a diagonal cell: n_k * L_k, exact, identical to the fma chain that fills lv[]
+                const float sx = pjx + (float)nx * cl[0], sy = pjy + (float)ny * cl[4], sz = pjz + (float)nz * cl[8];
+                const float dx = pix - sx, dy = piy - sy, dz = piz - sz;
+                const float d2 = (dx * dx + dy * dy) + dz * dz;
+                if (0.0f < d2 && d2 <= rc2) mask = (1u << ((nx + 1) * 9 + (ny + 1) * 3 + (nz + 1)));
+            } else if (j < N) {
                 const float pjx = pos[3 * j], pjy = pos[3 * j + 1], pjz = pos[3 * j + 2];
 #pragma unroll
                 for (int l = 0; l < 27; ++l) {
@@ -623,27 +1057,39 @@ __global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __res
                     if (0.0f < d2 && d2 <= rc2) mask |= (1u << l);
                 }
             }
-            int cnt = unique ? (mask != 0) : __popc(mask);
-            // exclusive prefix over the lanes
-            int incl = cnt;
+            int cnt, rank, total;
+            if (unique) {
+                cnt = (mask != 0);
+                const unsigned long long hits = __ballot(cnt);
+                rank = __popcll(hits & ((1ull << lane) - 1ull));
+                total = __popcll(hits);
+            } else {
+                cnt = __popc(mask);
+                int incl = cnt;                      // inclusive prefix over the lanes
 #pragma unroll
-            for (int o = 1; o < kWave; o <<= 1) {
-                const int v = __shfl_up(incl, o, kWave);
-                if (lane >= o) incl += v;
+                for (int o = 1; o < kWave; o <<= 1) {
+                    const int v = __shfl_up(incl, o, kWave);
+                    if (lane >= o) incl += v;
+                }
+                total = __shfl(incl, kWave - 1, kWave);
+                rank = incl - cnt;
             }
-            const int total = __shfl(incl, kWave - 1, kWave);
             if (FILL && cnt) {
-                int64_t e = base + running + (incl - cnt);
+                int64_t e = base + running + rank;
                 if (unique) {
-                    edges[2 * e] = row;
-                    edges[2 * e + 1] = b * N + j;
+                    longlong2 pair;
+                    pair.x = row;
+                    pair.y = row - i + j;
+                    reinterpret_cast<longlong2*>(edges)[e] = pair;      // one 16-B store per edge
                 } else {
                     uint32_t m = mask;
                     while (m) {
                         const int l = __ffs(m) - 1;
                         m &= m - 1;
-                        edges[2 * e] = i;
-                        edges[2 * e + 1] = j;
+                        longlong2 pair;
+                        pair.x = i;
+                        pair.y = j;
+                        reinterpret_cast<longlong2*>(edges)[e] = pair;
                         image_out[e] = l;
                         if (shifts_out) {
                             shifts_out[3 * e] = lv[3 * l];
@@ -714,6 +1160,21 @@ inline unsigned flat_grid(int64_t work_items)
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
+
+template <bool LDS_WEIGHTS>
+static void launch_mlp_sampler(int G, unsigned grid, size_t lds, hipStream_t st, const MlpSampleArgs& a)
+{
+    const dim3 block(kMlpWaves * kWave);
+    switch (G) {
+        case 1: hipLaunchKernelGGL((mlp_pc_sample_kernel<1, LDS_WEIGHTS>), dim3(grid), block, lds, st, a); break;
+        case 2: hipLaunchKernelGGL((mlp_pc_sample_kernel<2, LDS_WEIGHTS>), dim3(grid), block, lds, st, a); break;
+        case 4: hipLaunchKernelGGL((mlp_pc_sample_kernel<4, LDS_WEIGHTS>), dim3(grid), block, lds, st, a); break;
+        case 8: hipLaunchKernelGGL((mlp_pc_sample_kernel<8, LDS_WEIGHTS>), dim3(grid), block, lds, st, a); break;
+        case 16: hipLaunchKernelGGL((mlp_pc_sample_kernel<16, LDS_WEIGHTS>), dim3(grid), block, lds, st, a); break;
+        case 32: hipLaunchKernelGGL((mlp_pc_sample_kernel<32, LDS_WEIGHTS>), dim3(grid), block, lds, st, a); break;
+        default: hipLaunchKernelGGL((mlp_pc_sample_kernel<64, LDS_WEIGHTS>), dim3(grid), block, lds, st, a); break;
+    }
+}
 
 // =================================================================================================================
 // C ABI
@@ -954,6 +1415,121 @@ int mdx_radius_graph_fill(const float* cart, const float* cell, float rc, int64_
     hipLaunchKernelGGL(radius_graph_kernel<true>, dim3((unsigned)(batch * chunks)), dim3(kBlock), lds, as_stream(stream),
                        cart, cell, rc, batch, N, unique, chunks, (int64_t*)nullptr, offsets, edges_out, image_out,
                        shifts_out, (uint32_t*)nullptr);
+    return launch_status();
+}
+
+static int mlp_ok(const mdx_mlp_t* m)
+{
+    if (!m) return MDX_ERR_INVALID_ARG;
+    if (m->number_of_atoms < 1 || m->spatial_dimension < 1 || m->spatial_dimension > 3 || m->num_classes < 2 ||
+        m->hidden_size < 1 || m->n_hidden < 1 || m->e_coordinates < 1 || m->e_noise < 1 || m->e_time < 1 ||
+        m->e_atom_type < 1 || m->e_lattice < 1)
+        return MDX_ERR_INVALID_ARG;
+    if (m->n_hidden > MDX_MLP_MAX_HIDDEN || m->num_classes > MDX_MAX_CLASSES) return MDX_ERR_UNSUPPORTED;
+    if (!m->w_coordinates_t || !m->b_coordinates || !m->w_noise_t || !m->b_noise || !m->w_time_t || !m->b_time ||
+        !m->w_atom_type_t || !m->b_atom_type || !m->w_lattice_t || !m->b_lattice || !m->w_out_a_t || !m->b_out_a ||
+        !m->w_out_x_t || !m->b_out_x || !m->w_out_l_t || !m->b_out_l)
+        return MDX_ERR_INVALID_ARG;
+    for (int k = 0; k < m->n_hidden; ++k)
+        if (!m->w_hidden_t[k] || !m->b_hidden[k]) return MDX_ERR_INVALID_ARG;
+    return MDX_OK;
+}
+
+constexpr size_t kMlpLdsBudget = 64 * 1024;      // default dynamic-LDS limit per workgroup
+
+int mdx_mlp_forward(const mdx_mlp_t* mlp_host, const int64_t* atom_types, const float* x, const float* l,
+                    const float* time, const float* sigma, int64_t batch, float* logits_out, float* score_x_out,
+                    float* score_l_out, mdx_stream_t stream)
+{
+    const int ok = mlp_ok(mlp_host);
+    if (ok != MDX_OK) return ok;
+    if (batch < 0) return MDX_ERR_INVALID_ARG;
+    if (batch == 0) return MDX_OK;
+    if (!atom_types || !x || !l || !time || !sigma || !logits_out || !score_x_out || !score_l_out) return MDX_ERR_INVALID_ARG;
+    // x and l are read as broadcast vectors by the layer loops; the forward-only kernel reads them from global memory
+    const size_t scratch = sizeof(float) * (size_t)mlp_wave_floats(*mlp_host) * kMlpWaves;
+    const size_t image = sizeof(float) * (size_t)mlp_offsets(*mlp_host).total;
+    if (scratch > kMlpLdsBudget) return MDX_ERR_UNSUPPORTED;
+    const bool in_lds = scratch + image <= 2 * kMlpLdsBudget;
+    const int64_t blocks = cdiv(batch, kMlpWaves);
+    const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+    if (in_lds && scratch + image > kMlpLdsBudget &&
+        hipFuncSetAttribute((const void*)mlp_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(scratch + image)) != hipSuccess)
+        return MDX_ERR_HIP;
+    if (in_lds)
+        hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(grid), dim3(kMlpWaves * kWave), scratch + image, as_stream(stream),
+                           *mlp_host, atom_types, x, l, time, sigma, batch, logits_out, score_x_out, score_l_out);
+    else
+        hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid), dim3(kMlpWaves * kWave), scratch, as_stream(stream),
+                           *mlp_host, atom_types, x, l, time, sigma, batch, logits_out, score_x_out, score_l_out);
+    return launch_status();
+}
+
+int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_host, const mdx_pc_flags_t* f,
+                      int number_of_corrector_steps, int atom_type_transition_in_corrector, int start_index,
+                      int n_iterations, mdx_rng_t rng, int64_t batch, int64_t* atom_types, float* x, float* l,
+                      uint32_t* status, mdx_stream_t stream)
+{
+    const int ok = mlp_ok(mlp_host);
+    if (ok != MDX_OK) return ok;
+    if (!sched_host || !f || batch < 0 || number_of_corrector_steps < 0 || n_iterations < 0) return MDX_ERR_INVALID_ARG;
+    if (start_index < 1 || start_index > sched_host->total_time_steps || n_iterations > start_index) return MDX_ERR_INVALID_ARG;
+    if (sched_host->num_classes != mlp_host->num_classes) return MDX_ERR_INVALID_ARG;
+    if (mlp_host->number_of_atoms > kWave) return MDX_ERR_UNSUPPORTED;      // one lane per atom in the update
+    if ((int64_t)batch * mlp_host->number_of_atoms > 0xffffffffLL) return MDX_ERR_UNSUPPORTED;
+    if (batch == 0 || n_iterations == 0) return MDX_OK;
+    if (!atom_types || !x || !l) return MDX_ERR_INVALID_ARG;
+    const size_t per_wave = sizeof(float) * (size_t)mlp_wave_floats(*mlp_host);
+    const size_t image = sizeof(float) * (size_t)mlp_offsets(*mlp_host).total;
+    if (per_wave * kMlpWaves > kMlpLdsBudget) return MDX_ERR_UNSUPPORTED;
+    const bool in_lds = per_wave * kMlpWaves + image <= 2 * kMlpLdsBudget;
+    MlpSampleArgs a{};
+    PcArgs& pc = a.pc;
+    pc.sched = to_dev(sched_host);
+    pc.use_tables = 1;
+    pc.atoms_pow = pow((double)mlp_host->number_of_atoms, 1.0 / (double)mlp_host->spatial_dimension);
+    pc.greedy = f->atom_type_greedy_sampling; pc.one_transition = f->one_atom_type_transition_per_step;
+    pc.fixed_lattice = f->use_fixed_lattice_parameters;
+    pc.do_coords = 1; pc.do_lattice = 1;
+    pc.small_eps = f->small_epsilon;
+    pc.rng = rng;
+    pc.rng.draw_stride = (uint32_t)number_of_corrector_steps + 1;
+    pc.B = batch; pc.N = mlp_host->number_of_atoms; pc.d = mlp_host->spatial_dimension; pc.C = mlp_host->num_classes;
+    pc.nl = pc.d * (pc.d + 1) / 2;
+    pc.status = status;
+    a.mlp = *mlp_host;
+    a.M = number_of_corrector_steps;
+    a.types_in_corrector = atom_type_transition_in_corrector ? 1 : 0;
+    a.start_index = start_index;
+    a.n_iterations = n_iterations;
+    a.a = atom_types; a.x = x; a.l = l;
+    if (const char* diag = getenv("MDX_DIAG_SKIP")) a.diag_skip = atoi(diag);
+    int G = 1;
+    while (G < pc.N) G <<= 1;
+    const int64_t blocks = cdiv(batch, kMlpWaves);
+    const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+    hipStream_t st = as_stream(stream);
+    if (in_lds) {
+        const size_t lds = per_wave * kMlpWaves + image;
+        if (lds > kMlpLdsBudget) {    // up to 128 KiB of the CU's 160 KiB: opt in above the 64 KiB default
+            const void* fn = nullptr;
+            switch (G) {
+                case 1: fn = (const void*)mlp_pc_sample_kernel<1, true>; break;
+                case 2: fn = (const void*)mlp_pc_sample_kernel<2, true>; break;
+                case 4: fn = (const void*)mlp_pc_sample_kernel<4, true>; break;
+                case 8: fn = (const void*)mlp_pc_sample_kernel<8, true>; break;
+                case 16: fn = (const void*)mlp_pc_sample_kernel<16, true>; break;
+                case 32: fn = (const void*)mlp_pc_sample_kernel<32, true>; break;
+                default: fn = (const void*)mlp_pc_sample_kernel<64, true>; break;
+            }
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return MDX_ERR_HIP;
+        }
+        launch_mlp_sampler<true>(G, grid, lds, st, a);
+    } else {
+        launch_mlp_sampler<false>(G, grid, per_wave * kMlpWaves, st, a);
+    }
     return launch_status();
 }
 

@@ -64,6 +64,8 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         assert rng_mode in ("reference", "device"), f"unknown rng_mode {rng_mode}"
         self.rng_mode = rng_mode
         self.use_hip_graph = bool(getattr(sp, "use_hip_graph", False))
+        self.fused_score_network = bool(getattr(sp, "fused_score_network", False))
+        self._mlp_pack = None
         self._seed = getattr(sp, "seed", None)
         self._call_counter = 0
         self.noise_source = ReferenceOrderNoise() if rng_mode == "reference" else None
@@ -249,6 +251,8 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         self._prepare(starting_noisy_composition.X.device)
         if self.noise_source is None:
             self._begin_call(starting_noisy_composition.X.device)
+        if self.fused_score_network:
+            return self._sample_fused(starting_noisy_composition, starting_step_index, ending_step_index)
         if self.use_hip_graph and getattr(self.noise_source, "device_rng", False) and not self.record:
             return self._sample_with_graph(starting_noisy_composition, starting_step_index, ending_step_index)
         composition = starting_noisy_composition
@@ -266,6 +270,29 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         for m in range(self.number_of_corrector_steps):
             comp, _ = self._step(MDX_CORRECTOR, comp, 0, forces, 1 + m, d_index=d_index, in_place=True)
         kernels.index_add(d_index, -1)
+        return comp
+
+    def fused_pack(self, device):
+        """Device copy of the MLP's parameters for the fused kernels (loud errors when the path does not apply)."""
+        from ..models.score_networks.mlp_score_network import MLPScoreNetwork
+        if not isinstance(self.axl_network, MLPScoreNetwork):
+            raise MdxError("fused_score_network=True needs an MLPScoreNetwork; other networks use the per-step kernels")
+        if not getattr(self.noise_source, "device_rng", False) or self.record or type(self)._after_predictor is not \
+                LangevinGenerator._after_predictor:
+            raise MdxError("fused_score_network=True needs rng_mode='device', no recording and no repaint constraint")
+        if self._mlp_pack is None or self._mlp_pack.device != torch.device(device):
+            self._mlp_pack = kernels.MlpPack(self.axl_network, device)
+        return self._mlp_pack
+
+    def _sample_fused(self, start: AXL, starting_step_index: int, ending_step_index: int) -> AXL:
+        device = start.X.device
+        sched = self._prepare(device)
+        pack = self.fused_pack(device)
+        comp = AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
+        kernels.mlp_pc_sample(sched, pack, self._flags(True), self.number_of_corrector_steps,
+                              self.atom_type_transition_in_corrector, starting_step_index,
+                              starting_step_index - max(ending_step_index, 0), self._rng(0), comp.A, comp.X, comp.L,
+                              self._status)
         return comp
 
     def _sample_with_graph(self, start: AXL, starting_step_index: int, ending_step_index: int) -> AXL:

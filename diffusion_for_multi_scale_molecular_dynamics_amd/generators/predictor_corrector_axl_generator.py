@@ -27,6 +27,8 @@ class PredictorCorrectorSamplingParameters(SamplingParameters):
     #                                  "device": counter-based Philox inside the kernels (throughput mode)
     seed: Optional[int] = None       # device mode: Philox key (rank is added to it); None -> torch.initial_seed()
     use_hip_graph: bool = False      # device mode: capture one predictor+correctors iteration and replay it
+    fused_score_network: bool = False  # device mode + MLPScoreNetwork: network forward and update fused in ONE
+    #                                    persistent kernel that runs the whole loop (mdx_mlp_pc_sample)
 
 
 class PredictorCorrectorAXLGenerator(AXLGenerator):

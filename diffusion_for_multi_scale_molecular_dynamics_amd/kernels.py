@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 
 from . import _hip
-from ._hip import MDX_CORRECTOR, MDX_PREDICTOR, PcFlags, Rng, Schedule, check, lib, ptr, stream_handle
+from ._hip import MDX_CORRECTOR, MDX_PREDICTOR, Mlp, PcFlags, Rng, Schedule, check, lib, ptr, stream_handle
 
 F32, I64, I32 = torch.float32, torch.int64, torch.int32
 
@@ -213,6 +213,85 @@ def radius_graph(cartesian_positions, basis_vectors, radial_cutoff: float, uniqu
                                      ptr(image, I32, "image"), ptr(shifts, F32, "shifts"), stream_handle())
         check(rc, "mdx_radius_graph_fill")
     return dict(counts=counts, edges=edges, image=image, shifts=shifts)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# fused MLP score network
+# ----------------------------------------------------------------------------------------------------------------
+class MlpPack:
+    """Device copy of an MLPScoreNetwork's parameters in the layout of mdx_mlp_t (transposed weights, [in, out]).
+
+    Built from the module's state at construction; rebuild it if the parameters change."""
+
+    def __init__(self, network, device):
+        hp = network._hyper_params
+        if getattr(network, "use_permutation_invariance", False) or getattr(network, "use_time_dependent_prefactor", False):
+            raise _hip.MdxError("the fused MLP kernels implement the plain unconditional forward "
+                                "(no permutation symmetrisation, no time prefactor)")
+        n_hidden = len(network.mlp_layers)
+        if n_hidden > _hip.MLP_MAX_HIDDEN:
+            raise _hip.MdxError(f"at most {_hip.MLP_MAX_HIDDEN} hidden layers are supported by the fused MLP kernels")
+        self._keep = []
+
+        def wt(linear):
+            t = linear.weight.detach().to(device=device, dtype=F32).t().contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        def bias(linear):
+            t = linear.bias.detach().to(device=device, dtype=F32).contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        m = Mlp()
+        m.number_of_atoms, m.spatial_dimension, m.num_classes = network._natoms, network.spatial_dimension, network.num_classes
+        m.hidden_size, m.n_hidden = hp.hidden_dimensions_size, n_hidden
+        m.e_coordinates = hp.relative_coordinates_embedding_dimensions_size
+        m.e_noise, m.e_time = hp.noise_embedding_dimensions_size, hp.time_embedding_dimensions_size
+        m.e_atom_type = hp.atom_type_embedding_dimensions_size
+        m.e_lattice = hp.lattice_parameters_embedding_dimensions_size
+        for name, layer in (("coordinates", network.relative_coordinates_embedding_layer),
+                            ("noise", network.noise_embedding_layer), ("time", network.time_embedding_layer),
+                            ("atom_type", network.atom_type_embedding_layer),
+                            ("lattice", network.lattice_parameters_embedding_layer)):
+            setattr(m, f"w_{name}_t", wt(layer))
+            setattr(m, f"b_{name}", bias(layer))
+        for k, layer in enumerate(network.mlp_layers):
+            m.w_hidden_t[k] = wt(layer)
+            m.b_hidden[k] = bias(layer)
+        for name, layer in (("a", network.output_A_layer), ("x", network.output_X_layer), ("l", network.output_L_layer)):
+            setattr(m, f"w_out_{name}_t", wt(layer))
+            setattr(m, f"b_out_{name}", bias(layer))
+        self.c_struct = m
+        self.device = torch.device(device)
+        self.number_of_atoms, self.num_classes, self.spatial_dimension = m.number_of_atoms, m.num_classes, m.spatial_dimension
+
+
+def mlp_forward(pack: MlpPack, atom_types, x, l, time, sigma):
+    """Fused forward of the MLP score network: returns (logits [B,N,C] with MASK = -inf, score_x, score_l)."""
+    B, N, d = x.shape
+    assert N == pack.number_of_atoms and d == pack.spatial_dimension
+    logits = torch.empty(B, N, pack.num_classes, dtype=F32, device=x.device)
+    score_x = torch.empty_like(x)
+    score_l = torch.empty_like(l)
+    rc = lib().mdx_mlp_forward(C.byref(pack.c_struct), ptr(atom_types, I64, "atom_types"), ptr(x, F32, "x"),
+                               ptr(l, F32, "l"), ptr(time, F32, "time"), ptr(sigma, F32, "sigma"), B,
+                               ptr(logits, F32, "logits"), ptr(score_x, F32, "score_x"), ptr(score_l, F32, "score_l"),
+                               stream_handle())
+    check(rc, "mdx_mlp_forward")
+    return logits, score_x, score_l
+
+
+def mlp_pc_sample(sched: DeviceSchedule, pack: MlpPack, flags: PcFlags, number_of_corrector_steps: int,
+                  atom_type_transition_in_corrector: bool, start_index: int, n_iterations: int, rng: Rng,
+                  atom_types, x, l, status):
+    """n_iterations x (predictor + M correctors) in one launch, composition updated in place."""
+    B = x.shape[0]
+    rc = lib().mdx_mlp_pc_sample(C.byref(sched.c_struct), C.byref(pack.c_struct), C.byref(flags),
+                                 int(number_of_corrector_steps), int(bool(atom_type_transition_in_corrector)),
+                                 int(start_index), int(n_iterations), rng, B, ptr(atom_types, I64, "atom_types"),
+                                 ptr(x, F32, "x"), ptr(l, F32, "l"), ptr(status, I32, "status"), stream_handle())
+    check(rc, "mdx_mlp_pc_sample")
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -192,6 +192,46 @@ MDX_API int mdx_radius_graph_fill(const float* cartesian_positions, const float*
                           int64_t batch, int number_of_atoms, int unique, const int64_t* offsets,
                           int64_t* edges_out, int32_t* image_out, float* shifts_out, mdx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fused score network: the reference's MLPScoreNetwork (models/score_networks/mlp_score_network.py:54-370,
+ * unconditional forward, no permutation symmetrisation, no time prefactor) evaluated inside the kernels.
+ * All pointers are float32 device memory; every w_*_t is the TRANSPOSE of the nn.Linear weight, i.e. [in, out]
+ * row-major, so that consecutive lanes (output neurons) read consecutive addresses. */
+#define MDX_MLP_MAX_HIDDEN 8
+typedef struct mdx_mlp {
+    int32_t number_of_atoms, spatial_dimension, num_classes;
+    int32_t hidden_size, n_hidden;                       /* hidden_dimensions_size, n_hidden_dimensions */
+    int32_t e_coordinates, e_noise, e_time, e_atom_type, e_lattice;   /* embedding sizes */
+    const float *w_coordinates_t, *b_coordinates;        /* [2*N*d, e_coordinates] */
+    const float *w_noise_t, *b_noise;                    /* [1, e_noise] */
+    const float *w_time_t, *b_time;                      /* [1, e_time] */
+    const float *w_atom_type_t, *b_atom_type;            /* [C, e_atom_type] */
+    const float *w_lattice_t, *b_lattice;                /* [d(d+1)/2, e_lattice] */
+    const float* w_hidden_t[MDX_MLP_MAX_HIDDEN];         /* [in_k, hidden_size] */
+    const float* b_hidden[MDX_MLP_MAX_HIDDEN];
+    const float *w_out_a_t, *b_out_a;                    /* [hidden_size, N*C] */
+    const float *w_out_x_t, *b_out_x;                    /* [hidden_size, N*d] */
+    const float *w_out_l_t, *b_out_l;                    /* [hidden_size, d(d+1)/2] */
+} mdx_mlp_t;
+
+/* ScoreNetwork.forward of the MLP (mlp_score_network.py:281-370 + score_network.py:183-185: MASK logit = -inf):
+ * one wavefront per structure, weights streamed from L2, activations in LDS.  time, sigma: [B,1]. */
+MDX_API int mdx_mlp_forward(const mdx_mlp_t* mlp_host, const int64_t* atom_types, const float* x, const float* l,
+                            const float* time, const float* sigma, int64_t batch, float* logits_out,
+                            float* score_x_out, float* score_l_out, mdx_stream_t stream);
+
+/* The whole sampling loop of LangevinGenerator.sample_from_noisy_composition
+ * (generators/predictor_corrector_axl_generator.py:145-160 with langevin_generator.py:536-805) in ONE launch for an
+ * MLP score network: every wavefront owns one structure, keeps its composition in LDS, and runs
+ * `n_iterations` x (predictor + M correctors) -- network forward and fused update -- without returning to the host.
+ * Device RNG only (the Philox specification makes it equal, draw for draw, to the per-step kernels).
+ * The first iteration's predictor has time index `start_index`; the composition is updated in place. */
+MDX_API int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_host,
+                              const mdx_pc_flags_t* flags_host, int number_of_corrector_steps,
+                              int atom_type_transition_in_corrector, int start_index, int n_iterations, mdx_rng_t rng,
+                              int64_t batch, int64_t* atom_types, float* x, float* l, uint32_t* status,
+                              mdx_stream_t stream);
+
 /* Device-RNG draws as stand-alone fills (trajectory initialisation, tests of the RNG specification).
  * kind 0 = uniform (0,1), 1 = standard normal, 2 = Gumbel(0,1).  out [n_items, width]. */
 MDX_API int mdx_rng_fill(int kind, uint64_t seed, uint32_t call, uint32_t draw, uint32_t tag, int64_t n_items, int width,

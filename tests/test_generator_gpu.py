@@ -344,3 +344,77 @@ def test_cli_end_to_end(cuda, tmp_path):
         if sub == "repaint":
             x = samples["original_axl"].X[:, :3].cpu()
             assert torch.equal(x, constraint.constrained_relative_coordinates.expand(12, 3, 3))
+
+
+# -------------------------------------------------------------------------------------------------------------
+# fused MLP score network: forward against the PyTorch module, persistent sampler against the per-step path
+# -------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_atoms,nat,hidden,n_hidden", [(8, 1, 64, 3), (8, 2, 64, 3), (5, 4, 48, 2), (20, 1, 96, 4),
+                                                         (64, 2, 128, 3)])
+def test_fused_mlp_forward_against_torch(cuda, n_atoms, nat, hidden, n_hidden):
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
+                                                                              NOISY_AXL_COMPOSITION, TIME)
+    torch.manual_seed(n_atoms + nat)
+    net = nets.mlp_net(n_atoms, nat, hidden=hidden, n_hidden=n_hidden).to(cuda)
+    B = 37
+    batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.randint(0, nat + 1, (B, n_atoms), device=cuda),
+                                        X=torch.rand(B, n_atoms, 3, device=cuda),
+                                        L=torch.tensor([5.43, 5.5, 5.6, 0, 0, 0.0], device=cuda).repeat(B, 1)),
+             TIME: torch.rand(B, 1, device=cuda), NOISE: torch.rand(B, 1, device=cuda) * 0.25,
+             CARTESIAN_FORCES: torch.zeros(B, n_atoms, 3, device=cuda)}
+    with torch.no_grad():
+        want = net(batch, conditional=False)
+    pack = kernels.MlpPack(net, cuda)
+    comp = batch[NOISY_AXL_COMPOSITION]
+    logits, sx, sl = kernels.mlp_forward(pack, comp.A, comp.X, comp.L, batch[TIME], batch[NOISE])
+    assert torch.isinf(logits[..., -1]).all()
+    # float32 forward with a different summation order and an exactly periodic cos/sin: 1e-5 relative to the output scale
+    for got, ref in ((sx, want.X), (sl, want.L), (logits[..., :-1], want.A[..., :-1])):
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("name", ["traj_mlp_c3", "traj_mlp_c1"])
+def test_fused_sampler_against_per_step_path_and_oracle(cuda, name):
+    """One persistent launch for the whole trajectory == the per-step kernels with the PyTorch forward (same Philox
+    draws; the forwards differ by float32 rounding only) == the CPU oracle."""
+    seed, batch = 99, 40
+    outs = {}
+    for fused in (False, True):
+        gen, npar, spar, net_cpu = _build(name, cases.TRAJECTORIES, cuda, rng_mode="device", seed=seed,
+                                          fused_score_network=fused)
+        with torch.no_grad():
+            outs[fused] = _np(gen.sample(batch, cuda))
+    ora = RS.OracleLangevinGenerator(npar, spar, net_cpu, noise=RS.PhiloxNoise(seed, 0)).sample(batch)
+    tol = FREE_RUN_TOLERANCE.get(name, 1e-5)
+    assert np.array_equal(outs[True].A, outs[False].A) and np.array_equal(outs[True].A, ora.A)
+    assert torus_rel_l2(outs[True].X, outs[False].X) < tol
+    assert torus_rel_l2(outs[True].X, ora.X) < tol
+
+
+def test_fused_sampler_segments_compose(cuda):
+    """Running the loop as 3 launches over consecutive index ranges == one launch (state round-trips through HBM)."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    gen, npar, spar, _ = _build("traj_mlp_c3", cases.TRAJECTORIES, cuda, rng_mode="device", seed=5,
+                                fused_score_network=True)
+    with torch.no_grad():
+        gen._prepare(cuda)
+        gen._begin_call(cuda)
+        start = gen.initialize(16, cuda)
+        whole = gen._sample_fused(start, 16, 0)
+        comp = RS.AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
+        sched, pack = gen._prepare(cuda), gen.fused_pack(cuda)
+        for first, n in ((16, 5), (11, 10), (1, 1)):
+            kernels.mlp_pc_sample(sched, pack, gen._flags(True), 2, False, first, n, gen._rng(0), comp.A, comp.X, comp.L,
+                                  gen._status)
+    assert torch.equal(whole.A, comp.A) and torch.equal(whole.X, comp.X)
+
+
+def test_fused_needs_mlp_and_device_rng(cuda):
+    from diffusion_for_multi_scale_molecular_dynamics_amd._hip import MdxError
+    gen, *_ = _build("traj_fake_c2", cases.TRAJECTORIES, cuda, rng_mode="device", seed=1, fused_score_network=True)
+    with pytest.raises(MdxError, match="MLPScoreNetwork"):
+        gen.sample(2, cuda)
+    gen, *_ = _build("traj_mlp_c3", cases.TRAJECTORIES, cuda, fused_score_network=True)     # reference RNG
+    with pytest.raises(MdxError, match="rng_mode='device'"):
+        gen.sample(2, cuda)

@@ -239,6 +239,20 @@ def test_radius_graph_random(K, oracle, cuda, B, N, box, rc):
     _check_graph(K, oracle, cuda, cart, cell, rc)
 
 
+@pytest.mark.parametrize("B,N,box,rc", [(4, 64, 16.5, 7.5), (3, 216, 16.5, 7.5), (5, 8, 5.43, 2.4), (2, 100, 11.0, 5.0),
+                                        (2, 33, 10.0, 4.6)])
+def test_radius_graph_orthorhombic_fast_path(K, oracle, cuda, B, N, box, rc):
+    """Diagonal cells with rc <= L/2.2 take the nearest-image path (one image evaluated instead of 27); rc > L/2.2
+    (last case) and the triclinic cases above take the 27-image path.  Both must equal the oracle's brute force."""
+    rng = np.random.default_rng(B * N)
+    X = rng.random((B, N, 3), dtype=np.float32)
+    X[0, 0] = 0.0
+    X[0, 1] = [0.99999994, 0.5, 0.0]           # atoms on the cell faces
+    cell = np.tile(np.diag([box, box * 1.1, box * 1.25]).astype(np.float32), (B, 1, 1))
+    cart = np.matmul(X, cell).astype(np.float32)
+    _check_graph(K, oracle, cuda, cart, cell, rc)
+
+
 def test_radius_graph_cutoff_too_large_sets_status(K, cuda):
     cart = torch.rand(2, 8, 3, device=cuda) * 4.0
     cell = torch.diag(torch.tensor([4.0, 4.0, 4.0])).repeat(2, 1, 1).to(cuda)
