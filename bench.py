@@ -353,8 +353,14 @@ def main():
             else:
                 m = time_radius_graph(batch, w, device)
             achieved = m["bytes"] / (m["ms"] * 1e-3) / 1e9
+            traffic = None          # HBM bytes per launch measured with PMC counters in a separate rocprofv3 pass
+            try:
+                table = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+                traffic = table[m["kernel"].split()[0].split("<")[0]]["bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, kernel=m["kernel"],
+                            frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, kernel=m["kernel"],
                             avg_launch_us=round(m["ms"] * 1e3, 3), algorithmic_bytes_per_launch=m["bytes"])
 
     if rank != 0:

@@ -278,33 +278,37 @@ struct PcArgs {
     uint32_t* status;
 };
 
-// posterior p(a_{t-1} | a_t, logits) for one atom (utils/d3pm_utils.py:105-150)
+// posterior p(a_{t-1} | a_t, logits) for one atom (utils/d3pm_utils.py:105-150).  Loops run to the compile-time
+// bound MDX_MAX_CLASSES with a (c < C) predicate so that e[] / p[] stay in registers (no scratch); the operations
+// performed, and their order, are those of the runtime-bound loops.
+#define MDX_FOR_CLASSES(c) _Pragma("unroll") for (int c = 0; c < MDX_MAX_CLASSES; ++c) if (c < C)
 __device__ __forceinline__ void posterior(const float* __restrict__ logits, int a_t, const float* __restrict__ q,
                                           const float* __restrict__ qbar, const float* __restrict__ qbar_tm1, int C,
                                           float small_eps, float* p)
 {
-    float e[MDX_MAX_CLASSES];
-    float m = logits[0];
-    for (int c = 1; c < C; ++c) m = (logits[c] > m) ? logits[c] : m;
+    float e[MDX_MAX_CLASSES], lg[MDX_MAX_CLASSES];
+    MDX_FOR_CLASSES(c) lg[c] = logits[c];
+    float m = lg[0];
+    MDX_FOR_CLASSES(c) if (c > 0) m = (lg[c] > m) ? lg[c] : m;
     float S = 0.0f;
-    for (int c = 0; c < C; ++c) {
-        e[c] = expf_(logits[c] - m);
+    MDX_FOR_CLASSES(c) {
+        e[c] = expf_(lg[c] - m);
         S = S + e[c];
     }
     const float invS = 1.0f / S;
     float S2 = 0.0f;
-    for (int c = 0; c < C; ++c) {
+    MDX_FOR_CLASSES(c) {
         float r = e[c] * invS;
         r = (r < small_eps) ? small_eps : r;
         e[c] = r;
         S2 = S2 + r;
     }
-    for (int c = 0; c < C; ++c) e[c] = e[c] / S2;
+    MDX_FOR_CLASSES(c) e[c] = e[c] / S2;
     float den = 0.0f;
-    for (int j = 0; j < C; ++j) den = den + e[j] * qbar[j * C + a_t];
-    for (int i = 0; i < C; ++i) {
+    MDX_FOR_CLASSES(j) den = den + e[j] * qbar[j * C + a_t];
+    MDX_FOR_CLASSES(i) {
         float num1 = 0.0f;
-        for (int j = 0; j < C; ++j) num1 = num1 + e[j] * qbar_tm1[j * C + i];
+        MDX_FOR_CLASSES(j) num1 = num1 + e[j] * qbar_tm1[j * C + i];
         const float num2 = q[i * C + a_t];
         p[i] = (num1 * num2) / den;
     }
@@ -335,23 +339,22 @@ struct PcView {
     int64_t item0, b;
 };
 
-__device__ __forceinline__ PcStep make_step(const PcArgs& p)
+__device__ __forceinline__ PcStep make_step(const PcArgs& p, int mode, int index, uint32_t draw_offset)
 {
     PcStep st;
     const int C = p.C;
     st.q = p.q_explicit; st.qbar = p.qbar_explicit; st.qbar_tm1 = p.qbar_tm1_explicit;
     st.one = p.one_transition;
     st.last_predictor_step = 0;
-    st.draw = p.rng.draw_offset;
+    st.draw = draw_offset;
     if (p.use_tables) {
-        const int index = (p.d_index ? *p.d_index : 0) + p.index_i;
-        st.sc = step_scalars(p.sched, p.mode, index, p.atoms_pow);
+        st.sc = step_scalars(p.sched, mode, index, p.atoms_pow);
         st.q = p.sched.q + (int64_t)st.sc.idx * C * C;
         st.qbar = p.sched.qbar + (int64_t)st.sc.idx * C * C;
         st.qbar_tm1 = p.sched.qbar_tm1 + (int64_t)st.sc.idx * C * C;
-        st.last_predictor_step = (p.mode == MDX_PREDICTOR && st.sc.idx == 0);
+        st.last_predictor_step = (mode == MDX_PREDICTOR && st.sc.idx == 0);
         if (st.last_predictor_step) st.one = 0;                 // generators/langevin_generator.py:601-604
-        st.draw = (uint32_t)index * p.rng.draw_stride + p.rng.draw_offset;
+        st.draw = (uint32_t)index * p.rng.draw_stride + draw_offset;
     }
     st.k0 = (uint32_t)p.rng.seed;
     st.k1 = (uint32_t)(p.rng.seed >> 32);
@@ -359,16 +362,22 @@ __device__ __forceinline__ PcStep make_step(const PcArgs& p)
     return st;
 }
 
+__device__ __forceinline__ PcStep make_step(const PcArgs& p)
+{
+    return make_step(p, p.mode, (p.d_index ? *p.d_index : 0) + p.index_i, p.rng.draw_offset);
+}
+
 // The update of one structure by the G lanes of its group (P2, P1, P3).  Used by pc_step_kernel on global memory and
 // by the fused MLP sampler kernel on its LDS-resident state: one body, one arithmetic.
 template <int G>
-__device__ __forceinline__ void pc_update_structure(const PcArgs& p, const PcStep& st, const PcView& v, int lane)
+__device__ __forceinline__ void pc_update_structure(const PcArgs& p, const PcStep& st, const PcView& v, int lane,
+                                                    int update_types)
 {
     const int N = p.N, C = p.C, d = p.d, M = p.C - 1;
     const StepScalars& sc = st.sc;
     const int one = st.one;
     int all_masked = 1;
-    if (p.update_types && p.greedy) {
+    if (update_types && p.greedy) {
         for (int n = lane; n < N; n += G) all_masked &= (v.a[n] == M);
         all_masked = group_and<G>(all_masked);
     }
@@ -377,30 +386,38 @@ __device__ __forceinline__ void pc_update_structure(const PcArgs& p, const PcSte
     int best_prop = 0;
     for (int n = lane; n < N; n += G) {
         const uint32_t item = (uint32_t)(v.item0 + n);
-        if (p.update_types) {
+        if (update_types) {
             const int a_t = (int)v.a[n];
             float pr[MDX_MAX_CLASSES], gm[MDX_MAX_CLASSES];
             posterior(v.logits + n * C, a_t, st.q, st.qbar, st.qbar_tm1, C, p.small_eps, pr);
             if (v.gumbel) {
-                for (int c = 0; c < C; ++c) gm[c] = v.gumbel[n * C + c];
+                MDX_FOR_CLASSES(c) gm[c] = v.gumbel[n * C + c];
             } else {
-                for (int sub = 0; sub * 4 < C; ++sub) {
-                    const u32x4 r = philox4x32_10(item, st.call8 | (uint32_t)sub, st.draw, MDX_TAG_GUMBEL, st.k0, st.k1);
-                    for (int l = 0; l < 4 && sub * 4 + l < C; ++l) gm[sub * 4 + l] = gumbel_from_u(u01(r.v[l]));
-                }
+#pragma unroll
+                for (int sub = 0; sub < MDX_MAX_CLASSES / 4; ++sub)
+                    if (sub * 4 < C) {
+                        const u32x4 r = philox4x32_10(item, st.call8 | (uint32_t)sub, st.draw, MDX_TAG_GUMBEL, st.k0, st.k1);
+#pragma unroll
+                        for (int l = 0; l < 4; ++l)
+                            if (sub * 4 + l < C) gm[sub * 4 + l] = gumbel_from_u(u01(r.v[l]));
+                    }
             }
+            float pr_mask = 0.0f;
+            MDX_FOR_CLASSES(c) if (c == M) pr_mask = pr[c];
             if (p.greedy) {                                      // :382-439
                 float uu;
                 if (v.u) uu = v.u[n];
                 else uu = u01(philox4x32_10(item, st.call8, st.draw, MDX_TAG_BINARY, st.k0, st.k1).v[0]);
-                const int unmask = uu > pr[M];
-                if (!all_masked && unmask && a_t == M) pr[M] = 0.0f;
-                if (!all_masked)
-                    for (int c = 0; c < C; ++c) gm[c] = 0.0f;
+                const int unmask = uu > pr_mask;
+                const bool zero_mask = !all_masked && unmask && a_t == M;
+                MDX_FOR_CLASSES(c) {
+                    if (zero_mask && c == M) pr[c] = 0.0f;
+                    if (!all_masked) gm[c] = 0.0f;
+                }
             }
             float v_best = 0.0f;
             int prop = 0;
-            for (int c = 0; c < C; ++c) {                        // :311-315, first maximal index
+            MDX_FOR_CLASSES(c) {                                 // :311-315, first maximal index
                 const float val = logf_(pr[c] + p.small_eps) + gm[c];
                 if (c == 0 || val > v_best) { v_best = val; prop = c; }
                 if (v.p_out) v.p_out[n * C + c] = pr[c];
@@ -417,20 +434,23 @@ __device__ __forceinline__ void pc_update_structure(const PcArgs& p, const PcSte
             v.a_out[n] = v.a[n];
         }
         if (p.do_coords) {                                       // :194-201
-            float z[4];
+            float z0 = 0.0f, z1 = 0.0f, z2 = 0.0f, z3 = 0.0f;
             if (!v.z_coord) {
                 const u32x4 r = philox4x32_10(item, st.call8, st.draw, MDX_TAG_COORD, st.k0, st.k1);
-                box_muller(r.v[0], r.v[1], z[0], z[1]);
-                if (d > 2) box_muller(r.v[2], r.v[3], z[2], z[3]);
+                box_muller(r.v[0], r.v[1], z0, z1);
+                if (d > 2) box_muller(r.v[2], r.v[3], z2, z3);
             }
-            for (int k = 0; k < d; ++k) {
-                const int e = n * d + k;
-                const float zz = v.z_coord ? v.z_coord[e] : z[k];
-                v.x_out[e] = coord_update(v.x[e], v.score_x[e], zz, sc.w, sc.n, sc.sigma);
-            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < d) {
+                    const int e = n * d + k;
+                    const float zk = k == 0 ? z0 : (k == 1 ? z1 : z2);
+                    const float zz = v.z_coord ? v.z_coord[e] : zk;
+                    v.x_out[e] = coord_update(v.x[e], v.score_x[e], zz, sc.w, sc.n, sc.sigma);
+                }
         }
     }
-    if (p.update_types && one) {
+    if (update_types && one) {
         // arg-max over the atoms of the structure: larger value wins, ties go to the smaller atom index
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) {
@@ -487,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void pc_step_kernel(PcArgs p)
         v.x_out = off(p.x_out, a0 * d); v.l_out = off(p.l_out, b * p.nl); v.p_out = off(p.p_out, a0 * C);
         v.item0 = a0;
         v.b = b;
-        pc_update_structure<G>(p, st, v, lane);
+        pc_update_structure<G>(p, st, v, lane, p.update_types);
     }
 }
 
@@ -582,8 +602,11 @@ __device__ __forceinline__ void linear_wave(WP wt, WP bias, lds_cf* in, int in_d
 
 // Offsets (in floats) of every parameter tensor inside one packed weight image, in the order they are staged.
 struct MlpOffsets {
-    int wc, bc, wn, bn, wt, bt, wa, ba, wl, bl, wh[MDX_MLP_MAX_HIDDEN], bh[MDX_MLP_MAX_HIDDEN], woa, boa, wox, box, wol, bol,
-        total, in0;
+    int wc, bc, wn, bn, wt, bt, wa, ba, wl, bl, wh0, wh_first, wh_size, bh_size, woa, boa, total, in0;
+    // hidden layer k: weights at wh(k), bias right behind them -- arithmetic instead of arrays (arrays indexed by a
+    // loop variable end up in scratch memory)
+    __host__ __device__ int wh(int k) const { return k == 0 ? wh0 : wh0 + wh_first + bh_size + (k - 1) * (wh_size + bh_size); }
+    __host__ __device__ int bh(int k) const { return wh(k) + (k == 0 ? wh_first : wh_size); }
 };
 
 __host__ __device__ inline MlpOffsets mlp_offsets(const mdx_mlp_t& m)
@@ -599,24 +622,29 @@ __host__ __device__ inline MlpOffsets mlp_offsets(const mdx_mlp_t& m)
     o.wt = take(m.e_time); o.bt = take(m.e_time);
     o.wa = take(C * m.e_atom_type); o.ba = take(m.e_atom_type);
     o.wl = take(nl * m.e_lattice); o.bl = take(m.e_lattice);
-    for (int k = 0; k < m.n_hidden; ++k) {
-        o.wh[k] = take(quad(k == 0 ? o.in0 : H, H));
-        o.bh[k] = take(H);
-    }
+    o.wh_first = quad(o.in0, H);
+    o.wh_size = quad(H, H);
+    o.bh_size = (H + 3) & ~3;
+    o.wh0 = take(o.wh_first + o.bh_size + (m.n_hidden - 1) * (o.wh_size + o.bh_size));
     // the three heads are staged as ONE [H][N C + N d + nl] matrix (one layer loop instead of three); woa/boa name it
     o.woa = take(quad(H, N * C + N * d + nl)); o.boa = take(N * C + N * d + nl);
-    o.wox = o.woa; o.box = o.boa; o.wol = o.woa; o.bol = o.boa;
     o.total = t;
     return o;
 }
 
 // The network's parameters as plain pointers (either the caller's global tensors or the LDS image)
-template <typename P>
-struct MlpWeightsT {
-    P wc, bc, wn, bn, wt, bt, wa, ba, wl, bl, wh[MDX_MLP_MAX_HIDDEN], bh[MDX_MLP_MAX_HIDDEN], woa, boa, wox, box, wol, bol;
+struct MlpWeights {          // the caller's tensors in global memory
+    const float *wc, *bc, *wn, *bn, *wt, *bt, *wa, *ba, *wl, *bl, *woa, *boa, *wox, *box, *wol, *bol;
+    const mdx_mlp_t* m;
+    __device__ const float* wh(int k) const { return m->w_hidden_t[k]; }
+    __device__ const float* bh(int k) const { return m->b_hidden[k]; }
 };
-typedef MlpWeightsT<const float*> MlpWeights;
-typedef MlpWeightsT<lds_cf*> MlpWeightsLds;
+struct MlpWeightsLds {       // the workgroup's LDS image
+    lds_cf *wc, *bc, *wn, *bn, *wt, *bt, *wa, *ba, *wl, *bl, *woa, *boa, *wox, *box, *wol, *bol, *img;
+    MlpOffsets off;
+    __device__ lds_cf* wh(int k) const { return img + off.wh(k); }
+    __device__ lds_cf* bh(int k) const { return img + off.bh(k); }
+};
 
 __device__ __forceinline__ MlpWeights weights_global(const mdx_mlp_t& m)
 {
@@ -624,7 +652,7 @@ __device__ __forceinline__ MlpWeights weights_global(const mdx_mlp_t& m)
     w.wc = m.w_coordinates_t; w.bc = m.b_coordinates; w.wn = m.w_noise_t; w.bn = m.b_noise;
     w.wt = m.w_time_t; w.bt = m.b_time; w.wa = m.w_atom_type_t; w.ba = m.b_atom_type;
     w.wl = m.w_lattice_t; w.bl = m.b_lattice;
-    for (int k = 0; k < m.n_hidden; ++k) { w.wh[k] = m.w_hidden_t[k]; w.bh[k] = m.b_hidden[k]; }
+    w.m = &m;
     w.woa = m.w_out_a_t; w.boa = m.b_out_a; w.wox = m.w_out_x_t; w.box = m.b_out_x; w.wol = m.w_out_l_t; w.bol = m.b_out_l;
     return w;
 }
@@ -653,9 +681,11 @@ __device__ __forceinline__ MlpWeightsLds weights_to_lds(const mdx_mlp_t& m, cons
     w.wa = copy(m.w_atom_type_t, o.wa, C * m.e_atom_type); w.ba = copy(m.b_atom_type, o.ba, m.e_atom_type);
     w.wl = copy(m.w_lattice_t, o.wl, nl * m.e_lattice); w.bl = copy(m.b_lattice, o.bl, m.e_lattice);
     for (int k = 0; k < m.n_hidden; ++k) {
-        w.wh[k] = copy_quad(m.w_hidden_t[k], o.wh[k], k == 0 ? o.in0 : H, H);
-        w.bh[k] = copy(m.b_hidden[k], o.bh[k], H);
+        copy_quad(m.w_hidden_t[k], o.wh(k), k == 0 ? o.in0 : H, H);
+        copy(m.b_hidden[k], o.bh(k), H);
     }
+    w.img = (lds_cf*)img;
+    w.off = o;
     {   // merged heads: columns [0, NC) logits, [NC, NC+Nd) score_x, [NC+Nd, ..) score_l
         const int nt = N * C + N * d + nl, kp = (H + 3) & ~3;
         for (int e = threadIdx.x; e < kp * nt; e += blockDim.x) {
@@ -720,7 +750,7 @@ __device__ __forceinline__ void mlp_forward_wave(const mdx_mlp_t& m, const W& w,
     lds_f* out = buf_a;
     int in_dim = o;
     for (int k = 0; k < m.n_hidden; ++k) {
-        linear_wave<QUAD>(w.wh[k], w.bh[k], in, in_dim, m.hidden_size, out, lane, k + 1 < m.n_hidden);
+        linear_wave<QUAD>(w.wh(k), w.bh(k), in, in_dim, m.hidden_size, out, lane, k + 1 < m.n_hidden);
         if (lane < 4) out[m.hidden_size + lane] = 0.0f;
         wave_sync();
         lds_f* t = in; in = out; out = t;
@@ -851,17 +881,13 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
             for (int it = 0; it < p.n_iterations; ++it) {
                 const int i = p.start_index - 1 - it;               // loop variable of the reference (:147)
                 for (int sub = 0; sub <= p.M; ++sub) {
-                    PcArgs a = p.pc;
-                    a.mode = sub == 0 ? MDX_PREDICTOR : MDX_CORRECTOR;
-                    a.index_i = sub == 0 ? i + 1 : i;
-                    a.d_index = nullptr;
-                    a.rng.draw_offset = (uint32_t)sub;
-                    a.update_types = sub == 0 ? 1 : p.types_in_corrector;
-                    const PcStep st = make_step(a);
+                    const int mode = sub == 0 ? MDX_PREDICTOR : MDX_CORRECTOR;
+                    const PcStep st = make_step(p.pc, mode, sub == 0 ? i + 1 : i, (uint32_t)sub);
                     if (!(p.diag_skip & 1))
                         mlp_forward_wave<LDS_WEIGHTS>(m, w, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b,
                                                       r.logits, r.sx, r.sl);
-                    if (lane < G && !(p.diag_skip & 2)) pc_update_structure<G>(a, st, v, lane);
+                    if (lane < G && !(p.diag_skip & 2))
+                        pc_update_structure<G>(p.pc, st, v, lane, sub == 0 ? 1 : p.types_in_corrector);
                     wave_sync();
                 }
             }

@@ -3,6 +3,7 @@ from typing import Optional
 
 from ..models.score_networks.score_network import ScoreNetwork
 from ..noise_schedulers.noise_parameters import NoiseParameters
+from .adaptive_corrector import AdaptiveCorrectorGenerator
 from .axl_generator import SamplingParameters
 from .constrained_langevin_generator import ConstrainedLangevinGenerator
 from .langevin_generator import LangevinGenerator
@@ -25,5 +26,8 @@ def instantiate_generator(sampling_parameters: SamplingParameters, noise_paramet
     if sampling_parameters.algorithm == "predictor_corrector":
         return LangevinGenerator(sampling_parameters=sampling_parameters, noise_parameters=noise_parameters,
                                  axl_network=axl_network, trajectory_initializer=trajectory_initializer)
+    if sampling_parameters.algorithm == "adaptive_corrector":
+        return AdaptiveCorrectorGenerator(sampling_parameters=sampling_parameters, noise_parameters=noise_parameters,
+                                          axl_network=axl_network, trajectory_initializer=trajectory_initializer)
     raise NotImplementedError(f"algorithm '{sampling_parameters.algorithm}' is outside the MI355X hot path "
                               "(SURVEY.md section 8)")

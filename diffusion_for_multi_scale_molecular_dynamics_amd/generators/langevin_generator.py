@@ -204,7 +204,33 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
                                None if self.use_fixed_lattice_parameters else predictions.L.contiguous(),
                                z, gumbel, u, z_lattice, self._rng(draw_offset),
                                a_out if update_types else None, x_out, l_out, self._status)
+        if self.record_atom_type_update and update_types:
+            self._record_atom_type_update(sched, mode, index_i, logits, a_in, gumbel, u, a_out, batch)
         return AXL(A=a_out, X=x_out, L=l_out), predictions
+
+    def _record_atom_type_update(self, sched, mode, index_i, logits, a_in, gumbel, u, a_out, batch):
+        """langevin_generator.py:325-335: logits, p(a_{t-1}|a_t) after the greedy adjustment, Gumbel values used."""
+        idx = index_i - 1 if (mode == MDX_PREDICTOR or index_i > 0) else 0
+        src = self.noise_source
+        if gumbel is None:       # device RNG: materialise the same draws the fused kernel generated in registers
+            from .._hip import TAG_BINARY, TAG_GUMBEL
+            draw = index_i * (self.number_of_corrector_steps + 1) + (0 if mode == MDX_PREDICTOR else 1)
+            n = batch * self.number_of_atoms
+            gumbel = kernels.rng_fill(kernels.RNG_GUMBEL, src.seed, src.call, draw, TAG_GUMBEL, n, self.num_classes,
+                                      logits.device).view(batch, self.number_of_atoms, self.num_classes)
+            u = kernels.rng_fill(kernels.RNG_UNIFORM, src.seed, src.call, draw, TAG_BINARY, n, 1,
+                                 logits.device).view(batch, self.number_of_atoms)
+        one = self.one_atom_type_transition_per_step and not (mode == MDX_PREDICTOR and idx == 0)
+        a_check, probs = kernels.atom_types_update(logits, a_in, sched.q_matrix[idx], sched.q_bar_matrix[idx],
+                                                   sched.q_bar_tm1_matrix[idx], gumbel, u, self.small_epsilon,
+                                                   self.atom_type_greedy_sampling, one, return_probabilities=True)
+        assert torch.equal(a_check, a_out), "stand-alone and fused atom-type updates disagree"
+        if self.atom_type_greedy_sampling:
+            all_masked = (a_in == self.masked_atom_type_index).all(dim=-1)
+            gumbel = torch.where(all_masked.view(-1, 1, 1), gumbel, torch.zeros_like(gumbel))
+        self.sample_trajectory_recorder.record(key="atom_type_update", entry=dict(
+            predicted_logits=logits.detach().cpu(), one_step_transition_probabilities=probs.cpu(),
+            gumbel_sample=gumbel.cpu(), a_i=a_in.cpu(), a_im1=a_out.cpu()))
 
     def predictor_step(self, composition_i: AXL, index_i: int, cartesian_forces: torch.Tensor) -> AXL:
         """composition at time index i -> i-1  (langevin_generator.py:536-645)."""

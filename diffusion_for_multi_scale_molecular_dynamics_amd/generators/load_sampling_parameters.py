@@ -4,7 +4,7 @@ from typing import Any, AnyStr, Dict
 from .axl_generator import SamplingParameters
 from .predictor_corrector_axl_generator import PredictorCorrectorSamplingParameters
 
-SUPPORTED = ("predictor_corrector",)
+SUPPORTED = ("predictor_corrector", "adaptive_corrector")
 KNOWN = ("ode", "sde", "predictor_corrector", "adaptive_corrector")
 
 
@@ -16,5 +16,5 @@ def load_sampling_parameters(sampling_parameter_dictionary: Dict[AnyStr, Any]) -
     if algorithm not in SUPPORTED:
         raise NotImplementedError(
             f"algorithm '{algorithm}' is outside the MI355X hot path (SURVEY.md section 8: torchode/torchsde "
-            "generators are out of scope; adaptive_corrector is listed under 'next')")
+            "generators are out of scope)")
     return PredictorCorrectorSamplingParameters(**sampling_parameter_dictionary)

@@ -102,8 +102,12 @@ def main(args: Optional[Any] = None, axl_network: Optional[ScoreNetwork] = None)
                 f"The path {args.checkpoint} does not exist. Cannot go on."
             axl_network = get_axl_network(args.checkpoint, hyper_params)
     axl_network = axl_network.to(device)
-    if "force_field" in hyper_params:
-        raise NotImplementedError("force_field augmentation is listed under 'next' in SURVEY.md section 8(f)")
+    if "force_field" in hyper_params:                                  # src/sample_diffusion.py:132-139
+        from .models.score_networks.force_field_augmented_score_network import (ForceFieldAugmentedScoreNetwork,
+                                                                                 ForceFieldParameters)
+        force_field_parameters = ForceFieldParameters(**hyper_params["force_field"])
+        logger.info("Augmenting the AXL_network with an excluding Force Field.")
+        axl_network = ForceFieldAugmentedScoreNetwork(axl_network, force_field_parameters)
 
     trajectory_initializer = instantiate_trajectory_initializer(
         sampling_parameters=sampling_parameters,

@@ -327,3 +327,57 @@ def create_batch_of_samples(generator, number_of_samples, sample_batchsize=None)
     L[..., d:] = 0
     cart = (X * L[:, None, :d]).astype(np.float32)   # X @ diag(L[:d])
     return {"cartesian_positions": cart, "original_axl": AXL(A=A, X=X, L=L)}
+
+
+class OracleAdaptiveCorrectorGenerator(OracleLangevinGenerator):
+    """generators/adaptive_corrector.py:17-148: predictor touches the atom types only; corrector step size
+    eps = 2 (r mean|z| / (mean|sigma s| / sigma))^2 from batch means."""
+
+    def __init__(self, noise_parameters, sampling_parameters, axl_network, noise=None):
+        super().__init__(noise_parameters, sampling_parameters, axl_network, noise=noise)
+        self.corrector_r = noise_parameters.corrector_r
+
+    def predictor_step(self, comp, index):
+        B = comp.X.shape[0]
+        sc = step_scalars(self.tables, self.sigma_min, PREDICTOR, index, self.N, self.d)
+        pred = self._predict(comp, sc["time"], sc["sigma"])
+        last = sc["idx"] == 0
+        A = self._atom_types(pred.A, comp.A, sc["idx"], self.one and not last, index, 0)
+        if self.noise.reference_order:
+            self.noise.randn(B, self.N, self.d)          # drawn by the reference, unused
+            self.noise.randn(B, self.nl)
+        out = AXL(A=A, X=comp.X, L=comp.L)
+        if self.record:
+            self.records.append(("predictor", index, comp, out, pred))
+        return out
+
+    def _eps(self, sigma, score, z, coordinates):
+        f32 = np.float32
+        flat = score.reshape(score.shape[0], -1) if coordinates else score
+        score_norm = f32(np.linalg.norm(flat.astype(np.float32), axis=-1).mean(dtype=np.float32)) / f32(sigma)
+        z_norm = f32(np.linalg.norm(z.astype(np.float32), axis=-1).mean(dtype=np.float32))
+        ratio = f32(self.corrector_r) * z_norm / max(score_norm, f32(self.small_epsilon))
+        return f32(2.0) * f32(ratio) * f32(ratio)
+
+    def corrector_step(self, comp, index, m=0):
+        B = comp.X.shape[0]
+        sc = step_scalars(self.tables, self.sigma_min, CORRECTOR, index, self.N, self.d)
+        pred = self._predict(comp, sc["time"], sc["sigma"])
+        z = self._normal_coords(B, index, 1 + m)
+        eps = self._eps(sc["sigma"], pred.X, z, True)
+        X = O.coordinates_update(comp.X, pred.X, z, eps, np.sqrt(np.float32(2.0) * eps), sc["sigma"])
+        L = comp.L
+        if self.noise.reference_order:
+            z_lat = self.noise.randn(B, self.nl)
+        if not self.fixed:
+            if self.noise.reference_order:
+                z_used = self.noise.randn(B, self.nl)
+            else:
+                z_lat = self._normal_lattice(B, index, 1 + m, needed=True)
+                z_used = z_lat
+            eps_l = self._eps(sc["sigma_n"], pred.L, z_lat, False)
+            L = O.lattice_update(comp.L, pred.L, z_used, eps_l, np.sqrt(np.float32(2.0) * eps_l), sc["sigma_n"])
+        out = AXL(A=comp.A, X=X, L=L)
+        if self.record:
+            self.records.append(("corrector", index, comp, out, pred))
+        return out

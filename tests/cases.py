@@ -8,7 +8,7 @@ LIN = dict(sigma_min=1e-4, sigma_max=0.2, schedule_type="linear", corrector_step
 
 def noise_ns(T, **kw):
     d = dict(total_time_steps=T, schedule_type="exponential", time_delta=1e-5, sigma_min=0.005, sigma_max=0.5,
-             corrector_step_epsilon=2e-5)
+             corrector_step_epsilon=2e-5, corrector_r=0.17)
     d.update(kw)
     return d
 
@@ -46,3 +46,9 @@ REPAINT = {
 
 def as_objects(noise_kw, sampling_kw):
     return SimpleNamespace(**noise_kw), SimpleNamespace(**sampling_kw)
+
+ADAPTIVE = {
+    "traj_adaptive_fake": (noise_ns(8, corrector_r=0.5), dict(sampling_ns(8, 2, M=2), algorithm="adaptive_corrector"), None),
+    "traj_adaptive_mlp": (noise_ns(10, sigma_min=1e-3, sigma_max=0.2, schedule_type="linear"),
+                          dict(sampling_ns(8, 1), algorithm="adaptive_corrector"), lambda eb: nets.mlp_net(8, 1)),
+}

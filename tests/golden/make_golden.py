@@ -602,12 +602,76 @@ def golden_networks():
         save(name + ".npz", **out)
 
 
+# --------------------------------------------------------------------------------------------------------------
+# "next" rows of SURVEY 8(f): adaptive corrector, force-field augmentation, atom-type update recording
+# (appended after the first fixtures were committed; run with `python make_golden.py next` to write only these)
+# --------------------------------------------------------------------------------------------------------------
+def golden_next():
+    from diffusion_for_multi_scale_molecular_dynamics.generators.adaptive_corrector import AdaptiveCorrectorGenerator
+    from diffusion_for_multi_scale_molecular_dynamics.models.score_networks.force_field_augmented_score_network import (
+        ForceFieldAugmentedScoreNetwork, ForceFieldParameters)
+    import warnings
+
+    # adaptive corrector (generators/adaptive_corrector.py:17-148)
+    for name, kw, netf, B, seed in [
+        ("traj_adaptive_fake", dict(T=8, N=8, num_atom_types=2, M=2, noise_kw=dict(corrector_r=0.5)), None, 4, 41),
+        ("traj_adaptive_mlp", dict(T=10, N=8, num_atom_types=1, M=1,
+                                   noise_kw=dict(sigma_min=1e-3, sigma_max=0.2, schedule_type="linear")),
+         lambda: _mlp(8, 1), 5, 42),
+    ]:
+        net = netf() if netf else None
+        gen0, npar, spar = make_generator(record=True, net=net, **kw)
+        spar.algorithm = "adaptive_corrector"
+        gen = AdaptiveCorrectorGenerator(noise_parameters=npar, sampling_parameters=spar, axl_network=gen0.axl_network)
+        torch.manual_seed(seed)
+        with torch.no_grad(), DrawRecorder() as rec:
+            axl = gen.sample(B, torch.device("cpu"))
+        out = dict(final_A=_np(axl.A), final_X=_np(axl.X), final_L=_np(axl.L), batch=np.array(B))
+        out.update(rec.pack())
+        out.update(_pack_records(gen))
+        if net is not None:
+            out.update(_state_dict_np(net))
+        save(name + ".npz", **out)
+
+    # force-field augmented network (models/score_networks/force_field_augmented_score_network.py:44-236)
+    g = torch.Generator().manual_seed(606)
+    for name, N, cell, rc, strength in [("ff_n8", 8, 5.43, 1.5, 2.0), ("ff_n32", 32, 8.0, 2.2, 0.7)]:
+        B = 4
+        base = FakeAXLNetwork(ScoreNetworkParameters(architecture="dummy", spatial_dimension=3, num_atom_types=1))
+        ff = ForceFieldAugmentedScoreNetwork(base, ForceFieldParameters(radial_cutoff=rc, strength=strength))
+        batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.zeros(B, N, dtype=torch.long), X=torch.rand(B, N, 3, generator=g),
+                                            L=torch.tensor([cell, cell * 1.1, cell * 1.2, 0, 0, 0.0]).repeat(B, 1)),
+                 TIME: torch.rand(B, 1, generator=g), NOISE: torch.rand(B, 1, generator=g) * 0.2,
+                 CARTESIAN_FORCES: torch.zeros(B, N, 3)}
+        forces = ff.get_relative_coordinates_pseudo_force(batch)
+        out = ff(batch, conditional=False)
+        save(name + ".npz", X=_np(batch[NOISY_AXL_COMPOSITION].X), L=_np(batch[NOISY_AXL_COMPOSITION].L),
+             rc=np.array(rc), strength=np.array(strength), forces=_np(forces), out_X=_np(out.X))
+
+    # atom-type update recording (langevin_generator.py:325-335)
+    gen, npar, spar = make_generator(T=6, N=8, num_atom_types=2, M=1, record=True)
+    gen.record_atom_type_update = True
+    torch.manual_seed(43)
+    with torch.no_grad(), DrawRecorder() as rec:
+        axl = gen.sample(3, torch.device("cpu"))
+    entries = gen.sample_trajectory_recorder._internal_data["atom_type_update"]
+    out = dict(final_A=_np(axl.A), final_X=_np(axl.X), final_L=_np(axl.L), batch=np.array(3))
+    out.update(rec.pack())
+    for key in ("predicted_logits", "one_step_transition_probabilities", "gumbel_sample", "a_i", "a_im1"):
+        out["rec_" + key] = np.stack([_np(e[key]) for e in entries])
+    save("traj_record_atom_types.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    golden_schedules()
-    golden_p1_p3()
-    golden_p2()
-    golden_noisers()
-    golden_neighbors()
-    golden_trajectories()
-    golden_networks()
+    if len(sys.argv) > 1 and sys.argv[1] == "next":
+        golden_next()
+    else:
+        golden_schedules()
+        golden_p1_p3()
+        golden_p2()
+        golden_noisers()
+        golden_neighbors()
+        golden_trajectories()
+        golden_networks()
+        golden_next()

@@ -418,3 +418,79 @@ def test_fused_needs_mlp_and_device_rng(cuda):
     gen, *_ = _build("traj_mlp_c3", cases.TRAJECTORIES, cuda, fused_score_network=True)     # reference RNG
     with pytest.raises(MdxError, match="rng_mode='device'"):
         gen.sample(2, cuda)
+
+
+# -------------------------------------------------------------------------------------------------------------
+# SURVEY 8(f) "next" rows: adaptive corrector, force-field augmentation, atom-type update recording
+# -------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(cases.ADAPTIVE))
+def test_adaptive_corrector_against_golden_and_oracle(cuda, name):
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.adaptive_corrector import AdaptiveCorrectorGenerator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.instantiate_generator import instantiate_generator
+    P = _pkg()
+    g = load_golden(name + ".npz")
+    noise_kw, sampling_kw, netf = cases.ADAPTIVE[name]
+    npar, spar = P["Noise"](**noise_kw), P["Sampling"](**sampling_kw)
+    torch.manual_seed(1234)
+    net = nets.fake_net(spar.num_atom_types) if netf is None else nets.load_fixture_weights(netf(None), g)
+    import copy
+    net_cpu = copy.deepcopy(net)
+    gen = instantiate_generator(spar, npar, net.to(cuda), None)
+    assert type(gen) is AdaptiveCorrectorGenerator
+    gen.noise_source = _replayed(g)
+    with torch.no_grad():
+        out = _np(gen.sample(int(g["batch"]), cuda))
+    assert gen.noise_source.inner.exhausted()
+    assert np.array_equal(out.A, g["final_A"])
+    assert torus_rel_l2(out.X, g["final_X"]) < 1e-5
+    # device RNG against the oracle
+    spar2 = P["Sampling"](**dict(sampling_kw, rng_mode="device", seed=17))
+    gen2 = AdaptiveCorrectorGenerator(npar, spar2, net)
+    with torch.no_grad():
+        dev_out = _np(gen2.sample(6, cuda))
+    ora = RS.OracleAdaptiveCorrectorGenerator(npar, spar2, net_cpu, noise=RS.PhiloxNoise(17, 0)).sample(6)
+    assert np.array_equal(dev_out.A, ora.A)
+    assert torus_rel_l2(dev_out.X, ora.X) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["ff_n8", "ff_n32"])
+def test_force_field_against_golden(cuda, name):
+    from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.force_field_augmented_score_network import (
+        ForceFieldAugmentedScoreNetwork, ForceFieldParameters)
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
+                                                                              NOISY_AXL_COMPOSITION, TIME)
+    g = load_golden(name + ".npz")
+    B, N, _ = g["X"].shape
+    ff = ForceFieldAugmentedScoreNetwork(nets.fake_net(1).to(cuda), ForceFieldParameters(
+        radial_cutoff=float(g["rc"]), strength=float(g["strength"])))
+    batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.zeros(B, N, dtype=torch.long, device=cuda),
+                                        X=torch.from_numpy(g["X"]).to(cuda), L=torch.from_numpy(g["L"]).to(cuda)),
+             TIME: torch.zeros(B, 1, device=cuda), NOISE: torch.zeros(B, 1, device=cuda),
+             CARTESIAN_FORCES: torch.zeros(B, N, 3, device=cuda)}
+    forces = ff.get_relative_coordinates_pseudo_force(batch).cpu().numpy()
+    # per-atom sums of a few float32 terms in a different order than the reference's scatter_add: 1e-5 of the scale
+    assert np.abs(forces - g["forces"]).max() <= 1e-5 * np.abs(g["forces"]).max()
+    out = ff(batch, conditional=False)
+    assert np.abs(out.X.cpu().numpy() - g["out_X"]).max() <= 1e-5 * np.abs(g["out_X"]).max()
+
+
+def test_atom_type_update_recording(cuda):
+    P = _pkg()
+    g = load_golden("traj_record_atom_types.npz")
+    npar = P["Noise"](**cases.noise_ns(6))
+    spar = P["Sampling"](**cases.sampling_ns(8, 2), record_samples=True, record_atom_type_update=True)
+    gen = P["Langevin"](npar, spar, nets.fake_net(2).to(cuda))
+    gen.noise_source = _replayed(g)
+    with torch.no_grad():
+        out = _np(gen.sample(int(g["batch"]), cuda))
+    assert np.array_equal(out.A, g["final_A"])
+    rec = gen.sample_trajectory_recorder._internal_data["atom_type_update"]
+    assert len(rec) == len(g["rec_a_i"])
+    for k, e in enumerate(rec):
+        assert np.array_equal(e["a_i"].numpy(), g["rec_a_i"][k]) and np.array_equal(e["a_im1"].numpy(), g["rec_a_im1"][k])
+        # the Gumbel values are computed by torch on the HOST CPU like the reference's (langevin_generator.py:100-107);
+        # torch's CPU log differs in the last bit between hosts (AVX2 / AVX512 Sleef), hence a 2-ulp tolerance
+        np.testing.assert_allclose(e["gumbel_sample"].numpy(), g["rec_gumbel_sample"][k], rtol=3e-7, atol=1e-7)
+        assert np.array_equal(e["predicted_logits"].numpy(), g["rec_predicted_logits"][k])
+        from conftest import ulp_diff
+        assert ulp_diff(e["one_step_transition_probabilities"].numpy(), g["rec_one_step_transition_probabilities"][k]).max() <= 4

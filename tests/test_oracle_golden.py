@@ -233,3 +233,22 @@ def test_conditioning_of_reference_map(oracle):
         amplification[name] = torus_rel_l2(outs[1].X, outs[0].X)
     assert amplification["traj_mlp_c3"] < 1e-6 and amplification["traj_egnn_fc"] < 1e-6      # neutral maps
     assert 1e-4 < amplification["traj_mlp_c1"] < 5e-3                                       # expanding: ~7.7e-4
+
+
+@pytest.mark.parametrize("name", list(cases.ADAPTIVE))
+def test_adaptive_corrector_trajectories(oracle, name):
+    g = load_golden(name + ".npz")
+    noise_kw, sampling_kw, netf = cases.ADAPTIVE[name]
+    npar, spar = cases.as_objects(noise_kw, sampling_kw)
+    net = nets.fake_net(spar.num_atom_types) if netf is None else nets.load_fixture_weights(netf(None), g)
+    replay = RS.ReplayNoise(g)
+    gen = RS.OracleAdaptiveCorrectorGenerator(npar, spar, net, noise=replay)
+    gen.record = True
+    out = gen.sample(int(g["batch"]))
+    assert replay.exhausted()
+    assert np.array_equal(out.A, g["final_A"])
+    # the step size is a ratio of batch-mean norms: float32 reduction order differs from torch's (1e-7 relative)
+    assert torus_rel_l2(out.X, g["final_X"]) < 1e-5
+    for k, r in enumerate([r for r in gen.records if r[0] == "predictor"]):
+        assert np.array_equal(r[3].X, r[2].X)                                  # predictor leaves X untouched
+        assert np.array_equal(r[3].A, g["pred_composition_im1_A"][k])
