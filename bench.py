@@ -280,6 +280,9 @@ def main():
                     help="score-network forward: 'pytorch' (plugin API, any network) or 'fused' (MLP only: network "
                          "forward + update in one persistent HIP kernel); default: fused for MLP workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo (with ranks sharing a GPU) exists to rehearse the multi-rank control "
+                         "flow on a one-GPU box")
     args = ap.parse_args()
 
     w = WORKLOADS[args.workload]
@@ -288,12 +291,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py measures the GPU hot path: no GPU is visible (there is no CPU fallback)")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)      # RCCL over xGMI
+        else:
+            dist.init_process_group(backend="gloo")
+    coll = (lambda t: t) if args.backend == "nccl" else (lambda t: t.cpu())   # gloo rehearsal: collectives on host copies
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     batch = args.batch or w["batch"]
@@ -329,16 +336,17 @@ def main():
         comp = loop.composition
         gather_ms = 0.0
         if dist is not None:
-            outs = [torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=device) for t in comp]
+            parts = [coll(t.contiguous()) for t in comp]
+            outs = [torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in parts]
             barrier()
             g0 = time.perf_counter()
-            for o, t in zip(outs, comp):
-                dist.all_gather_into_tensor(o, t.contiguous())
+            for o, t in zip(outs, parts):
+                dist.all_gather_into_tensor(o, t)
             barrier()
             gather_ms = (time.perf_counter() - g0) * 1e3
         gen.check_status()
         if dist is not None:
-            t = torch.tensor([elapsed, gather_ms], dtype=torch.float64, device=device)
+            t = coll(torch.tensor([elapsed, gather_ms], dtype=torch.float64, device=device))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, gather_ms = float(t[0]), float(t[1])
         ms_per_step = elapsed * 1e3 / steps
