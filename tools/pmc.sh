@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes (one counter per pass, with --kernel-trace only) for the dominant kernel of a workload.
-# usage: bash scratch/pmc.sh <tag> <bench args...>
+# usage: bash tools/pmc.sh <tag> <bench args...>
 set -e
 cd /tmp && export TMPDIR=/tmp
 TAG=$1; shift
