@@ -275,3 +275,83 @@ def test_radius_graph_full_size_properties(K, cuda):
     assert torch.equal(rev, key)                                     # (i,j) present <=> (j,i) present
     assert bool((e[:, 0] // N == e[:, 1] // N).all())                # no edge crosses structures
     assert 20.0 < e.shape[0] / (B * N) < 30.0                        # ~25 neighbours per atom
+
+
+# -------------------------------------------------------------------------------------------------------------
+# edge cases and error behaviour of the C ABI
+# -------------------------------------------------------------------------------------------------------------
+def test_empty_batches_are_no_ops(K, cuda):
+    e3 = torch.empty(0, 8, 3, device=cuda)
+    assert K.relative_coordinates_update(e3, e3, e3, 0.1, 0.1, 0.1).shape == (0, 8, 3)
+    assert K.noise_relative_coordinates(e3, e3, 0.1).shape == (0, 8, 3)
+    a = torch.empty(0, 8, dtype=torch.int64, device=cuda)
+    q = torch.eye(2, device=cuda)
+    out = K.atom_types_update(torch.empty(0, 8, 2, device=cuda), a, q, q, q, torch.empty(0, 8, 2, device=cuda),
+                              torch.empty(0, 8, device=cuda), 1e-8, True, True)
+    assert out.shape == (0, 8)
+    g = K.radius_graph(torch.empty(0, 8, 3, device=cuda), torch.empty(0, 3, 3, device=cuda), 2.0, unique=True)
+    assert g["edges"].shape == (0, 2) and g["counts"].shape == (0, 8)
+    # a structure with no neighbour at all: E = 0 but B*N > 0
+    cart = torch.tensor([[[0.0, 0.0, 0.0], [5.0, 5.0, 5.0]]], device=cuda)
+    cell = (torch.eye(3, device=cuda) * 10.0).unsqueeze(0)
+    g = K.radius_graph(cart, cell, 1.0, unique=False)
+    assert g["edges"].shape == (0, 2) and int(g["counts"].sum()) == 0
+
+
+def test_limits_and_invalid_arguments_raise(K, oracle, cuda):
+    from diffusion_for_multi_scale_molecular_dynamics_amd._hip import MdxError
+    B, N = 2, 4
+    # C = 8 is the largest class count of the fused kernels; it must work and match the oracle
+    C = 8
+    rng = np.random.default_rng(8)
+    sched = oracle.noise_schedule(10, num_classes=C)
+    logits = rng.standard_normal((B, N, C)).astype(np.float32)
+    logits[..., -1] = -np.inf
+    a = rng.integers(0, C, (B, N))
+    gum = rng.standard_normal((B, N, C)).astype(np.float32)
+    u = rng.random((B, N), dtype=np.float32)
+    args = [logits, a, sched["q_matrix"][3], sched["q_bar_matrix"][3], sched["q_bar_tm1_matrix"][3], gum, u]
+    got = K.atom_types_update(*[dev(t, cuda) for t in args], 1e-8, True, True)
+    assert np.array_equal(got.cpu().numpy(), oracle.atom_types_update(*args, 1e-8, True, True))
+    # C = 9: unsupported, reported through the status code (no abort, no exception inside the library)
+    C = 9
+    q9 = torch.eye(C, device=cuda)
+    with pytest.raises(MdxError, match="unsupported"):
+        K.atom_types_update(torch.zeros(B, N, C, device=cuda), torch.zeros(B, N, dtype=torch.int64, device=cuda), q9, q9,
+                            q9, torch.zeros(B, N, C, device=cuda), torch.zeros(B, N, device=cuda), 1e-8, True, True)
+    with pytest.raises(MdxError, match="unsupported"):       # structure tile larger than the LDS budget
+        K.radius_graph(torch.zeros(1, 5001, 3, device=cuda), torch.eye(3, device=cuda).unsqueeze(0) * 50, 1.0, unique=True)
+    with pytest.raises(MdxError, match="invalid argument"):   # non-positive cutoff (neighbors.py:101)
+        K.radius_graph(torch.zeros(1, 4, 3, device=cuda), torch.eye(3, device=cuda).unsqueeze(0), 0.0, unique=True)
+    with pytest.raises(MdxError, match="invalid argument"):   # T = 1 schedule
+        K.noise_schedule_build(1, "linear", 1e-5, 1e-3, 0.5, 2e-5, 2, cuda)
+    s = K.noise_schedule_build(5, "linear", 1e-5, 1e-3, 0.5, 2e-5, 2, cuda)
+    t = torch.empty(3, 1, device=cuda)
+    with pytest.raises(MdxError, match="invalid argument"):   # predictor index outside 1..T
+        K.fill_time_sigma(s, 0, 6, None, t, t.clone())
+    with pytest.raises(MdxError, match="invalid argument"):   # corrector index outside 0..T-1
+        K.fill_time_sigma(s, 1, 5, None, t, t.clone())
+    with pytest.raises(TypeError):                            # wrong dtype is caught before the ABI
+        K.relative_coordinates_update(torch.zeros(4, device=cuda, dtype=torch.float64),
+                                      torch.zeros(4, device=cuda), torch.zeros(4, device=cuda), 0.1, 0.1, 0.1)
+    with pytest.raises(ValueError):                           # non-contiguous view
+        x = torch.zeros(4, 6, device=cuda)[:, ::2]
+        K.relative_coordinates_update(x, x, x, 0.1, 0.1, 0.1)
+
+
+def test_corrector_index_zero_uses_sigma_min_and_time_zero(K, oracle, cuda):
+    """langevin_generator.py:719-725: the last corrector extrapolates to t = 0, sigma = sigma_min."""
+    s = K.noise_schedule_build(10, "exponential", 1e-5, 0.005, 0.5, 2e-5, 2, cuda)
+    t, sg = torch.empty(4, 1, device=cuda), torch.empty(4, 1, device=cuda)
+    K.fill_time_sigma(s, 1, 0, None, t, sg)
+    assert float(t[0]) == 0.0 and float(sg[0]) == np.float32(0.005)
+    K.fill_time_sigma(s, 1, 3, None, t, sg)
+    assert float(t[0]) == float(s.time[2]) and float(sg[0]) == float(s.sigma[2])
+    K.fill_time_sigma(s, 0, 3, None, t, sg)
+    assert float(t[0]) == float(s.time[2])
+    d_index = torch.tensor([2], dtype=torch.int32, device=cuda)       # device-resident index + by-value offset
+    K.fill_time_sigma(s, 0, 1, d_index, t, sg)
+    assert float(t[0]) == float(s.time[2])
+    K.index_add(d_index, -1)
+    K.fill_time_sigma(s, 0, 1, d_index, t, sg)
+    assert float(t[0]) == float(s.time[1])
