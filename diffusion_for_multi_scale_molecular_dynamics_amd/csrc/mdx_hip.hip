@@ -487,9 +487,13 @@ __device__ __forceinline__ const float* off(const float* p, int64_t o) { return 
 __device__ __forceinline__ float* off(float* p, int64_t o) { return p ? p + o : nullptr; }
 
 // G lanes cooperate on one structure; a 64-lane wavefront carries 64/G structures.
-template <int G>
-__global__ __launch_bounds__(kBlock) void pc_step_kernel(PcArgs p)
+// CSPEC > 0: number of classes (and d = 3) substituted as literals -- the class loops unroll to exactly C bodies and
+// the per-atom index arithmetic folds; CSPEC = 0 is the generic instantiation.  Same code, same arithmetic.
+template <int G, int CSPEC>
+__global__ __launch_bounds__(kBlock) void pc_step_kernel(PcArgs p_in)
 {
+    PcArgs p = p_in;
+    if constexpr (CSPEC > 0) { p.C = CSPEC; p.d = 3; p.nl = 6; }
     const int lane = threadIdx.x & (G - 1);
     const int64_t groups_per_grid = ((int64_t)gridDim.x * blockDim.x) / G;
     const int64_t group0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
@@ -521,15 +525,21 @@ int launch_pc(const PcArgs& a, hipStream_t st)
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     dim3 grid((unsigned)blocks), block(kBlock);
+    const int cspec = (a.d == 3 && (a.C == 2 || a.C == 3)) ? a.C : 0;
+#define MDX_LAUNCH_PC(GG)                                                                                   \
+    if (cspec == 2) hipLaunchKernelGGL((pc_step_kernel<GG, 2>), grid, block, 0, st, a);                       \
+    else if (cspec == 3) hipLaunchKernelGGL((pc_step_kernel<GG, 3>), grid, block, 0, st, a);                  \
+    else hipLaunchKernelGGL((pc_step_kernel<GG, 0>), grid, block, 0, st, a);
     switch (G) {
-        case 1: hipLaunchKernelGGL(pc_step_kernel<1>, grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(pc_step_kernel<2>, grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL(pc_step_kernel<4>, grid, block, 0, st, a); break;
-        case 8: hipLaunchKernelGGL(pc_step_kernel<8>, grid, block, 0, st, a); break;
-        case 16: hipLaunchKernelGGL(pc_step_kernel<16>, grid, block, 0, st, a); break;
-        case 32: hipLaunchKernelGGL(pc_step_kernel<32>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(pc_step_kernel<64>, grid, block, 0, st, a); break;
+        case 1: MDX_LAUNCH_PC(1) break;
+        case 2: MDX_LAUNCH_PC(2) break;
+        case 4: MDX_LAUNCH_PC(4) break;
+        case 8: MDX_LAUNCH_PC(8) break;
+        case 16: MDX_LAUNCH_PC(16) break;
+        case 32: MDX_LAUNCH_PC(32) break;
+        default: MDX_LAUNCH_PC(64) break;
     }
+#undef MDX_LAUNCH_PC
     return launch_status();
 }
 
