@@ -779,6 +779,87 @@ __device__ __forceinline__ void mlp_forward_wave(const mdx_mlp_t& m, const W& w,
     wave_sync();
 }
 
+// ---- template-MLP specialisation: every layer's weights live in the lane's registers for the whole trajectory ----
+// (one wavefront per SIMD, so the full 512-register file is available; 79 float4 = 316 VGPRs per lane)
+struct MlpRegs {
+    lds_f4 wc[12], wh0[19], wh1[16], wh2[16], wo[16];      // [k/4] quads of the lane's neuron: 48, 73(+3), 64, 64, 64 inputs
+    float bc, bh0, bh1, bh2, bo;
+};
+
+__device__ __forceinline__ void load_mlp_regs(MlpRegs& R, const MlpWeightsLds& w, int lane)
+{
+    const lds_f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < 12; ++q) R.wc[q] = lane < 32 ? ((lds_cf4*)w.wc)[q * 32 + lane] : zero;
+#pragma unroll
+    for (int q = 0; q < 19; ++q) R.wh0[q] = ((lds_cf4*)w.wh(0))[q * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) R.wh1[q] = ((lds_cf4*)w.wh(1))[q * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) R.wh2[q] = ((lds_cf4*)w.wh(2))[q * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) R.wo[q] = lane < 46 ? ((lds_cf4*)w.woa)[q * 46 + lane] : zero;
+    R.bc = lane < 32 ? w.bc[lane] : 0.0f;
+    R.bh0 = w.bh(0)[lane]; R.bh1 = w.bh(1)[lane]; R.bh2 = w.bh(2)[lane];
+    R.bo = lane < 46 ? w.boa[lane] : 0.0f;
+}
+
+// same partial sums and the same final ((s0+s1)+(s2+s3))+bias as linear_wave<true>
+template <int KQ>
+__device__ __forceinline__ float dot_regs(const lds_f4 (&wq)[KQ], lds_cf* in, float bias)
+{
+    lds_cf4* in4 = (lds_cf4*)in;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        const lds_f4 v = in4[q];
+        s0 = __builtin_fmaf(wq[q].x, v.x, s0);
+        s1 = __builtin_fmaf(wq[q].y, v.y, s1);
+        s2 = __builtin_fmaf(wq[q].z, v.z, s2);
+        s3 = __builtin_fmaf(wq[q].w, v.w, s3);
+    }
+    return ((s0 + s1) + (s2 + s3)) + bias;
+}
+
+__device__ __forceinline__ float silu_(float a) { return a / (1.0f + expf_(-a)); }
+
+// mlp_forward_wave for the template dimensions (N 8, d 3, C 2, embeddings 32/16/16/1/1, hidden 64 x 3)
+__device__ __forceinline__ void mlp_forward_regs(const MlpWeightsLds& w, const MlpRegs& R, int lane, lds_cf* x, lds_ci64* a,
+                                                 lds_cf* l, float time, float sigma, lds_f* buf_a, lds_f* buf_b,
+                                                 lds_f* logits)
+{
+    if (lane < 24) {
+        float sn, cs;
+        sincospif_(2.0f * x[lane], sn, cs);
+        buf_a[lane] = cs;
+        buf_a[24 + lane] = sn;
+    }
+    wave_sync();
+    if (lane < 32) buf_b[lane] = dot_regs<12>(R.wc, buf_a, R.bc);
+    else if (lane < 48) buf_b[lane] = __builtin_fmaf(w.wn[lane - 32], sigma, w.bn[lane - 32]);
+    else buf_b[lane] = __builtin_fmaf(w.wt[lane - 48], time, w.bt[lane - 48]);
+    if (lane < 8) buf_b[64 + lane] = w.wa[(int)a[lane]] + w.ba[0];
+    if (lane == 8) {
+        float acc = w.bl[0];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc = __builtin_fmaf(w.wl[k], l[k], acc);
+        buf_b[72] = acc;
+    }
+    if (lane >= 9 && lane < 12) buf_b[64 + lane] = 0.0f;        // zero padding of the 73-wide input up to 76
+    wave_sync();
+    buf_a[lane] = silu_(dot_regs<19>(R.wh0, buf_b, R.bh0));
+    wave_sync();
+    buf_b[lane] = silu_(dot_regs<16>(R.wh1, buf_a, R.bh1));
+    wave_sync();
+    buf_a[lane] = dot_regs<16>(R.wh2, buf_b, R.bh2);
+    wave_sync();
+    if (lane < 46) {                                            // logits (16) | score_x (24) | score_l (6), contiguous
+        const float o = dot_regs<16>(R.wo, buf_a, R.bo);
+        logits[lane] = (lane < 16 && (lane & 1)) ? -__builtin_huge_valf() : o;
+    }
+    wave_sync();
+}
+
 __host__ __device__ inline int mlp_scratch_floats(const mdx_mlp_t& m)
 {
     const int N = m.number_of_atoms, d = m.spatial_dimension;
@@ -899,6 +980,8 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     auto run = [&](const auto& w, lds_f* scratch) {
         const MlpWaveLds r = carve_wave_lds(m, scratch + wave * mlp_wave_floats(m));
+        [[maybe_unused]] MlpRegs regs;
+        if constexpr (SPEC == 1 && LDS_WEIGHTS) load_mlp_regs(regs, w, lane);
         for (int64_t b = (int64_t)blockIdx.x * kMlpWaves + wave; b < p.pc.B; b += (int64_t)gridDim.x * kMlpWaves) {
             for (int e = lane; e < N; e += kWave) r.a[e] = p.a[b * N + e];
             for (int e = lane; e < N * d; e += kWave) r.x[e] = p.x[b * N * d + e];
@@ -916,9 +999,13 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
                 for (int sub = 0; sub <= p.M; ++sub) {
                     const int mode = sub == 0 ? MDX_PREDICTOR : MDX_CORRECTOR;
                     const PcStep st = make_step(p.pc, mode, sub == 0 ? i + 1 : i, (uint32_t)sub);
-                    if (!(p.diag_skip & 1))
-                        mlp_forward_wave<LDS_WEIGHTS>(m, w, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b,
-                                                      r.logits, r.sx, r.sl);
+                    if (!(p.diag_skip & 1)) {
+                        if constexpr (SPEC == 1 && LDS_WEIGHTS)
+                            mlp_forward_regs(w, regs, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b, r.logits);
+                        else
+                            mlp_forward_wave<LDS_WEIGHTS>(m, w, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a,
+                                                          r.buf_b, r.logits, r.sx, r.sl);
+                    }
                     if (lane < G && !(p.diag_skip & 2))
                         pc_update_structure<G>(p.pc, st, v, lane, sub == 0 ? 1 : p.types_in_corrector);
                     wave_sync();
