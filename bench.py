@@ -364,7 +364,9 @@ def main():
             traffic = None          # HBM bytes per launch measured with PMC counters in a separate rocprofv3 pass
             try:
                 table = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-                traffic = table[m["kernel"].split()[0].split("<")[0]]["bytes_per_launch"]
+                entry = table[f"{args.workload}/{forward}"]
+                if entry["kernel"] == m["kernel"].split()[0].split("<")[0] and batch == w["batch"]:
+                    traffic = entry["bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 pass
             roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",

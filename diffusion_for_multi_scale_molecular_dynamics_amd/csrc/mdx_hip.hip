@@ -440,14 +440,23 @@ __device__ __forceinline__ void pc_update_structure(const PcArgs& p, const PcSte
                 box_muller(r.v[0], r.v[1], z0, z1);
                 if (d > 2) box_muller(r.v[2], r.v[3], z2, z3);
             }
+            // all loads first, then the three stores back to back (adjacent addresses -> one 12-byte store when d = 3)
+            float xin[3], sin_[3], out[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k)
                 if (k < d) {
                     const int e = n * d + k;
                     const float zk = k == 0 ? z0 : (k == 1 ? z1 : z2);
-                    const float zz = v.z_coord ? v.z_coord[e] : zk;
-                    v.x_out[e] = coord_update(v.x[e], v.score_x[e], zz, sc.w, sc.n, sc.sigma);
+                    xin[k] = v.x[e];
+                    sin_[k] = v.score_x[e];
+                    out[k] = v.z_coord ? v.z_coord[e] : zk;
                 }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < d) out[k] = coord_update(xin[k], sin_[k], out[k], sc.w, sc.n, sc.sigma);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < d) v.x_out[n * d + k] = out[k];
         }
     }
     if (update_types && one) {
