@@ -1204,7 +1204,9 @@ __global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __res
                 if (0.0f < d2 && d2 <= rc2) mask = (1u << ((nx + 1) * 9 + (ny + 1) * 3 + (nz + 1)));
             } else if (j < N) {
                 const float pjx = pos[3 * j], pjy = pos[3 * j + 1], pjz = pos[3 * j + 2];
-#pragma unroll
+                // not unrolled: a full unroll hoists the 81 image-vector components into registers (113 VGPRs, half
+                // the occupancy) for the benefit of the rare triclinic path
+#pragma nounroll
                 for (int l = 0; l < 27; ++l) {
                     const float sx = pjx + lv[3 * l], sy = pjy + lv[3 * l + 1], sz = pjz + lv[3 * l + 2];
                     const float dx = pix - sx, dy = piy - sy, dz = piz - sz;

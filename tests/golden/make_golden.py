@@ -662,11 +662,34 @@ def golden_next():
     save("traj_record_atom_types.npz", **out)
 
 
+
+
+def golden_distances():
+    """utils/structure_utils.py:41-121 (pymatgen is only imported by that module for an unrelated helper: stubbed)."""
+    pm = types.ModuleType("pymatgen")
+    pmc = types.ModuleType("pymatgen.core")
+    pmc.Lattice = object
+    pmc.Structure = object
+    pm.core = pmc
+    sys.modules["pymatgen"] = pm
+    sys.modules["pymatgen.core"] = pmc
+    from diffusion_for_multi_scale_molecular_dynamics.utils.structure_utils import compute_distances_in_batch
+    g = torch.Generator().manual_seed(707)
+    out = {}
+    for name, B, N, box, rc in (("d8", 3, 8, 5.43, 4.0), ("d64", 2, 64, 10.86, 5.0)):
+        X = torch.rand(B, N, 3, generator=g)
+        cell = torch.diag(torch.tensor([box, box * 1.05, box * 1.1])).repeat(B, 1, 1)
+        cart = torch.matmul(X, cell)
+        dist = compute_distances_in_batch(cart, cell, rc)
+        out[f"{name}/cart"], out[f"{name}/cell"], out[f"{name}/rc"] = _np(cart), _np(cell), np.array(rc)
+        out[f"{name}/distances_sorted"] = np.sort(_np(dist))
+    save("distances.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    if len(sys.argv) > 1 and sys.argv[1] == "next":
-        golden_next()
-    else:
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all",):
         golden_schedules()
         golden_p1_p3()
         golden_p2()
@@ -674,4 +697,7 @@ if __name__ == "__main__":
         golden_neighbors()
         golden_trajectories()
         golden_networks()
+    if which in ("all", "next"):
         golden_next()
+    if which in ("all", "distances"):
+        golden_distances()

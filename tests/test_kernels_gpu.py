@@ -4,6 +4,8 @@ Bar: bit-exact for integer outputs (atom types, edges, counts) AND for float out
 execute the same IEEE operation sequence ("MDX arithmetic"), so equality is by construction; where a test compares
 against the reference's golden vectors instead, the tolerance is written at the assert.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -355,3 +357,35 @@ def test_corrector_index_zero_uses_sigma_min_and_time_zero(K, oracle, cuda):
     K.index_add(d_index, -1)
     K.fill_time_sigma(s, 0, 1, d_index, t, sg)
     assert float(t[0]) == float(s.time[1])
+
+
+def test_compute_distances_in_batch_against_golden(cuda):
+    from diffusion_for_multi_scale_molecular_dynamics_amd.utils.structure_utils import compute_distances_in_batch
+    g = load_golden("distances.npz")
+    for name in ("d8", "d64"):
+        got = compute_distances_in_batch(dev(g[f"{name}/cart"], cuda), dev(g[f"{name}/cell"], cuda), float(g[f"{name}/rc"]))
+        got = np.sort(got.cpu().numpy())
+        want = g[f"{name}/distances_sorted"]
+        assert got.shape == want.shape          # same number of (pair, image) entries within the cutoff
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+
+
+def test_bench_contract(cuda):
+    """bench.py prints ONE JSON line with the contract's keys (tiny run: 20 steps of the default workload)."""
+    import json
+    import subprocess
+    import sys as _sys
+    from conftest import ROOT
+    out = subprocess.run([_sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0 and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("C2") and d["scaling"] == "weak" and d["dtype"] == "f32"
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
