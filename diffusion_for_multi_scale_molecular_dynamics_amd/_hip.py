@@ -25,7 +25,8 @@ ABI_SYMBOLS = (
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
     "mdx_repaint_constrained_rows", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_mlp_forward",
-    "mdx_mlp_pc_sample", "mdx_rng_fill", "mdx_math_probe",
+    "mdx_mlp_pc_sample", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input",
+    "mdx_rng_fill", "mdx_math_probe",
 )
 MLP_MAX_HIDDEN = 8
 
@@ -132,6 +133,14 @@ def _declare(L):
     L.mdx_mlp_pc_sample.restype = i32
     L.mdx_mlp_pc_sample.argtypes = [C.POINTER(Schedule), C.POINTER(Mlp), C.POINTER(PcFlags), i32, i32, i32, i32, Rng, i64,
                                     vp, vp, vp, vp, vp]
+    L.mdx_blas_create.restype = i32
+    L.mdx_blas_create.argtypes = [C.POINTER(vp)]
+    L.mdx_blas_destroy.restype = i32
+    L.mdx_blas_destroy.argtypes = [vp]
+    L.mdx_linear_act.restype = i32
+    L.mdx_linear_act.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, u64, vp]
+    L.mdx_egnn_message_input.restype = i32
+    L.mdx_egnn_message_input.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]
     L.mdx_rng_fill.restype = i32
     L.mdx_rng_fill.argtypes = [i32, u64, u32, u32, u32, i64, i32, vp, vp]
     L.mdx_math_probe.restype = i32

@@ -295,6 +295,63 @@ def mlp_pc_sample(sched: DeviceSchedule, pack: MlpPack, flags: PcFlags, number_o
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# EGNN helpers: library GEMM with fused bias(+SiLU) epilogue, fused first message layer
+# ----------------------------------------------------------------------------------------------------------------
+class BlasContext:
+    """A hipBLASLt context (mdx_blas_t) + its workspace, one per device; owned here, destroyed with the object."""
+
+    WORKSPACE_BYTES = 64 << 20
+    _by_device = {}
+
+    def __init__(self, device):
+        handle = C.c_void_p()
+        check(lib().mdx_blas_create(C.byref(handle)), "mdx_blas_create")
+        self.handle = handle
+        self.workspace = torch.empty(self.WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        self.silu_epilogue_ok = True      # cleared the first time the library reports no SWISH_BIAS kernel
+
+    def __del__(self):
+        try:
+            lib().mdx_blas_destroy(self.handle)
+        except Exception:
+            pass
+
+    @classmethod
+    def get(cls, device):
+        device = torch.device(device)
+        if device not in cls._by_device:
+            with torch.cuda.device(device):
+                cls._by_device[device] = cls(device)
+        return cls._by_device[device]
+
+
+def linear_act(x: torch.Tensor, weight: torch.Tensor, bias, silu: bool) -> torch.Tensor:
+    """act(x @ weight.T + bias) as one hipBLASLt matmul with the BIAS / SWISH_BIAS epilogue (mdx_linear_act)."""
+    ctx = BlasContext.get(x.device)
+    M, K = x.shape
+    N = weight.shape[0]
+    out = torch.empty(M, N, dtype=F32, device=x.device)
+    rc = lib().mdx_linear_act(ctx.handle, ptr(x, F32, "x"), ptr(weight, F32, "weight"), ptr(bias, F32, "bias"),
+                              ptr(out, F32, "out"), M, K, N, int(bool(silu)), C.c_void_p(ctx.workspace.data_ptr()),
+                              ctx.workspace.numel(), stream_handle())
+    check(rc, "mdx_linear_act")
+    return out
+
+
+def egnn_message_input(node_proj, edges, radial, bias, w_radial, silu: bool = True) -> torch.Tensor:
+    """First message layer on an edge list: SiLU(P[src,:H] + P[dst,H:] + b + r w_r)  (mdx_egnn_message_input)."""
+    E = edges.shape[0]
+    H = bias.shape[0]
+    assert node_proj.shape[1] == 2 * H and radial.numel() == E
+    out = torch.empty(E, H, dtype=F32, device=node_proj.device)
+    rc = lib().mdx_egnn_message_input(ptr(node_proj, F32, "node_proj"), ptr(edges, I64, "edges"),
+                                      ptr(radial, F32, "radial"), ptr(bias, F32, "bias"), ptr(w_radial, F32, "w_radial"),
+                                      E, H, int(bool(silu)), ptr(out, F32, "out"), stream_handle())
+    check(rc, "mdx_egnn_message_input")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # RNG fills / probes
 # ----------------------------------------------------------------------------------------------------------------
 RNG_UNIFORM, RNG_NORMAL, RNG_GUMBEL = 0, 1, 2

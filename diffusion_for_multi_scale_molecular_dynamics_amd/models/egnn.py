@@ -16,6 +16,29 @@ from torch import nn
 from ..namespace import AXL
 
 
+def run_mlp(layers, x: torch.Tensor, fused: bool) -> torch.Tensor:
+    """Apply a Sequential of Linear / SiLU / ... modules.  With `fused` (device tensors) every Linear, together with a
+    SiLU that follows it, is ONE library matmul with a bias(+SiLU) epilogue (kernels.linear_act) instead of a matmul
+    plus a read+write pass over the activations."""
+    layers = list(layers)
+    if not fused:
+        for layer in layers:
+            x = layer(x)
+        return x
+    from .. import kernels
+    k = 0
+    while k < len(layers):
+        layer = layers[k]
+        if isinstance(layer, nn.Linear) and layer.out_features > 1:
+            with_silu = k + 1 < len(layers) and isinstance(layers[k + 1], nn.SiLU)
+            x = kernels.linear_act(x.contiguous(), layer.weight, layer.bias, with_silu)
+            k += 2 if with_silu else 1
+        else:
+            x = layer(x)
+            k += 1
+    return x
+
+
 def segment_sum_sorted(data: torch.Tensor, degree: torch.Tensor) -> torch.Tensor:
     """Sum rows of `data` over consecutive segments of lengths `degree` (edges sorted by source node).
 
@@ -41,6 +64,7 @@ class E_GCL(nn.Module):
         self.message_mean = message_agg == "mean"
         self.epsilon = 1e-8
         self.input_size = input_size
+        self.use_fused_ops = True        # device tensors only; the CPU path is plain PyTorch
 
         mh, nh, ch = message_hidden_dimensions_size, node_hidden_dimensions_size, coordinate_hidden_dimensions_size
         layers = [nn.Linear(2 * input_size + 1, mh), act_fn]
@@ -65,18 +89,24 @@ class E_GCL(nn.Module):
         if attention:
             self.att_mlp = nn.Sequential(nn.Linear(mh, 1), nn.Sigmoid())
 
-    def _messages(self, h: torch.Tensor, row: torch.Tensor, col: torch.Tensor, radial: torch.Tensor) -> torch.Tensor:
+    def _messages(self, h: torch.Tensor, edge_index: torch.Tensor, radial: torch.Tensor, fused: bool) -> torch.Tensor:
         first = self.message_mlp[0]
         n_in = self.input_size
         w = first.weight
-        # node-level projections, gathered per edge
-        proj = torch.nn.functional.linear(h, torch.cat([w[:, :n_in], w[:, n_in:2 * n_in]], dim=0))
         mh = w.shape[0]
-        pre = proj[:, :mh].index_select(0, row) + proj[:, mh:].index_select(0, col)
-        pre = torch.addcmul(pre + first.bias, radial, w[:, 2 * n_in].unsqueeze(0))
-        out = pre
-        for layer in list(self.message_mlp)[1:]:
-            out = layer(out)
+        # node-level projections h W_src^T | h W_dst^T, combined per edge
+        proj = torch.nn.functional.linear(h, torch.cat([w[:, :n_in], w[:, n_in:2 * n_in]], dim=0))
+        rest = list(self.message_mlp)[1:]
+        if fused and mh % 4 == 0 and isinstance(rest[0], nn.SiLU):
+            from .. import kernels
+            out = kernels.egnn_message_input(proj.contiguous(), edge_index, radial.reshape(-1).contiguous(), first.bias,
+                                             w[:, 2 * n_in].contiguous(), silu=True)
+            rest = rest[1:]
+        else:
+            row, col = edge_index[:, 0], edge_index[:, 1]
+            pre = proj[:, :mh].index_select(0, row) + proj[:, mh:].index_select(0, col)
+            out = torch.addcmul(pre + first.bias, radial, w[:, 2 * n_in].unsqueeze(0))
+        out = run_mlp(rest, out, fused)
         if self.attention:
             out = out * self.att_mlp(out)
         return out
@@ -94,15 +124,16 @@ class E_GCL(nn.Module):
         if self.normalize:
             coord_diff = torch.tanh(radial) / torch.sqrt(radial + self.epsilon ** 2) * coord_diff
 
-        messages = self._messages(h, row, col, radial)
+        fused = self.use_fused_ops and h.is_cuda
+        messages = self._messages(h, edge_index, radial, fused)
 
-        trans = segment_sum_sorted(coord_diff * self.coord_mlp(messages), degree)
+        trans = segment_sum_sorted(coord_diff * run_mlp(self.coord_mlp, messages, fused), degree)
         coord = coord + (trans * inv_deg if self.coords_mean else trans)
 
         agg = segment_sum_sorted(messages, degree)
         if self.message_mean:
             agg = agg * inv_deg
-        out = self.node_mlp(torch.cat([h, agg], dim=1))
+        out = run_mlp(self.node_mlp, torch.cat([h, agg], dim=1), fused)
         if self.residual:
             out = h + out
         return out, coord

@@ -232,6 +232,26 @@ MDX_API int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t*
                               int64_t batch, int64_t* atom_types, float* x, float* l, uint32_t* status,
                               mdx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * EGNN score network helpers (the forward stays a PyTorch module; these remove passes PyTorch cannot fuse).
+ * mdx_blas_t is an opaque handle around a hipBLASLt context, owned by the caller (create once per device/thread). */
+typedef struct mdx_blas_handle* mdx_blas_t;
+MDX_API int mdx_blas_create(mdx_blas_t* handle_out);
+MDX_API int mdx_blas_destroy(mdx_blas_t handle);
+
+/* out[M,N] = act(x[M,K] . w[N,K]^T + bias[N]) -- nn.Linear (+ nn.SiLU) of the EGNN MLPs (models/egnn.py:85-131) as one
+ * hipBLASLt fp32 matmul with the BIAS / SWISH_BIAS epilogue.  w in nn.Linear layout; bias nullable; act 0 none, 1 SiLU.
+ * workspace: caller-owned device scratch for the library.  MDX_ERR_UNSUPPORTED when the library has no such kernel. */
+MDX_API int mdx_linear_act(mdx_blas_t handle, const float* x, const float* w, const float* bias, float* out, int64_t M,
+                           int K, int N, int act, void* workspace, uint64_t workspace_bytes, mdx_stream_t stream);
+
+/* First layer of E_GCL.message_model (models/egnn.py:136-160) on an edge list [E,2] of node indices:
+ * out[e,:] = act(node_proj[src_e, :H] + node_proj[dst_e, H:] + bias + radial[e] * w_radial), node_proj [n_nodes, 2H] being
+ * the per-node projections h W_src^T | h W_dst^T of the layer's weight.  H % 4 == 0. */
+MDX_API int mdx_egnn_message_input(const float* node_proj, const int64_t* edges, const float* radial, const float* bias,
+                                   const float* w_radial, int64_t n_edges, int H, int silu, float* out,
+                                   mdx_stream_t stream);
+
 /* Device-RNG draws as stand-alone fills (trajectory initialisation, tests of the RNG specification).
  * kind 0 = uniform (0,1), 1 = standard normal, 2 = Gumbel(0,1).  out [n_items, width]. */
 MDX_API int mdx_rng_fill(int kind, uint64_t seed, uint32_t call, uint32_t draw, uint32_t tag, int64_t n_items, int width,
