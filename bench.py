@@ -122,16 +122,34 @@ class FusedLoop:
     def __init__(self, gen, start, starting_step_index):
         self.gen = gen
         self.composition = type(start)(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
-        self.remaining = starting_step_index
+        self.remaining = self.total = starting_step_index
         self.sched = gen._prepare(start.X.device)
         self.pack = gen.fused_pack(start.X.device)
 
     def advance(self, iterations):
         g, c = self.gen, self.composition
-        kernels.mlp_pc_sample(self.sched, self.pack, g._flags(True), g.number_of_corrector_steps,
-                              g.atom_type_transition_in_corrector, self.remaining, iterations, g._rng(0), c.A, c.X, c.L,
-                              g._status)
-        self.remaining -= iterations
+        while iterations > 0:        # more steps than the trajectory has: start another trajectory on the same buffers
+            n = min(iterations, self.remaining)
+            kernels.mlp_pc_sample(self.sched, self.pack, g._flags(True), g.number_of_corrector_steps,
+                                  g.atom_type_transition_in_corrector, self.remaining, n, g._rng(0), c.A, c.X, c.L,
+                                  g._status)
+            iterations -= n
+            self.remaining -= n
+            if self.remaining == 0:
+                self.remaining = self.total
+
+
+def advance(loop, iterations, total):
+    """loop.advance with wrap-around: a run longer than the trajectory continues with a fresh time index."""
+    if isinstance(loop, FusedLoop):
+        return loop.advance(iterations)
+    while iterations > 0:
+        n = min(iterations, loop.remaining)
+        loop.advance(n)
+        iterations -= n
+        if loop.remaining == 0:
+            kernels.index_set(loop.d_index, total - 1)
+            loop.remaining = total
 
 
 def time_fused_kernel(gen, loop, batch, w, device, iterations=100):
@@ -311,7 +329,6 @@ def main():
     forward = args.forward or ("fused" if mlp else "pytorch")
     assert forward == "pytorch" or mlp, "the fused forward exists for the MLP score network only"
     use_graph = w["graph"] and not args.no_graph and forward == "pytorch"
-    assert steps + warmup <= T
 
     gen, noise, sampling, net = build_generator(w, device, rank, batch, use_graph)
     gen.fused_score_network = forward == "fused"
@@ -326,10 +343,10 @@ def main():
         gen._begin_call(device)                      # Philox seed = BASE_SEED + rank
         start = gen.initialize(batch, device)
         loop = FusedLoop(gen, start, T) if forward == "fused" else IterationLoop(gen, start, T, use_graph=use_graph)
-        loop.advance(warmup)
+        advance(loop, warmup, T)
         barrier()
         t0 = time.perf_counter()
-        loop.advance(steps)
+        advance(loop, steps, T)
         barrier()
         elapsed = time.perf_counter() - t0
         # the single collective of the job: gather of the final compositions
