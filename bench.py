@@ -334,9 +334,16 @@ def main():
     gen.fused_score_network = forward == "fused"
 
     def barrier():
+        """dist.barrier + torch.cuda.synchronize.  The GPU is first awaited by polling an event: a blocking synchronize
+        wakes the host tens of microseconds late, which matters when K steps take ~100 us."""
+        done = torch.cuda.Event()
+        done.record()
+        while not done.query():
+            pass
+        torch.cuda.synchronize(device)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(device)
+            torch.cuda.synchronize(device)
 
     with torch.no_grad():
         gen._prepare(device)

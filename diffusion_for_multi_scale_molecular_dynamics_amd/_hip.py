@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
     "mdx_repaint_constrained_rows", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_mlp_forward",
-    "mdx_mlp_pc_sample", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input",
+    "mdx_mlp_pc_sample", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input",
     "mdx_rng_fill", "mdx_math_probe",
 )
 MLP_MAX_HIDDEN = 8
@@ -63,7 +63,8 @@ class Mlp(C.Structure):
         [(n, C.c_void_p) for n in ("w_coordinates_t", "b_coordinates", "w_noise_t", "b_noise", "w_time_t", "b_time",
                                    "w_atom_type_t", "b_atom_type", "w_lattice_t", "b_lattice")] + \
         [("w_hidden_t", C.c_void_p * 8), ("b_hidden", C.c_void_p * 8)] + \
-        [(n, C.c_void_p) for n in ("w_out_a_t", "b_out_a", "w_out_x_t", "b_out_x", "w_out_l_t", "b_out_l")]
+        [(n, C.c_void_p) for n in ("w_out_a_t", "b_out_a", "w_out_x_t", "b_out_x", "w_out_l_t", "b_out_l",
+                                   "packed_image")]
 
 
 def build(force=False):
@@ -133,6 +134,10 @@ def _declare(L):
     L.mdx_mlp_pc_sample.restype = i32
     L.mdx_mlp_pc_sample.argtypes = [C.POINTER(Schedule), C.POINTER(Mlp), C.POINTER(PcFlags), i32, i32, i32, i32, Rng, i64,
                                     vp, vp, vp, vp, vp]
+    L.mdx_mlp_image_floats.restype = i64
+    L.mdx_mlp_image_floats.argtypes = [C.POINTER(Mlp)]
+    L.mdx_mlp_pack_image.restype = i32
+    L.mdx_mlp_pack_image.argtypes = [C.POINTER(Mlp), vp, vp]
     L.mdx_blas_create.restype = i32
     L.mdx_blas_create.argtypes = [C.POINTER(vp)]
     L.mdx_blas_destroy.restype = i32

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 
@@ -676,35 +677,31 @@ __device__ __forceinline__ MlpWeights weights_global(const mdx_mlp_t& m)
     return w;
 }
 
-// Copy every parameter tensor into the workgroup's LDS image (all threads of the block) and point at the copies.
-__device__ __forceinline__ MlpWeightsLds weights_to_lds(const mdx_mlp_t& m, const MlpOffsets& o, lds_f* img)
+// Write every parameter tensor into an image (LDS or global) in the kernels' layout: matrices as [k/4][n][k%4] with
+// zero rows up to a multiple of four, the three heads as one matrix.  Executed by all threads of one workgroup.
+template <typename Dst>
+__device__ __forceinline__ void write_mlp_image(const mdx_mlp_t& m, const MlpOffsets& o, Dst img)
 {
     const int N = m.number_of_atoms, d = m.spatial_dimension, C = m.num_classes, nl = d * (d + 1) / 2, H = m.hidden_size;
     auto copy = [&](const float* src, int at, int n) {
         for (int e = threadIdx.x; e < n; e += blockDim.x) img[at + e] = src[e];
-        return (lds_cf*)(img + at);
     };
-    // [k][n] (global, transposed Linear weight) -> [k/4][n][k%4] with zero rows up to a multiple of four
     auto copy_quad = [&](const float* src, int at, int k_dim, int n) {
         const int kp = (k_dim + 3) & ~3;
         for (int e = threadIdx.x; e < kp * n; e += blockDim.x) {
             const int q = e / (4 * n), r = e - q * 4 * n, j = r >> 2, c = r & 3, k = 4 * q + c;
             img[at + e] = k < k_dim ? src[k * n + j] : 0.0f;
         }
-        return (lds_cf*)(img + at);
     };
-    MlpWeightsLds w;
-    w.wc = copy_quad(m.w_coordinates_t, o.wc, 2 * N * d, m.e_coordinates); w.bc = copy(m.b_coordinates, o.bc, m.e_coordinates);
-    w.wn = copy(m.w_noise_t, o.wn, m.e_noise); w.bn = copy(m.b_noise, o.bn, m.e_noise);
-    w.wt = copy(m.w_time_t, o.wt, m.e_time); w.bt = copy(m.b_time, o.bt, m.e_time);
-    w.wa = copy(m.w_atom_type_t, o.wa, C * m.e_atom_type); w.ba = copy(m.b_atom_type, o.ba, m.e_atom_type);
-    w.wl = copy(m.w_lattice_t, o.wl, nl * m.e_lattice); w.bl = copy(m.b_lattice, o.bl, m.e_lattice);
+    copy_quad(m.w_coordinates_t, o.wc, 2 * N * d, m.e_coordinates); copy(m.b_coordinates, o.bc, m.e_coordinates);
+    copy(m.w_noise_t, o.wn, m.e_noise); copy(m.b_noise, o.bn, m.e_noise);
+    copy(m.w_time_t, o.wt, m.e_time); copy(m.b_time, o.bt, m.e_time);
+    copy(m.w_atom_type_t, o.wa, C * m.e_atom_type); copy(m.b_atom_type, o.ba, m.e_atom_type);
+    copy(m.w_lattice_t, o.wl, nl * m.e_lattice); copy(m.b_lattice, o.bl, m.e_lattice);
     for (int k = 0; k < m.n_hidden; ++k) {
         copy_quad(m.w_hidden_t[k], o.wh(k), k == 0 ? o.in0 : H, H);
         copy(m.b_hidden[k], o.bh(k), H);
     }
-    w.img = (lds_cf*)img;
-    w.off = o;
     {   // merged heads: columns [0, NC) logits, [NC, NC+Nd) score_x, [NC+Nd, ..) score_l
         const int nt = N * C + N * d + nl, kp = (H + 3) & ~3;
         for (int e = threadIdx.x; e < kp * nt; e += blockDim.x) {
@@ -719,10 +716,39 @@ __device__ __forceinline__ MlpWeightsLds weights_to_lds(const mdx_mlp_t& m, cons
         }
         for (int j = threadIdx.x; j < nt; j += blockDim.x)
             img[o.boa + j] = j < N * C ? m.b_out_a[j] : (j < N * C + N * d ? m.b_out_x[j - N * C] : m.b_out_l[j - N * C - N * d]);
-        w.woa = (lds_cf*)(img + o.woa); w.boa = (lds_cf*)(img + o.boa);
-        w.wox = w.woa; w.box = w.boa; w.wol = w.woa; w.bol = w.boa;
     }
+}
+
+// Stage the weights into the workgroup's LDS image -- one coalesced 16-byte-per-lane copy when the caller supplied the
+// packed image, the re-layout on the fly otherwise -- and point at the pieces.
+__device__ __forceinline__ MlpWeightsLds weights_to_lds(const mdx_mlp_t& m, const MlpOffsets& o, lds_f* img)
+{
+    if (m.packed_image) {
+        typedef __attribute__((address_space(3))) lds_f4 lds_wf4;
+        const lds_f4* src = reinterpret_cast<const lds_f4*>(m.packed_image);
+        lds_wf4* dst = (lds_wf4*)img;
+        const int n4 = o.total >> 2;
+#pragma unroll 8
+        for (int e = threadIdx.x; e < n4; e += blockDim.x) dst[e] = src[e];     // 16-B loads in flight, 16-B LDS stores
+    } else {
+        write_mlp_image(m, o, img);
+    }
+    MlpWeightsLds w;
+    lds_cf* c = (lds_cf*)img;
+    w.wc = c + o.wc; w.bc = c + o.bc; w.wn = c + o.wn; w.bn = c + o.bn; w.wt = c + o.wt; w.bt = c + o.bt;
+    w.wa = c + o.wa; w.ba = c + o.ba; w.wl = c + o.wl; w.bl = c + o.bl;
+    w.woa = c + o.woa; w.boa = c + o.boa; w.wox = w.woa; w.box = w.boa; w.wol = w.woa; w.bol = w.boa;
+    w.img = c;
+    w.off = o;
     return w;
+}
+
+__global__ __launch_bounds__(kBlock) void mlp_pack_image_kernel(mdx_mlp_t m, float* image)
+{
+    const MlpOffsets o = mlp_offsets(m);
+    for (int e = threadIdx.x; e < o.total; e += blockDim.x) image[e] = 0.0f;      // padding between the pieces
+    __syncthreads();
+    write_mlp_image(m, o, image);
 }
 
 // MLPScoreNetwork forward for ONE structure by one wavefront (mlp_score_network.py:281-370).
@@ -1608,6 +1634,23 @@ static int mlp_ok(const mdx_mlp_t* m)
 
 constexpr size_t kMlpLdsBudget = 64 * 1024;      // default dynamic-LDS limit per workgroup
 
+int64_t mdx_mlp_image_floats(const mdx_mlp_t* mlp_host)
+{
+    if (mlp_ok(mlp_host) != MDX_OK) return -1;
+    return mlp_offsets(*mlp_host).total;
+}
+
+int mdx_mlp_pack_image(const mdx_mlp_t* mlp_host, float* image_out, mdx_stream_t stream)
+{
+    const int ok = mlp_ok(mlp_host);
+    if (ok != MDX_OK) return ok;
+    if (!image_out) return MDX_ERR_INVALID_ARG;
+    mdx_mlp_t m = *mlp_host;
+    m.packed_image = nullptr;
+    hipLaunchKernelGGL(mlp_pack_image_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), m, image_out);
+    return launch_status();
+}
+
 int mdx_mlp_forward(const mdx_mlp_t* mlp_host, const int64_t* atom_types, const float* x, const float* l,
                     const float* time, const float* sigma, int64_t batch, float* logits_out, float* score_x_out,
                     float* score_l_out, mdx_stream_t stream)
@@ -1685,10 +1728,17 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
         const size_t lds = per_wave * kMlpWaves + image;
         const char* generic = getenv("MDX_MLP_GENERIC");          // tests: force the generic instantiation
         const bool spec = matches_template_mlp(*mlp_host) && !(generic && generic[0] == '1');
-        if (lds > kMlpLdsBudget &&       // up to 128 KiB of the CU's 160 KiB: opt in above the 64 KiB default
-            hipFuncSetAttribute(mlp_sampler_lds_function(G, spec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-                hipSuccess)
-            return MDX_ERR_HIP;
+        if (lds > kMlpLdsBudget) {       // up to 128 KiB of the CU's 160 KiB: opt in above the 64 KiB default
+            // the attribute is a property of the code object: set it when the requirement grows, not on every launch
+            static std::atomic<size_t> granted[16];
+            const int slot = (spec ? 8 : 0) + (G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : G == 32 ? 5 : 6);
+            if (granted[slot].load() < lds) {
+                if (hipFuncSetAttribute(mlp_sampler_lds_function(G, spec), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds) != hipSuccess)
+                    return MDX_ERR_HIP;
+                granted[slot].store(lds);
+            }
+        }
         if (spec)
             hipLaunchKernelGGL((mlp_pc_sample_kernel<8, true, 1>), dim3(grid), dim3(kMlpWaves * kWave), lds, st, a);
         else

@@ -262,6 +262,14 @@ class MlpPack:
         for name, layer in (("a", network.output_A_layer), ("x", network.output_X_layer), ("l", network.output_L_layer)):
             setattr(m, f"w_out_{name}_t", wt(layer))
             setattr(m, f"b_out_{name}", bias(layer))
+        m.packed_image = None
+        n_floats = lib().mdx_mlp_image_floats(C.byref(m))
+        if n_floats > 0:      # the kernels' own layout, built once: kernel start-up becomes one coalesced copy
+            self.image = torch.empty(n_floats, dtype=F32, device=device)
+            with torch.cuda.device(device):
+                check(lib().mdx_mlp_pack_image(C.byref(m), ptr(self.image, F32, "image"), stream_handle()),
+                      "mdx_mlp_pack_image")
+            m.packed_image = self.image.data_ptr()
         self.c_struct = m
         self.device = torch.device(device)
         self.number_of_atoms, self.num_classes, self.spatial_dimension = m.number_of_atoms, m.num_classes, m.spatial_dimension

@@ -212,7 +212,14 @@ typedef struct mdx_mlp {
     const float *w_out_a_t, *b_out_a;                    /* [hidden_size, N*C] */
     const float *w_out_x_t, *b_out_x;                    /* [hidden_size, N*d] */
     const float *w_out_l_t, *b_out_l;                    /* [hidden_size, d(d+1)/2] */
+    const float* packed_image;                           /* optional (NULL allowed): all of the above re-laid out by
+                                                            mdx_mlp_pack_image; lets a kernel stage the weights into
+                                                            LDS with one coalesced copy */
 } mdx_mlp_t;
+
+/* Size (in floats) and construction of the packed weight image referenced by mdx_mlp_t.packed_image. */
+MDX_API int64_t mdx_mlp_image_floats(const mdx_mlp_t* mlp_host);
+MDX_API int mdx_mlp_pack_image(const mdx_mlp_t* mlp_host, float* image_out, mdx_stream_t stream);
 
 /* ScoreNetwork.forward of the MLP (mlp_score_network.py:281-370 + score_network.py:183-185: MASK logit = -inf):
  * one wavefront per structure, weights streamed from L2, activations in LDS.  time, sigma: [B,1]. */

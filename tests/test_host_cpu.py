@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     from diffusion_for_multi_scale_molecular_dynamics_amd import _hip
     _hip.build()
     header = open(os.path.join(ROOT, "include", "mdx_hip.h")).read()
-    declared = re.findall(r"MDX_API\s+(?:const\s+char\*|int)\s+(mdx_[a-z0-9_]+)\s*\(", header)
+    declared = re.findall(r"MDX_API\s+(?:const\s+char\*|int64_t|int)\s+(mdx_[a-z0-9_]+)\s*\(", header)
     assert len(declared) >= 17 and sorted(declared) == sorted(_hip.ABI_SYMBOLS)
     exported = subprocess.check_output(["nm", "-D", "--defined-only", _hip.LIB_PATH], text=True)
     for sym in declared:
