@@ -84,7 +84,7 @@ WORKLOADS = {
     "C5": dict(desc="Si_diffusion_3x3x3 repaint (108 of 216 atoms pinned), EGNN, 2000 steps, batch=256 per GPU",
                n_atoms=216, num_atom_types=1, cell=16.29, net="egnn", batch=256, M=2, greedy=False, one=False,
                noise=dict(total_time_steps=2000, **LINEAR), graph=False, dominant="radius_graph_kernel",
-               repaint=108),
+               repaint=108, resampling=1),
 }
 
 
@@ -96,7 +96,7 @@ def diamond_sites(n_cells):
     return ((cells[:, None, :] + base[None]) / n_cells).reshape(-1, 3)
 
 
-def build_generator(w, device, rank, batch, use_graph, edge_builder=None):
+def build_generator(w, device, rank, batch, use_graph, edge_builder=None, resampling=0):
     torch.manual_seed(NET_SEED)
     net = (mlp_template(w["num_atom_types"], w["n_atoms"]) if w["net"] == "mlp"
            else egnn_experiment(w["num_atom_types"], edge_builder)).eval().to(device)
@@ -105,7 +105,8 @@ def build_generator(w, device, rank, batch, use_graph, edge_builder=None):
         number_of_atoms=w["n_atoms"], num_atom_types=w["num_atom_types"], number_of_samples=batch,
         number_of_corrector_steps=w["M"], atom_type_greedy_sampling=w["greedy"],
         one_atom_type_transition_per_step=w["one"], use_fixed_lattice_parameters=True,
-        cell_dimensions=[w["cell"]] * 3, rng_mode="device", seed=BASE_SEED, use_hip_graph=use_graph)
+        cell_dimensions=[w["cell"]] * 3, rng_mode="device", seed=BASE_SEED, use_hip_graph=use_graph,
+        repaint_resampling_steps=resampling if "repaint" in w else 0)
     if "repaint" in w:
         k = w["repaint"]
         constraint = SamplingConstraint(elements=["Si"], constrained_relative_coordinates=diamond_sites(3)[:k].clone(),
@@ -245,7 +246,7 @@ def time_radius_graph(batch, w, device, launches=50):
                 edges_per_atom=n_edges / (batch * n))
 
 
-def cpu_baseline(w, name, budget_s=15.0):
+def cpu_baseline(w, name, budget_s=15.0, resampling=0):
     """The CPU oracle on this host's cores over a bounded sample of the same workload."""
     import nets as test_nets
     from oracle import mdx_oracle
@@ -255,7 +256,7 @@ def cpu_baseline(w, name, budget_s=15.0):
     mdx_oracle.build()
     batch = w["batch"] if w["net"] == "mlp" else 16
     gen, noise, sampling, net = build_generator(w, torch.device("cpu"), 0, batch, False,
-                                                edge_builder=test_nets.oracle_edge_builder)
+                                                edge_builder=test_nets.oracle_edge_builder, resampling=resampling)
     constraint = None
     if "repaint" in w:
         k = w["repaint"]
@@ -268,10 +269,8 @@ def cpu_baseline(w, name, budget_s=15.0):
     def run(i0, count):
         nonlocal comp
         t0 = time.perf_counter()
-        for i in range(i0, i0 - count, -1):
-            comp = ora.predictor_step(comp, i + 1)
-            for m in range(sampling.number_of_corrector_steps):
-                comp = ora.corrector_step(comp, i, m)
+        for i in range(i0, i0 - count, -1):       # one sampler iteration = what OracleLangevinGenerator's loop does
+            comp = ora.sample_from_noisy_composition(comp, i + 1, i)
         return time.perf_counter() - t0
 
     probe = 2 if w["net"] == "egnn" else 10
@@ -298,6 +297,9 @@ def main():
                     help="score-network forward: 'pytorch' (plugin API, any network) or 'fused' (MLP only: network "
                          "forward + update in one persistent HIP kernel); default: fused for MLP workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--resampling", type=int, default=None,
+                    help="C5 only: RePaint resampling passes per time index (BASELINE configs[4] 'with resampling'; "
+                         "default 1; 0 = the reference's loop, which has no resampling)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (with ranks sharing a GPU) exists to rehearse the multi-rank control "
                          "flow on a one-GPU box")
@@ -330,7 +332,8 @@ def main():
     assert forward == "pytorch" or mlp, "the fused forward exists for the MLP score network only"
     use_graph = w["graph"] and not args.no_graph and forward == "pytorch"
 
-    gen, noise, sampling, net = build_generator(w, device, rank, batch, use_graph)
+    resampling = (args.resampling if args.resampling is not None else w.get("resampling", 0)) if "repaint" in w else 0
+    gen, noise, sampling, net = build_generator(w, device, rank, batch, use_graph, resampling=resampling)
     gen.fused_score_network = forward == "fused"
 
     def barrier():
@@ -409,6 +412,7 @@ def main():
         "dtype": "f32", "data": "synthetic (random-init score network, uniform-random initial structures)",
         "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": batch, "global_batch": batch * world,
                    "number_of_atoms": w["n_atoms"], "total_time_steps": T, "corrector_steps": w["M"],
+                   "repaint_resampling_steps": resampling,
                    "rng": "device Philox4x32-10", "hip_graph": bool(use_graph),
                    "score_network_forward": "fused HIP (one persistent kernel per launch of K iterations)"
                    if forward == "fused" else "PyTorch-ROCm module (plugin API)", "gather_ms": round(gather_ms, 4),
@@ -416,7 +420,7 @@ def main():
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(w, args.workload)
+        result["cpu_baseline"] = cpu_baseline(w, args.workload, resampling=resampling)
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -18,13 +18,13 @@ MDX_PREDICTOR, MDX_CORRECTOR = 0, 1
 STATUS_CUTOFF_TOO_LARGE, STATUS_MASK_AT_LAST_STEP = 1, 2
 MAX_CLASSES = 8
 TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
-    TAG_INIT_LATTICE = range(9)
+    TAG_INIT_LATTICE, TAG_RESAMPLE_Z, TAG_RESAMPLE_U = range(11)
 
 ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
-    "mdx_repaint_constrained_rows", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_mlp_forward",
+    "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_mlp_forward",
     "mdx_mlp_pc_sample", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input",
     "mdx_rng_fill", "mdx_math_probe",
 )
@@ -125,6 +125,8 @@ def _declare(L):
     L.mdx_repaint_constrained_rows.restype = i32
     L.mdx_repaint_constrained_rows.argtypes = [C.POINTER(Schedule), i32, vp, vp, vp, vp, i32, vp, vp, Rng, i64, i32,
                                                i32, vp, vp, vp]
+    L.mdx_forward_diffusion_step.restype = i32
+    L.mdx_forward_diffusion_step.argtypes = [C.POINTER(Schedule), i32, vp, vp, vp, Rng, i64, i32, i32, vp, vp, vp]
     L.mdx_radius_graph_count.restype = i32
     L.mdx_radius_graph_count.argtypes = [vp, vp, f32, i64, i32, i32, vp, vp, vp]
     L.mdx_radius_graph_fill.restype = i32

@@ -1147,6 +1147,53 @@ __global__ __launch_bounds__(kBlock) void repaint_rows_kernel(RepaintArgs p)
     }
 }
 
+// RePaint resampling: one forward-process step i -> i+1 on every atom (no reference counterpart; include/mdx_hip.h)
+struct ForwardStepArgs {
+    SchedDev sched;
+    int index_i;
+    const int32_t* d_index;
+    const float *z, *u;
+    mdx_rng_t rng;
+    int64_t atoms;
+    int d, C;
+    float* x;
+    int64_t* a;
+};
+
+__global__ __launch_bounds__(kBlock) void forward_step_kernel(ForwardStepArgs p)
+{
+    const int index = (p.d_index ? *p.d_index : 0) + p.index_i;
+    if (index < 1 || index >= p.sched.T) return;          // nothing to re-noise at the ends of the trajectory
+    const int C = p.C, d = p.d;
+    const uint32_t k0 = (uint32_t)p.rng.seed, k1 = (uint32_t)(p.rng.seed >> 32);
+    const uint32_t call8 = p.rng.call << 8;
+    const uint32_t draw = (uint32_t)index * p.rng.draw_stride + p.rng.draw_offset;
+    const float g = p.sched.g[index];
+    const float* q = p.sched.q + (int64_t)index * C * C;
+    for (int64_t at = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; at < p.atoms; at += (int64_t)gridDim.x * blockDim.x) {
+        float z[4];
+        if (!p.z) {
+            const u32x4 r = philox4x32_10((uint32_t)at, call8, draw, MDX_TAG_RESAMPLE_Z, k0, k1);
+            box_muller(r.v[0], r.v[1], z[0], z[1]);
+            if (d > 2) box_muller(r.v[2], r.v[3], z[2], z[3]);
+        }
+        for (int c = 0; c < d; ++c) {
+            const float zz = p.z ? p.z[at * d + c] : z[c];
+            p.x[at * d + c] = wrap01(p.x[at * d + c] + g * zz);
+        }
+        float uu[MDX_MAX_CLASSES];
+        if (p.u) {
+            for (int c = 0; c < C; ++c) uu[c] = p.u[at * C + c];
+        } else {
+            for (int sub = 0; sub * 4 < C; ++sub) {
+                const u32x4 r = philox4x32_10((uint32_t)at, call8 | (uint32_t)sub, draw, MDX_TAG_RESAMPLE_U, k0, k1);
+                for (int l = 0; l < 4 && sub * 4 + l < C; ++l) uu[sub * 4 + l] = u01(r.v[l]);
+            }
+        }
+        p.a[at] = noised_atom_type((int)p.a[at], q, C, uu, true);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // N1: radius graph
 // ---------------------------------------------------------------------------------------------------------------
@@ -1573,6 +1620,26 @@ int mdx_repaint_constrained_rows(const mdx_schedule_t* sched_host, int index_i, 
     a.x = x_inout; a.a = a_inout;
     hipLaunchKernelGGL(repaint_rows_kernel, dim3(flat_grid(batch * number_of_constraints)), dim3(kBlock), 0,
                        as_stream(stream), a);
+    return launch_status();
+}
+
+int mdx_forward_diffusion_step(const mdx_schedule_t* sched_host, int index_i, const int32_t* d_index, const float* z,
+                               const float* u, mdx_rng_t rng, int64_t batch, int number_of_atoms, int spatial_dimension,
+                               float* x_inout, int64_t* a_inout, mdx_stream_t stream)
+{
+    if (!sched_host || batch < 0 || number_of_atoms < 1) return MDX_ERR_INVALID_ARG;
+    if (spatial_dimension < 1 || spatial_dimension > 3) return MDX_ERR_INVALID_ARG;
+    if (!d_index && (index_i < 1 || index_i >= sched_host->total_time_steps)) return MDX_ERR_INVALID_ARG;
+    if (sched_host->num_classes > MDX_MAX_CLASSES) return MDX_ERR_UNSUPPORTED;
+    if (batch == 0) return MDX_OK;
+    if (!x_inout || !a_inout) return MDX_ERR_INVALID_ARG;
+    ForwardStepArgs a{};
+    a.sched = to_dev(sched_host);
+    a.index_i = index_i; a.d_index = d_index;
+    a.z = z; a.u = u; a.rng = rng;
+    a.atoms = batch * number_of_atoms; a.d = spatial_dimension; a.C = sched_host->num_classes;
+    a.x = x_inout; a.a = a_inout;
+    hipLaunchKernelGGL(forward_step_kernel, dim3(flat_grid(a.atoms)), dim3(kBlock), 0, as_stream(stream), a);
     return launch_status();
 }
 

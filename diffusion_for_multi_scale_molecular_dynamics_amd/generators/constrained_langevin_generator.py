@@ -37,6 +37,8 @@ class ConstrainedLangevinGenerator(LangevinGenerator):
         else:
             self.constraint_indices = sampling_constraints.constrained_indices
         self._constraint_device = {}
+        self.resampling_steps = int(getattr(sampling_parameters, "repaint_resampling_steps", 0) or 0)
+        assert self.resampling_steps >= 0, "repaint_resampling_steps should be non-negative"
 
     def _constraint_on(self, device):
         if device not in self._constraint_device:
@@ -64,7 +66,20 @@ class ConstrainedLangevinGenerator(LangevinGenerator):
         rng = self._rng(0)
         rng_index = index_i
         kernels.repaint_constrained_rows(sched, rng_index, d_index, cx, ca, cidx, z, u,
-                                         Rng(rng.seed, rng.call, rng.draw_stride, rng.draw_stride), x, a)
+                                         Rng(rng.seed, rng.call, rng.draw_stride, rng.draw_stride + rng.draw_offset),
+                                         x, a)
+        return AXL(A=a, X=x, L=composition.L)
+
+    def _forward_step(self, composition: AXL, index_i: int, d_index=None) -> AXL:
+        """Resampling: forward-noise the WHOLE composition from time index i back to i+1, in place
+        (mdx_forward_diffusion_step; build-only, no reference counterpart).  Reference-RNG mode draws z then u."""
+        x, a = composition.X, composition.A
+        device = x.device
+        z = u = None
+        if not getattr(self.noise_source, "device_rng", False):
+            z = self.noise_source.randn(x.shape).to(device=device, dtype=torch.float32).contiguous()
+            u = self.noise_source.rand(x.shape[0], self.number_of_atoms, self.num_classes).to(device).contiguous()
+        kernels.forward_diffusion_step(self._prepare(device), index_i, d_index, z, u, self._rng(0), x, a)
         return AXL(A=a, X=x, L=composition.L)
 
     def predictor_step(self, composition_i: AXL, index_i: int, cartesian_forces: torch.Tensor) -> AXL:

@@ -69,6 +69,8 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         self._seed = getattr(sp, "seed", None)
         self._call_counter = 0
         self.noise_source = ReferenceOrderNoise() if rng_mode == "reference" else None
+        self.resampling_steps = 0     # set by ConstrainedLangevinGenerator (repaint_resampling_steps)
+        self._visit = 0               # which of the 1 + resampling_steps passes through the current time index
 
         self._scheduler = None       # device tables, built on first use for the sampling device
         self._status = None
@@ -108,10 +110,15 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         return PcFlags(int(self.atom_type_greedy_sampling), int(self.one_atom_type_transition_per_step),
                        int(self.use_fixed_lattice_parameters), int(update_atom_types), float(self.small_epsilon))
 
+    def _draw_stride(self) -> int:
+        """Philox draw ids per time index: (1 predictor + M correctors) x (1 + resampling passes)."""
+        return (self.number_of_corrector_steps + 1) * (self.resampling_steps + 1)
+
     def _rng(self, draw_offset: int) -> Rng:
         src = self.noise_source
         seed, call = (src.seed, src.call) if getattr(src, "device_rng", False) else (0, 0)
-        return Rng(seed, call, self.number_of_corrector_steps + 1, draw_offset)
+        return Rng(seed, call, self._draw_stride(),
+                   self._visit * (self.number_of_corrector_steps + 1) + draw_offset)
 
     def _begin_call(self, device):
         """One sample() call = one Philox `call` index; the trajectory initialiser shares the noise source."""
@@ -214,7 +221,8 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         src = self.noise_source
         if gumbel is None:       # device RNG: materialise the same draws the fused kernel generated in registers
             from .._hip import TAG_BINARY, TAG_GUMBEL
-            draw = index_i * (self.number_of_corrector_steps + 1) + (0 if mode == MDX_PREDICTOR else 1)
+            draw = index_i * self._draw_stride() + self._visit * (self.number_of_corrector_steps + 1) + \
+                (0 if mode == MDX_PREDICTOR else 1)
             n = batch * self.number_of_atoms
             gumbel = kernels.rng_fill(kernels.RNG_GUMBEL, src.seed, src.call, draw, TAG_GUMBEL, n, self.num_classes,
                                       logits.device).view(batch, self.number_of_atoms, self.num_classes)
@@ -284,17 +292,36 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         composition = starting_noisy_composition
         forces = torch.zeros_like(composition.X)
         for i in range(starting_step_index - 1, max(ending_step_index, 0) - 1, -1):
-            composition = self.predictor_step(composition, i + 1, forces)
-            for m in range(self.number_of_corrector_steps):
-                composition = self.corrector_step(composition, i, forces, m)
+            visits = self._visits_at(i)
+            for self._visit in range(visits):
+                composition = self.predictor_step(composition, i + 1, forces)
+                for m in range(self.number_of_corrector_steps):
+                    composition = self.corrector_step(composition, i, forces, m)
+                if self._visit < visits - 1:
+                    composition = self._forward_step(composition, i)
+            self._visit = 0
         return composition
 
-    def _iteration_on_device_index(self, comp: AXL, forces: torch.Tensor, d_index: torch.Tensor):
-        """One predictor + M correctors with the loop variable i read from *d_index on the device; in place."""
-        comp, _ = self._step(MDX_PREDICTOR, comp, 1, forces, 0, d_index=d_index, in_place=True)
-        comp = self._after_predictor(comp, 0, d_index=d_index)
-        for m in range(self.number_of_corrector_steps):
-            comp, _ = self._step(MDX_CORRECTOR, comp, 0, forces, 1 + m, d_index=d_index, in_place=True)
+    def _visits_at(self, index_i: int) -> int:
+        """Passes through time index i: 1 + resampling steps, none at the last index (RePaint algorithm 1, t > 1)."""
+        return 1 + self.resampling_steps if index_i > 0 else 1
+
+    def _forward_step(self, composition: AXL, index_i: int, d_index=None) -> AXL:
+        raise MdxError("resampling needs the repaint generator")
+
+    def _iteration_on_device_index(self, comp: AXL, forces: torch.Tensor, d_index: torch.Tensor,
+                                   visits: Optional[int] = None):
+        """One predictor + M correctors (x resampling passes) with the loop variable i read from *d_index on the
+        device; in place."""
+        visits = 1 + self.resampling_steps if visits is None else visits
+        for self._visit in range(visits):
+            comp, _ = self._step(MDX_PREDICTOR, comp, 1, forces, 0, d_index=d_index, in_place=True)
+            comp = self._after_predictor(comp, 0, d_index=d_index)
+            for m in range(self.number_of_corrector_steps):
+                comp, _ = self._step(MDX_CORRECTOR, comp, 0, forces, 1 + m, d_index=d_index, in_place=True)
+            if self._visit < visits - 1:
+                comp = self._forward_step(comp, 0, d_index=d_index)
+        self._visit = 0
         kernels.index_add(d_index, -1)
         return comp
 
@@ -392,10 +419,12 @@ class IterationLoop:
     def advance(self, iterations: int):
         """Run `iterations` sampler iterations (asynchronously on the current stream)."""
         assert iterations <= self.remaining, "cannot step past time index 0"
-        if self.graph is not None:
-            for _ in range(iterations):
+        gen = self.generator
+        for _ in range(iterations):
+            if self.remaining == 1 and gen.resampling_steps > 0:     # time index 0: never resampled
+                gen._iteration_on_device_index(self.composition, self.forces, self.d_index, visits=1)
+            elif self.graph is not None:
                 self.graph.replay()
-        else:
-            for _ in range(iterations):
-                self.generator._iteration_on_device_index(self.composition, self.forces, self.d_index)
-        self.remaining -= iterations
+            else:
+                gen._iteration_on_device_index(self.composition, self.forces, self.d_index)
+            self.remaining -= 1

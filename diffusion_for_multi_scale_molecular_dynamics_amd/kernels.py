@@ -181,6 +181,15 @@ def repaint_constrained_rows(sched: DeviceSchedule, index_i: int, d_index, const
     check(rc, "mdx_repaint_constrained_rows")
 
 
+def forward_diffusion_step(sched: DeviceSchedule, index_i: int, d_index, z, u, rng: Rng, x_inout, a_inout):
+    """RePaint resampling: one forward-process step i -> i+1 on every atom, in place (mdx_forward_diffusion_step)."""
+    B, N, d = x_inout.shape
+    rc = lib().mdx_forward_diffusion_step(C.byref(sched.c_struct), int(index_i), ptr(d_index, I32, "d_index"),
+                                          ptr(z, F32, "z"), ptr(u, F32, "u"), rng, B, N, d, ptr(x_inout, F32, "x"),
+                                          ptr(a_inout, I64, "a"), stream_handle())
+    check(rc, "mdx_forward_diffusion_step")
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # N1
 # ----------------------------------------------------------------------------------------------------------------

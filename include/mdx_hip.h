@@ -55,6 +55,8 @@ extern "C" {
 #define MDX_TAG_REPAINT_Z 6
 #define MDX_TAG_REPAINT_U 7
 #define MDX_TAG_INIT_LATTICE 8
+#define MDX_TAG_RESAMPLE_Z 9
+#define MDX_TAG_RESAMPLE_U 10
 
 #if defined(__GNUC__)
 #define MDX_API __attribute__((visibility("default")))
@@ -175,6 +177,19 @@ MDX_API int mdx_repaint_constrained_rows(const mdx_schedule_t* sched_host, int i
                                  const int64_t* constrained_indices, int number_of_constraints, const float* z,
                                  const float* u, mdx_rng_t rng, int64_t batch, int number_of_atoms,
                                  int spatial_dimension, float* x_inout, int64_t* a_inout, mdx_stream_t stream);
+
+/* RePaint resampling ("2000 steps with resampling", BASELINE configs[4]) -- no reference counterpart: the reference's
+ * ConstrainedLangevinGenerator (generators/constrained_langevin_generator.py:94-163) has no resampling loop, so this
+ * entry is the build-only option `repaint_resampling_steps` of SURVEY section 8(d); with 0 resampling steps it is never
+ * called and the reference's behaviour is unchanged.  One step of the FORWARD process from time index i to i+1
+ * (i = *d_index + index_i, 1 <= i < T), in place, for every atom of every structure, with the table row idx = i that
+ * the predictor step i+1 -> i reads:  X <- wrap(X + g[idx] * z)        (variance-exploding kernel, F1 arithmetic)
+ *                                     A <- argmax_c(log Q[idx][A][c] - log(-log u_c))   (one-step D3PM kernel, F2)
+ * z [B,N,d] / u [B,N,C] pre-drawn, or NULL for the device RNG (tags MDX_TAG_RESAMPLE_Z / _U). */
+MDX_API int mdx_forward_diffusion_step(const mdx_schedule_t* sched_host, int index_i, const int32_t* d_index,
+                                       const float* z, const float* u, mdx_rng_t rng, int64_t batch,
+                                       int number_of_atoms, int spatial_dimension, float* x_inout, int64_t* a_inout,
+                                       mdx_stream_t stream);
 
 /* N1 -- get_periodic_adjacency_information (utils/neighbors.py:36-224) and the EGNN consumer
  * get_edges_with_radial_cutoff (models/egnn_utils.py:107-144).  Two-call protocol:

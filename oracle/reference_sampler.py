@@ -150,13 +150,16 @@ class OracleLangevinGenerator:
             K = len(constraint["constrained_atom_types"])
             idx = constraint.get("constrained_indices")
             self.cidx = np.arange(K) if idx is None else np.asarray(idx)
+        # build-only RePaint resampling (no reference counterpart; 0 = the reference's loop)
+        self.resampling = int(getattr(spar, "repaint_resampling_steps", 0) or 0) if constraint is not None else 0
+        self.visit = 0
         self.records = []          # filled when record=True
         self.record = False
         self.mask_left_at_last_step = False
 
     # -- draws -------------------------------------------------------------------------------------------------
     def _draw_id(self, index, offset):
-        return index * (self.M + 1) + offset
+        return index * (self.M + 1) * (self.resampling + 1) + self.visit * (self.M + 1) + offset
 
     def _normal_coords(self, B, index, offset, tag=O.TAG_COORD):
         if self.noise.reference_order:
@@ -277,6 +280,24 @@ class OracleLangevinGenerator:
         A[:, self.cidx] = O.noise_atom_types(a0, qbar, np.ascontiguousarray(u[:, self.cidx]))
         return AXL(A=A, X=X, L=comp.L)
 
+    def forward_step(self, comp, index):
+        """Resampling: one step of the forward process, time index i -> i+1, on the whole composition
+        (X += g z wrapped -- the F1 arithmetic with g in place of sigma; A ~ one-step kernel Q -- the F2 arithmetic
+        with Q in place of Q-bar), using the table row the predictor step i+1 -> i reads."""
+        B = comp.X.shape[0]
+        g = self.tables["g"][index]
+        q = self.tables["q_matrix"][index]
+        if self.noise.reference_order:
+            z = self.noise.randn(B, self.N, self.d)
+            u = self.noise.rand(B, self.N, self.C)
+        else:
+            dr = self._draw_id(index, 0)
+            z = self.noise.normal(dr, O.TAG_RESAMPLE_Z, B * self.N, self.d).reshape(B, self.N, self.d)
+            u = self.noise.uniform(dr, O.TAG_RESAMPLE_U, B * self.N, self.C).reshape(B, self.N, self.C)
+        X = O.noise_coordinates(comp.X, z, g)
+        A = O.noise_atom_types(comp.A, q, np.ascontiguousarray(u))
+        return AXL(A=A, X=X, L=comp.L)
+
     # -- loop --------------------------------------------------------------------------------------------------
     def initialize(self, B):
         """trajectory_initializer.py:101-123"""
@@ -295,9 +316,14 @@ class OracleLangevinGenerator:
 
     def sample_from_noisy_composition(self, comp, starting_step_index, ending_step_index=0):
         for i in range(starting_step_index - 1, max(ending_step_index, 0) - 1, -1):
-            comp = self.predictor_step(comp, i + 1)
-            for m in range(self.M):
-                comp = self.corrector_step(comp, i, m)
+            visits = 1 + self.resampling if i > 0 else 1
+            for self.visit in range(visits):
+                comp = self.predictor_step(comp, i + 1)
+                for m in range(self.M):
+                    comp = self.corrector_step(comp, i, m)
+                if self.visit < visits - 1:
+                    comp = self.forward_step(comp, i)
+            self.visit = 0
         return comp
 
     def sample(self, number_of_samples):

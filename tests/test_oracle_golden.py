@@ -252,3 +252,42 @@ def test_adaptive_corrector_trajectories(oracle, name):
     for k, r in enumerate([r for r in gen.records if r[0] == "predictor"]):
         assert np.array_equal(r[3].X, r[2].X)                                  # predictor leaves X untouched
         assert np.array_equal(r[3].A, g["pred_composition_im1_A"][k])
+
+
+def test_repaint_resampling_specification():
+    """Build-only RePaint resampling (no reference counterpart): 0 steps is the reference's loop; with steps > 0
+    every index i > 0 is visited 1 + steps times, the forward step keeps MASK absorbing, constrained rows stay
+    pinned, no MASK is left, and the run is a pure function of the Philox seed."""
+    import cases
+    import nets
+    noise_kw, sampling_kw, _ = cases.REPAINT["traj_repaint_fake"]
+    nat = sampling_kw["num_atom_types"]
+    rng = np.random.default_rng(3)
+    constraint = dict(constrained_relative_coordinates=rng.random((4, 3), dtype=np.float32),
+                      constrained_atom_types=rng.integers(0, nat, 4), constrained_indices=np.array([5, 0, 2, 7]))
+    results = {}
+    for steps in (0, 2):
+        npar, spar = cases.as_objects(noise_kw, dict(sampling_kw, repaint_resampling_steps=steps))
+        runs = []
+        for _ in range(2):
+            gen = RS.OracleLangevinGenerator(npar, spar, nets.fake_net(nat), noise=RS.PhiloxNoise(5, 0),
+                                             constraint=constraint)
+            calls = []
+            inner = gen.predictor_step
+            gen.predictor_step = lambda comp, index, inner=inner, calls=calls: (calls.append(index), inner(comp, index))[1]
+            runs.append(gen.sample(6))
+        assert np.array_equal(runs[0].X, runs[1].X) and np.array_equal(runs[0].A, runs[1].A)
+        T = npar.total_time_steps
+        want = [i + 1 for i in range(T - 1, -1, -1) for _ in range(1 + steps if i > 0 else 1)]
+        assert calls == want
+        out = runs[0]
+        assert (out.A != nat).all()
+        assert np.array_equal(out.X[:, constraint["constrained_indices"]],
+                              np.broadcast_to(constraint["constrained_relative_coordinates"], (6, 4, 3)))
+        results[steps] = out
+    assert not np.array_equal(results[0].X, results[2].X)
+    # without the option the oracle is the reference's loop (pinned by test_repaint_trajectories)
+    npar, spar = cases.as_objects(noise_kw, sampling_kw)
+    base = RS.OracleLangevinGenerator(npar, spar, nets.fake_net(nat), noise=RS.PhiloxNoise(5, 0),
+                                      constraint=constraint).sample(6)
+    assert np.array_equal(base.X, results[0].X) and np.array_equal(base.A, results[0].A)
