@@ -20,12 +20,13 @@ MAX_CLASSES = 8
 TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
     TAG_INIT_LATTICE, TAG_RESAMPLE_Z, TAG_RESAMPLE_U = range(11)
 
+ABI_VERSION = 2          # MDX_ABI_VERSION of include/mdx_hip.h
 ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
     "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_mlp_forward",
-    "mdx_mlp_pc_sample", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input",
+    "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input",
     "mdx_rng_fill", "mdx_math_probe",
 )
 MLP_MAX_HIDDEN = 8
@@ -89,7 +90,7 @@ def lib():
                 f"(or `make -C {CSRC}`). There is no CPU fallback for the sampling hot path.")
         L = C.CDLL(LIB_PATH)
         _declare(L)
-        if L.mdx_abi_version() != 1:
+        if L.mdx_abi_version() != ABI_VERSION:
             raise MdxError("libmdx_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -135,7 +136,9 @@ def _declare(L):
     L.mdx_mlp_forward.argtypes = [C.POINTER(Mlp), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
     L.mdx_mlp_pc_sample.restype = i32
     L.mdx_mlp_pc_sample.argtypes = [C.POINTER(Schedule), C.POINTER(Mlp), C.POINTER(PcFlags), i32, i32, i32, i32, Rng, i64,
-                                    vp, vp, vp, vp, vp]
+                                    vp, vp, vp, vp, i64, vp, vp]
+    L.mdx_mlp_pc_sample_workspace_floats.restype = i64
+    L.mdx_mlp_pc_sample_workspace_floats.argtypes = [C.POINTER(Mlp), i32, i32, i32, i64]
     L.mdx_mlp_image_floats.restype = i64
     L.mdx_mlp_image_floats.argtypes = [C.POINTER(Mlp)]
     L.mdx_mlp_pack_image.restype = i32

@@ -909,13 +909,15 @@ __host__ __device__ inline int mlp_scratch_floats(const mdx_mlp_t& m)
 __host__ __device__ inline int mlp_wave_floats(const mdx_mlp_t& m)
 {
     const int N = m.number_of_atoms, d = m.spatial_dimension, C = m.num_classes, nl = d * (d + 1) / 2;
-    const int f = 2 * mlp_scratch_floats(m) + 2 * N + N * d + ((nl + 3) & ~3) + N * C + N * d + nl;
+    const int f = 2 * mlp_scratch_floats(m) + 2 * N + N * d + ((nl + 3) & ~3) + N * C + N * d + ((nl + 3) & ~3) +
+                  N * (d + C + 1);
     return (f + 3) & ~3;
 }
 
-// LDS per wavefront: [buf_a S][buf_b S][a: N int64][x: N d][l: nl pad 4][logits: N C][score_x: N d][score_l: nl]
+// LDS per wavefront: [buf_a S][buf_b S][a: N int64][x: N d][l: nl pad 4][logits: N C][score_x: N d][score_l: nl pad 4]
+//                    [noise record of the current step: z N d | gumbel N C | u N]
 struct MlpWaveLds {
-    lds_f *buf_a, *buf_b, *x, *l, *logits, *sx, *sl;
+    lds_f *buf_a, *buf_b, *x, *l, *logits, *sx, *sl, *noise;
     lds_i64* a;
 };
 
@@ -932,6 +934,7 @@ __device__ __forceinline__ MlpWaveLds carve_wave_lds(const mdx_mlp_t& m, lds_f* 
     r.logits = r.l + ((nl + 3) & ~3);
     r.sx = r.logits + N * C;
     r.sl = r.sx + N * d;
+    r.noise = r.sl + ((nl + 3) & ~3);
     return r;
 }
 
@@ -976,7 +979,60 @@ struct MlpSampleArgs {
     int diag_skip;           // diagnostic builds of the timing breakdown only (MDX_DIAG_SKIP): 1 = no forward, 2 = no update
     int64_t* a;
     float *x, *l;
+    // pre-drawn noise (pc_noise_fill_kernel): records [iteration][structure][predictor rec0 | M x corrector rec1];
+    // NULL: every wavefront evaluates the Philox specification itself, on the few lanes its structure's atoms occupy
+    const float* noise;
+    int rec0, rec1;
 };
+
+// ---- noise pre-pass of the persistent sampler -----------------------------------------------------------------
+// The draws of a trajectory do not depend on its state, so they are generated ahead of the loop by a kernel that
+// fills the chip (one lane per atom and step) instead of inside the persistent kernel, where a structure's N atoms
+// occupy N of the wavefront's 64 lanes and the ~600-instruction Philox / Box-Muller / Gumbel sequence sits on the
+// critical path of every step.  Same counters, same functions => the same bits as the in-kernel draws.
+struct NoiseFillArgs {
+    mdx_rng_t rng;
+    int start_index, n_iterations, types_in_corrector, greedy;
+    int64_t B;
+    int N, d, C, rec0, rec1, M;
+    float* out;
+};
+
+__global__ __launch_bounds__(kBlock) void pc_noise_fill_kernel(NoiseFillArgs p)
+{
+    const int sub = blockIdx.y;                                   // 0 predictor, 1 + m corrector m: uniform per block
+    const int N = p.N, d = p.d, C = p.C;
+    const int64_t per_it = p.B * N;
+    const int64_t total = per_it * p.n_iterations;
+    const int64_t rec_total = p.rec0 + (int64_t)p.M * p.rec1;
+    const uint32_t k0 = (uint32_t)p.rng.seed, k1 = (uint32_t)(p.rng.seed >> 32);
+    const uint32_t call8 = p.rng.call << 8;
+    const bool types = sub == 0 || p.types_in_corrector;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t it = t / per_it;
+        const int64_t item = t - it * per_it;                     // b * N + n
+        const int64_t b = item / N;
+        const int n = (int)(item - b * N);
+        const int i = p.start_index - 1 - (int)it;
+        const uint32_t draw = (uint32_t)(sub == 0 ? i + 1 : i) * p.rng.draw_stride + (uint32_t)sub;
+        float* rec = p.out + (it * p.B + b) * rec_total + (sub == 0 ? 0 : p.rec0 + (sub - 1) * p.rec1);
+        const u32x4 r = philox4x32_10((uint32_t)item, call8, draw, MDX_TAG_COORD, k0, k1);
+        float z0, z1, z2 = 0.0f, z3;
+        box_muller(r.v[0], r.v[1], z0, z1);
+        if (d > 2) box_muller(r.v[2], r.v[3], z2, z3);
+        rec[n * d] = z0;
+        if (d > 1) rec[n * d + 1] = z1;
+        if (d > 2) rec[n * d + 2] = z2;
+        if (types) {
+            for (int s4 = 0; s4 * 4 < C; ++s4) {
+                const u32x4 g = philox4x32_10((uint32_t)item, call8 | (uint32_t)s4, draw, MDX_TAG_GUMBEL, k0, k1);
+                for (int l = 0; l < 4 && s4 * 4 + l < C; ++l) rec[N * d + n * C + s4 * 4 + l] = gumbel_from_u(u01(g.v[l]));
+            }
+            if (p.greedy)
+                rec[N * d + N * C + n] = u01(philox4x32_10((uint32_t)item, call8, draw, MDX_TAG_BINARY, k0, k1).v[0]);
+        }
+    }
+}
 
 // One wavefront per structure, kMlpWaves structures per workgroup sharing one LDS image of the network's weights.
 // The composition, the activations and the network outputs of a structure stay in its wavefront's LDS region for
@@ -1029,11 +1085,25 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
             v.a_out = (int64_t*)r.a; v.x_out = (float*)r.x; v.l_out = (float*)r.l; v.p_out = nullptr;
             v.item0 = b * N;
             v.b = b;
+            constexpr int kPre = SPEC == 1 ? 1 : (MDX_MAX_CLASSES + 4);   // 64-lane fetches covering N (d + C + 1) floats
+            const int rec_total = p.rec0 + p.M * p.rec1;
             for (int it = 0; it < p.n_iterations; ++it) {
                 const int i = p.start_index - 1 - it;               // loop variable of the reference (:147)
                 for (int sub = 0; sub <= p.M; ++sub) {
                     const int mode = sub == 0 ? MDX_PREDICTOR : MDX_CORRECTOR;
                     const PcStep st = make_step(p.pc, mode, sub == 0 ? i + 1 : i, (uint32_t)sub);
+                    const int types = sub == 0 ? 1 : p.types_in_corrector;
+                    // this step's pre-drawn noise: fetched now, needed after the forward (the load's latency is hidden
+                    // behind it), handed to the update through LDS
+                    [[maybe_unused]] float pre[kPre];
+                    const int rec_len = types ? p.rec0 : N * d;
+                    if (p.noise) {
+                        const float* rec = p.noise + ((int64_t)it * p.pc.B + b) * rec_total +
+                                           (sub == 0 ? 0 : p.rec0 + (sub - 1) * p.rec1);
+#pragma unroll
+                        for (int j = 0; j < kPre; ++j)
+                            if (j * kWave + lane < rec_len) pre[j] = rec[j * kWave + lane];
+                    }
                     if (!(p.diag_skip & 1)) {
                         if constexpr (SPEC == 1 && LDS_WEIGHTS)
                             mlp_forward_regs(w, regs, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b, r.logits);
@@ -1041,8 +1111,16 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
                             mlp_forward_wave<LDS_WEIGHTS>(m, w, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a,
                                                           r.buf_b, r.logits, r.sx, r.sl);
                     }
-                    if (lane < G && !(p.diag_skip & 2))
-                        pc_update_structure<G>(p.pc, st, v, lane, sub == 0 ? 1 : p.types_in_corrector);
+                    if (p.noise) {
+#pragma unroll
+                        for (int j = 0; j < kPre; ++j)
+                            if (j * kWave + lane < rec_len) r.noise[j * kWave + lane] = pre[j];
+                        wave_sync();
+                        v.z_coord = (const float*)r.noise;
+                        v.gumbel = (const float*)(r.noise + N * d);
+                        v.u = p.pc.greedy ? (const float*)(r.noise + N * d + N * p.pc.C) : nullptr;
+                    }
+                    if (lane < G && !(p.diag_skip & 2)) pc_update_structure<G>(p.pc, st, v, lane, types);
                     wave_sync();
                 }
             }
@@ -1747,10 +1825,19 @@ int mdx_mlp_forward(const mdx_mlp_t* mlp_host, const int64_t* atom_types, const 
     return launch_status();
 }
 
+int64_t mdx_mlp_pc_sample_workspace_floats(const mdx_mlp_t* mlp_host, int number_of_corrector_steps,
+                                           int atom_type_transition_in_corrector, int n_iterations, int64_t batch)
+{
+    if (!mlp_host || number_of_corrector_steps < 0 || n_iterations < 0 || batch < 0) return -1;
+    const int64_t N = mlp_host->number_of_atoms, d = mlp_host->spatial_dimension, C = mlp_host->num_classes;
+    const int64_t rec0 = N * (d + C + 1), rec1 = atom_type_transition_in_corrector ? rec0 : N * d;
+    return (rec0 + number_of_corrector_steps * rec1) * batch * n_iterations;
+}
+
 int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_host, const mdx_pc_flags_t* f,
                       int number_of_corrector_steps, int atom_type_transition_in_corrector, int start_index,
                       int n_iterations, mdx_rng_t rng, int64_t batch, int64_t* atom_types, float* x, float* l,
-                      uint32_t* status, mdx_stream_t stream)
+                      float* noise_workspace, int64_t workspace_floats, uint32_t* status, mdx_stream_t stream)
 {
     const int ok = mlp_ok(mlp_host);
     if (ok != MDX_OK) return ok;
@@ -1761,6 +1848,24 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
     if ((int64_t)batch * mlp_host->number_of_atoms > 0xffffffffLL) return MDX_ERR_UNSUPPORTED;
     if (batch == 0 || n_iterations == 0) return MDX_OK;
     if (!atom_types || !x || !l) return MDX_ERR_INVALID_ARG;
+    if (noise_workspace) {
+        // as many iterations per launch as the workspace holds (one noise pre-pass + one persistent launch each)
+        const int64_t per_iteration = mdx_mlp_pc_sample_workspace_floats(mlp_host, number_of_corrector_steps,
+                                                                         atom_type_transition_in_corrector, 1, batch);
+        const int64_t fit = workspace_floats / per_iteration;
+        if (fit < 1) return MDX_ERR_INVALID_ARG;
+        if (fit < n_iterations) {
+            for (int done = 0; done < n_iterations;) {
+                const int n = (int)(n_iterations - done < fit ? n_iterations - done : fit);
+                const int rc = mdx_mlp_pc_sample(sched_host, mlp_host, f, number_of_corrector_steps,
+                                                 atom_type_transition_in_corrector, start_index - done, n, rng, batch,
+                                                 atom_types, x, l, noise_workspace, workspace_floats, status, stream);
+                if (rc != MDX_OK) return rc;
+                done += n;
+            }
+            return MDX_OK;
+        }
+    }
     const size_t per_wave = sizeof(float) * (size_t)mlp_wave_floats(*mlp_host);
     const size_t image = sizeof(float) * (size_t)mlp_offsets(*mlp_host).total;
     if (per_wave * kMlpWaves > kMlpLdsBudget) return MDX_ERR_UNSUPPORTED;
@@ -1785,12 +1890,26 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
     a.start_index = start_index;
     a.n_iterations = n_iterations;
     a.a = atom_types; a.x = x; a.l = l;
+    a.rec0 = pc.N * (pc.d + pc.C + 1);
+    a.rec1 = a.types_in_corrector ? a.rec0 : pc.N * pc.d;
+    a.noise = noise_workspace;
     if (const char* diag = getenv("MDX_DIAG_SKIP")) a.diag_skip = atoi(diag);
     int G = 1;
     while (G < pc.N) G <<= 1;
     const int64_t blocks = cdiv(batch, kMlpWaves);
     const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
     hipStream_t st = as_stream(stream);
+    if (noise_workspace) {
+        NoiseFillArgs nf{};
+        nf.rng = pc.rng;
+        nf.start_index = start_index; nf.n_iterations = n_iterations;
+        nf.types_in_corrector = a.types_in_corrector; nf.greedy = pc.greedy;
+        nf.B = batch; nf.N = pc.N; nf.d = pc.d; nf.C = pc.C; nf.rec0 = a.rec0; nf.rec1 = a.rec1; nf.M = a.M;
+        nf.out = noise_workspace;
+        hipLaunchKernelGGL(pc_noise_fill_kernel, dim3(flat_grid(batch * pc.N * n_iterations), a.M + 1), dim3(kBlock),
+                           0, st, nf);
+        if (hipGetLastError() != hipSuccess) return MDX_ERR_HIP;
+    }
     if (in_lds) {
         const size_t lds = per_wave * kMlpWaves + image;
         const char* generic = getenv("MDX_MLP_GENERIC");          // tests: force the generic instantiation

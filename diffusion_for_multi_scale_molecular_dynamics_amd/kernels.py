@@ -299,15 +299,44 @@ def mlp_forward(pack: MlpPack, atom_types, x, l, time, sigma):
     return logits, score_x, score_l
 
 
+_NOISE_WORKSPACE = {}                       # device -> float32 buffer reused by every fused-sampler launch
+NOISE_WORKSPACE_MAX_FLOATS = 1 << 28        # 1 GiB cap; longer segments are split into several launches by the library
+
+
+def noise_workspace(pack: "MlpPack", number_of_corrector_steps: int, atom_type_transition_in_corrector: bool,
+                    n_iterations: int, batch: int, device) -> torch.Tensor:
+    """The pre-drawn-noise buffer of mdx_mlp_pc_sample, sized by the library, grown on demand, owned here."""
+    need = lib().mdx_mlp_pc_sample_workspace_floats(C.byref(pack.c_struct), int(number_of_corrector_steps),
+                                                    int(bool(atom_type_transition_in_corrector)), int(n_iterations),
+                                                    int(batch))
+    if need < 0:
+        raise _hip.MdxError("mdx_mlp_pc_sample_workspace_floats: invalid argument")
+    per_iteration = need // max(int(n_iterations), 1)
+    need = max(min(need, NOISE_WORKSPACE_MAX_FLOATS), per_iteration, 1)
+    key = torch.device(device)
+    buf = _NOISE_WORKSPACE.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _NOISE_WORKSPACE[key] = torch.empty(need, dtype=F32, device=device)
+    return buf
+
+
 def mlp_pc_sample(sched: DeviceSchedule, pack: MlpPack, flags: PcFlags, number_of_corrector_steps: int,
                   atom_type_transition_in_corrector: bool, start_index: int, n_iterations: int, rng: Rng,
-                  atom_types, x, l, status):
-    """n_iterations x (predictor + M correctors) in one launch, composition updated in place."""
+                  atom_types, x, l, status, predrawn_noise: bool = True):
+    """n_iterations x (predictor + M correctors) in one launch, composition updated in place.
+
+    predrawn_noise: generate the segment's draws with the chip-filling pre-pass kernel into a workspace (default);
+    False: every wavefront draws in-kernel.  Both evaluate the same Philox specification: identical results."""
     B = x.shape[0]
+    work = None
+    if predrawn_noise and B > 0 and n_iterations > 0:
+        work = noise_workspace(pack, number_of_corrector_steps, atom_type_transition_in_corrector, n_iterations, B,
+                               x.device)
     rc = lib().mdx_mlp_pc_sample(C.byref(sched.c_struct), C.byref(pack.c_struct), C.byref(flags),
                                  int(number_of_corrector_steps), int(bool(atom_type_transition_in_corrector)),
                                  int(start_index), int(n_iterations), rng, B, ptr(atom_types, I64, "atom_types"),
-                                 ptr(x, F32, "x"), ptr(l, F32, "l"), ptr(status, I32, "status"), stream_handle())
+                                 ptr(x, F32, "x"), ptr(l, F32, "l"), ptr(work, F32, "noise_workspace"),
+                                 0 if work is None else work.numel(), ptr(status, I32, "status"), stream_handle())
     check(rc, "mdx_mlp_pc_sample")
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 1
+#define MDX_ABI_VERSION 2
 
 /* status codes */
 #define MDX_OK 0
@@ -247,12 +247,20 @@ MDX_API int mdx_mlp_forward(const mdx_mlp_t* mlp_host, const int64_t* atom_types
  * MLP score network: every wavefront owns one structure, keeps its composition in LDS, and runs
  * `n_iterations` x (predictor + M correctors) -- network forward and fused update -- without returning to the host.
  * Device RNG only (the Philox specification makes it equal, draw for draw, to the per-step kernels).
- * The first iteration's predictor has time index `start_index`; the composition is updated in place. */
+ * The first iteration's predictor has time index `start_index`; the composition is updated in place.
+ * noise_workspace (nullable, device, caller-owned, `workspace_floats` floats): when given, the draws of the segment
+ * are generated ahead of the loop by a chip-filling pre-pass kernel into this buffer (same Philox counters, same
+ * arithmetic => the same bits) and the persistent kernel only reads them; a workspace smaller than
+ * mdx_mlp_pc_sample_workspace_floats(...) splits the segment into several launches.  NULL: every wavefront draws
+ * in-kernel. */
+MDX_API int64_t mdx_mlp_pc_sample_workspace_floats(const mdx_mlp_t* mlp_host, int number_of_corrector_steps,
+                                                   int atom_type_transition_in_corrector, int n_iterations,
+                                                   int64_t batch);
 MDX_API int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_host,
                               const mdx_pc_flags_t* flags_host, int number_of_corrector_steps,
                               int atom_type_transition_in_corrector, int start_index, int n_iterations, mdx_rng_t rng,
-                              int64_t batch, int64_t* atom_types, float* x, float* l, uint32_t* status,
-                              mdx_stream_t stream);
+                              int64_t batch, int64_t* atom_types, float* x, float* l, float* noise_workspace,
+                              int64_t workspace_floats, uint32_t* status, mdx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * EGNN score network helpers (the forward stays a PyTorch module; these remove passes PyTorch cannot fuse).

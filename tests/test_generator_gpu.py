@@ -463,6 +463,40 @@ def test_fused_sampler_segments_compose(cuda):
     assert torch.equal(whole.A, comp.A) and torch.equal(whole.X, comp.X)
 
 
+@pytest.mark.parametrize("name,in_corrector", [("traj_mlp_c3", False), ("traj_mlp_c1", False), ("traj_mlp_c3", True)])
+def test_fused_sampler_predrawn_noise_equals_in_kernel_draws(cuda, name, in_corrector, monkeypatch):
+    """The noise pre-pass (chip-filling kernel + workspace) and the in-kernel draws evaluate the same Philox
+    specification: bit-identical trajectories; a workspace that holds only 3 iterations splits the segment."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    gen, npar, spar, _ = _build(name, cases.TRAJECTORIES, cuda, rng_mode="device", seed=5, fused_score_network=True,
+                                atom_type_transition_in_corrector=in_corrector)
+    T, M = npar.total_time_steps, spar.number_of_corrector_steps
+    with torch.no_grad():
+        gen._prepare(cuda)
+        gen._begin_call(cuda)
+        start = gen.initialize(19, cuda)
+        sched, pack = gen._prepare(cuda), gen.fused_pack(cuda)
+        outs = []
+        for mode in ("in_kernel", "predrawn", "predrawn_small_workspace"):
+            comp = RS.AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
+            if mode == "predrawn_small_workspace":
+                per_iteration = kernels.lib().mdx_mlp_pc_sample_workspace_floats(pack.c_struct, M, int(in_corrector), 1, 19)
+                monkeypatch.setattr(kernels, "NOISE_WORKSPACE_MAX_FLOATS", 3 * per_iteration)
+                kernels._NOISE_WORKSPACE.clear()
+            kernels.mlp_pc_sample(sched, pack, gen._flags(True), M, in_corrector, T, T, gen._rng(0), comp.A, comp.X,
+                                  comp.L, gen._status, predrawn_noise=mode != "in_kernel")
+            outs.append(comp)
+        monkeypatch.undo()
+        kernels._NOISE_WORKSPACE.clear()
+        assert kernels.noise_workspace(pack, M, in_corrector, T, 19, cuda).numel() == \
+            T * 19 * spar.number_of_atoms * ((3 + gen.num_classes + 1) * (1 + (M if in_corrector else 0))
+                                             + (0 if in_corrector else 3 * M))
+    for other in outs[1:]:
+        assert torch.equal(outs[0].A, other.A)
+        assert torch.equal(outs[0].X.view(torch.int32), other.X.view(torch.int32))
+    assert (outs[0].A != spar.num_atom_types).all()
+
+
 def test_fused_needs_mlp_and_device_rng(cuda):
     from diffusion_for_multi_scale_molecular_dynamics_amd._hip import MdxError
     gen, *_ = _build("traj_fake_c2", cases.TRAJECTORIES, cuda, rng_mode="device", seed=1, fused_score_network=True)
