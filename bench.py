@@ -246,6 +246,23 @@ def time_radius_graph(batch, w, device, launches=50):
                 edges_per_atom=n_edges / (batch * n))
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3    # dense fp32-input MFMA peak of MI355X (MI355X_MICROARCH.md; no xf32/TF32 on gfx950)
+
+
+def time_edge_gemm(n_edges, device, hidden=256, launches=10):
+    """The library GEMM that dominates the EGNN workloads (87 % of a C3 step): one hidden layer of the edge MLPs,
+    out[E,256] = SiLU(x[E,256] W^T + b) in fp32 through mdx_linear_act (hipBLASLt, SWISH_BIAS epilogue)."""
+    x = torch.randn(n_edges, hidden, device=device)
+    wgt = torch.randn(hidden, hidden, device=device) / hidden ** 0.5
+    bias = torch.zeros(hidden, device=device)
+    ms = time_launches(lambda: kernels.linear_act(x, wgt, bias, True), device, launches)
+    tflops = 2.0 * n_edges * hidden * hidden / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", achieved=round(tflops, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=round(tflops / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                kernel=f"hipBLASLt fp32 GEMM {n_edges} x {hidden} x {hidden} + bias + SiLU epilogue (library kernel, via "
+                       "mdx_linear_act; 36 of these per network forward)", avg_launch_us=round(ms * 1e3, 2))
+
+
 def cpu_baseline(w, name, budget_s=15.0, resampling=0):
     """The CPU oracle on this host's cores over a bounded sample of the same workload."""
     import nets as test_nets
@@ -379,7 +396,7 @@ def main():
         ms_per_step = elapsed * 1e3 / steps
         value = (batch * world) / ((T * ms_per_step + gather_ms) * 1e-3)
 
-        roofline = None
+        roofline = forward_gemm = None
         if rank == 0:
             if forward == "fused":
                 m = time_fused_kernel(gen, loop, batch, w, device)
@@ -387,6 +404,7 @@ def main():
                 m = time_update_kernel(gen, batch, w, device)
             else:
                 m = time_radius_graph(batch, w, device)
+                forward_gemm = time_edge_gemm(int(round(m["edges_per_atom"] * batch * w["n_atoms"])), device)
             achieved = m["bytes"] / (m["ms"] * 1e-3) / 1e9
             traffic = None          # HBM bytes per launch measured with PMC counters in a separate rocprofv3 pass
             try:
@@ -419,6 +437,8 @@ def main():
                    "parallelism": f"independent batches x{world}, one all-gather at the end"},
         "roofline": roofline,
     }
+    if forward_gemm is not None:      # EGNN workloads: the step is library-GEMM time; the hand-written kernels are < 1 %
+        result["forward_gemm"] = forward_gemm
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(w, args.workload, resampling=resampling)
     print(json.dumps(result), flush=True)
