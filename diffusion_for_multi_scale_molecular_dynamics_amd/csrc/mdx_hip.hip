@@ -843,17 +843,19 @@ __device__ __forceinline__ void load_mlp_regs(MlpRegs& R, const MlpWeightsLds& w
 template <int KQ>
 __device__ __forceinline__ float dot_regs(const lds_f4 (&wq)[KQ], lds_cf* in, float bias)
 {
+    // written on register PAIRS: (s0,s1) += w.xy * v.xy and (s2,s3) += w.zw * v.zw are one v_pk_fma_f32 each on the
+    // halves of the 16-byte LDS read as they stand (left to itself the vectoriser pairs (x,w) / (y,z) and spends
+    // three v_mov per quad re-packing the inputs).  Same four fmaf chains, same final sum.
+    typedef float f2 __attribute__((ext_vector_type(2)));
     lds_cf4* in4 = (lds_cf4*)in;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    f2 s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f};
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
         const lds_f4 v = in4[q];
-        s0 = __builtin_fmaf(wq[q].x, v.x, s0);
-        s1 = __builtin_fmaf(wq[q].y, v.y, s1);
-        s2 = __builtin_fmaf(wq[q].z, v.z, s2);
-        s3 = __builtin_fmaf(wq[q].w, v.w, s3);
+        s01 = __builtin_elementwise_fma(wq[q].xy, v.xy, s01);
+        s23 = __builtin_elementwise_fma(wq[q].zw, v.zw, s23);
     }
-    return ((s0 + s1) + (s2 + s3)) + bias;
+    return ((s01.x + s01.y) + (s23.x + s23.y)) + bias;
 }
 
 __device__ __forceinline__ float silu_(float a) { return a / (1.0f + expf_(-a)); }
