@@ -3,8 +3,9 @@
 The predictor only updates the atom types; each corrector step uses
     eps = 2 (r * mean|z| / (mean|sigma s| / sigma))^2
 with batch means, so the step needs two reductions over the batch (torch, on the device) before the update kernel
-(P1 with explicit scalars).  Not one of the BASELINE configurations; sharding a batch over ranks changes the batch
-means (SURVEY 8e caveat) -- this generator is single-device.
+(P1 with explicit scalars).  Not one of the BASELINE configurations.  Sharding a batch over ranks changes the batch
+means (SURVEY 8e caveat): with `sync_batch_statistics: true` the two means are taken over every rank's shard through one
+4-scalar all-reduce per corrector step (utils/batch_statistics.py), which reproduces the un-sharded step sizes.
 """
 from typing import Optional
 
@@ -15,6 +16,7 @@ from .._hip import MDX_CORRECTOR, MDX_PREDICTOR, TAG_COORD, TAG_LATTICE, MdxErro
 from ..models.score_networks.score_network import ScoreNetwork
 from ..namespace import AXL
 from ..noise_schedulers.noise_parameters import NoiseParameters
+from ..utils.batch_statistics import global_means
 from .langevin_generator import LangevinGenerator
 from .predictor_corrector_axl_generator import PredictorCorrectorSamplingParameters
 from .trajectory_initializer import TrajectoryInitializer
@@ -26,6 +28,7 @@ class AdaptiveCorrectorGenerator(LangevinGenerator):
         super().__init__(noise_parameters=noise_parameters, sampling_parameters=sampling_parameters,
                          axl_network=axl_network, trajectory_initializer=trajectory_initializer)
         self.corrector_r = noise_parameters.corrector_r
+        self.sync_batch_statistics = bool(getattr(sampling_parameters, "sync_batch_statistics", False))
         if self.use_hip_graph or self.fused_score_network:
             raise MdxError("the adaptive corrector needs batch reductions between the forward and the update: "
                            "use_hip_graph / fused_score_network do not apply")
@@ -76,8 +79,9 @@ class AdaptiveCorrectorGenerator(LangevinGenerator):
     def _step_size(self, sigma, sigma_normalized_score, z, coordinates: bool) -> torch.Tensor:
         """eps_i (:97-148): norms over (atoms, space) per structure for the score, over the last axis for z."""
         dims = [-2, -1] if coordinates else -1
-        score_norm = torch.linalg.norm(sigma_normalized_score, dim=dims).mean() / sigma
-        z_norm = torch.linalg.norm(z, dim=-1).mean()
+        score_mean, z_norm = global_means(torch.linalg.norm(sigma_normalized_score, dim=dims),
+                                          torch.linalg.norm(z, dim=-1), self.sync_batch_statistics)
+        score_norm = score_mean / sigma
         return 2 * (self.corrector_r * z_norm / score_norm.clip(min=self.small_epsilon)) ** 2
 
     def corrector_step(self, composition_i: AXL, index_i: int, cartesian_forces: torch.Tensor,

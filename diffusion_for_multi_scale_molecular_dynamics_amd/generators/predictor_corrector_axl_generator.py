@@ -29,6 +29,7 @@ class PredictorCorrectorSamplingParameters(SamplingParameters):
     use_hip_graph: bool = False      # device mode: capture one predictor+correctors iteration and replay it
     fused_score_network: bool = False  # device mode + MLPScoreNetwork: network forward and update fused in ONE
     #                                    persistent kernel that runs the whole loop (mdx_mlp_pc_sample)
+    sync_batch_statistics: bool = False  # adaptive_corrector under torchrun: batch means over every rank's shard
     repaint_resampling_steps: int = 0  # ConstrainedLangevinGenerator only (RePaint, arXiv:2201.09865, algorithm 1 with
     #                                    jump length 1): at every time index i > 0 the reverse step i+1 -> i is followed
     #                                    by this many (forward step i -> i+1, reverse step i+1 -> i) pairs.  0 = the
