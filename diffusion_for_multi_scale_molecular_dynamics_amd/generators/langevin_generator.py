@@ -25,7 +25,7 @@ from ..models.score_networks.score_network import ScoreNetwork
 from ..namespace import AXL, CARTESIAN_FORCES, NOISE, NOISY_AXL_COMPOSITION, TIME
 from ..noise_schedulers.noise_parameters import NoiseParameters
 from ..noise_schedulers.noise_scheduler import NoiseScheduler
-from ..utils.sample_trajectory import SampleTrajectory
+from ..utils.sample_trajectory import PinnedStaging, SampleTrajectory
 from .noise_sources import DevicePhiloxNoise, ReferenceOrderNoise
 from .predictor_corrector_axl_generator import PredictorCorrectorAXLGenerator, PredictorCorrectorSamplingParameters
 from .trajectory_initializer import TrajectoryInitializer
@@ -77,6 +77,7 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         self._buffers = {}
         if self.record:
             self.sample_trajectory_recorder = SampleTrajectory()
+            self._staging = PinnedStaging()
             self.sample_trajectory_recorder.record(key="noise_parameters", entry=dataclasses.asdict(noise_parameters))
             self.sample_trajectory_recorder.record(key="sampling_parameters",
                                                    entry={k: v for k, v in dataclasses.asdict(sp).items()})
@@ -237,8 +238,9 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
             all_masked = (a_in == self.masked_atom_type_index).all(dim=-1)
             gumbel = torch.where(all_masked.view(-1, 1, 1), gumbel, torch.zeros_like(gumbel))
         self.sample_trajectory_recorder.record(key="atom_type_update", entry=dict(
-            predicted_logits=logits.detach().cpu(), one_step_transition_probabilities=probs.cpu(),
-            gumbel_sample=gumbel.cpu(), a_i=a_in.cpu(), a_im1=a_out.cpu()))
+            predicted_logits=self._staging.to_host(logits), one_step_transition_probabilities=self._staging.to_host(probs),
+            gumbel_sample=self._staging.to_host(gumbel), a_i=self._staging.to_host(a_in),
+            a_im1=self._staging.to_host(a_out)))
 
     def predictor_step(self, composition_i: AXL, index_i: int, cartesian_forces: torch.Tensor) -> AXL:
         """composition at time index i -> i-1  (langevin_generator.py:536-645)."""
@@ -266,7 +268,10 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
     def _record_step(self, key, names, axls, index_i):
         entry = dict(time_step_index=index_i)
         for name, axl in zip(names, axls):
-            entry[name] = AXL(A=axl.A.detach().cpu(), X=axl.X.detach().cpu(), L=axl.L.detach().cpu())
+            # asynchronous copies into page-locked memory, ordered on the sampling stream before any later in-place
+            # update of these tensors; complete when sample() synchronises to read the status word
+            host = self._staging.to_host
+            entry[name] = AXL(A=host(axl.A), X=host(axl.X), L=host(axl.L))
         self.sample_trajectory_recorder.record(key=key, entry=entry)
 
     # ---------------------------------------------------------------------------------------------------------

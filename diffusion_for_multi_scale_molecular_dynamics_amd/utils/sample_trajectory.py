@@ -5,6 +5,47 @@ from typing import Any, Dict, NamedTuple, Union
 import torch
 
 
+def _compact(obj):
+    if isinstance(obj, torch.Tensor):
+        return obj.clone() if obj.untyped_storage().nbytes() > obj.numel() * obj.element_size() else obj
+    if isinstance(obj, tuple) and hasattr(obj, "_fields"):
+        return type(obj)(*[_compact(v) for v in obj])
+    if isinstance(obj, dict):
+        return {k: _compact(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_compact(v) for v in obj)
+    return obj
+
+
+class PinnedStaging:
+    """Host side of the recorder's device-to-host copies: page-locked memory taken in large chunks, so that recording a
+    step is a handful of ASYNCHRONOUS copies on the sampling stream (no host synchronisation per step, which is what
+    `.cpu()` costs); the copies are complete once the stream has been synchronised -- LangevinGenerator.sample() does
+    that when it reads the status word.  The recorded tensors are views into the chunks and keep them alive."""
+
+    CHUNK_BYTES = 32 << 20
+
+    def __init__(self):
+        self._chunk = None
+        self._used = 0
+
+    def to_host(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.detach()
+        if not t.is_cuda:
+            return t.clone()
+        n = t.numel() * t.element_size()
+        if n == 0:
+            return torch.empty(t.shape, dtype=t.dtype)
+        start = (self._used + 63) & ~63
+        if self._chunk is None or start + n > self._chunk.numel():
+            self._chunk = torch.empty(max(self.CHUNK_BYTES, n), dtype=torch.uint8, pin_memory=True)
+            start = 0
+        self._used = start + n
+        host = self._chunk[start:start + n].view(t.dtype).view(t.shape)
+        host.copy_(t if t.is_contiguous() else t.contiguous(), non_blocking=True)
+        return host
+
+
 class SampleTrajectory:
     def __init__(self):
         self._internal_data = defaultdict(list)
@@ -16,10 +57,13 @@ class SampleTrajectory:
         self._internal_data[key].append(entry)
 
     def write_to_pickle(self, path_to_pickle: str):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()          # the recorder's asynchronous device-to-host copies (PinnedStaging)
         data = dict(self._internal_data)
         for key, value in data.items():
             if len(value) == 1:
                 data[key] = value[0]
+        data = _compact(data)                 # views into the staging chunks -> tensors that own exactly their bytes
         self._internal_data = data
         with open(path_to_pickle, "wb") as fd:
             torch.save(data, fd)
