@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
     "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_mlp_forward",
-    "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input",
+    "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
     "mdx_rng_fill", "mdx_math_probe",
 )
 MLP_MAX_HIDDEN = 8
@@ -151,6 +151,10 @@ def _declare(L):
     L.mdx_linear_act.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, u64, vp]
     L.mdx_egnn_message_input.restype = i32
     L.mdx_egnn_message_input.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]
+    L.mdx_egnn_coord_head.restype = i32
+    L.mdx_egnn_coord_head.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]
+    L.mdx_segment_rows.restype = i32
+    L.mdx_segment_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp]
     L.mdx_rng_fill.restype = i32
     L.mdx_rng_fill.argtypes = [i32, u64, u32, u32, u32, i64, i32, vp, vp]
     L.mdx_math_probe.restype = i32

@@ -53,6 +53,67 @@ __global__ __launch_bounds__(kBlock) void egnn_message_input_kernel(const float*
     }
 }
 
+// Segment kernels on the radius graph's sorted edge list (edges of node i are rows [offset_i, offset_i + degree_i)):
+// one wavefront per node, a row of H floats read as 16-byte lane loads (H = 256: one fully coalesced 1-KB row per
+// instruction), four rows in flight.  No atomics; the summation order is fixed (edge order), run-to-run deterministic.
+constexpr int kWave = 64;
+
+// trans[i, :] = scale_i * sum_e coord_diff[e, :] * (hidden[e, :] . w)      -- last layer of E_GCL.coord_model
+// (Linear(H, 1, bias=False), models/egnn.py:162-200) + the multiplication with coord_diff + the segment sum/mean
+__global__ __launch_bounds__(kBlock) void egnn_coord_head_kernel(const float* __restrict__ hidden, const float* __restrict__ w,
+                                                                 const float* __restrict__ coord_diff,
+                                                                 const int64_t* __restrict__ offsets,
+                                                                 const int64_t* __restrict__ degree, int64_t n_nodes, int H,
+                                                                 int d, int mean, float* __restrict__ trans)
+{
+    const int lane = threadIdx.x % kWave;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / kWave;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) / kWave;
+    const int quads = H >> 2;
+    for (int64_t node = wave; node < n_nodes; node += n_waves) {
+        const int64_t e0 = offsets[node], deg = degree[node];
+        float acc = 0.0f;                                   // lane k < d: component k of the node's translation
+        for (int64_t e = e0; e < e0 + deg; ++e) {
+            float part = 0.0f;
+            for (int q = lane; q < quads; q += kWave) {
+                const float4 hv = reinterpret_cast<const float4*>(hidden + e * H)[q];
+                const float4 wv = reinterpret_cast<const float4*>(w)[q];
+                part += (hv.x * wv.x + hv.y * wv.y) + (hv.z * wv.z + hv.w * wv.w);
+            }
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
+            if (lane < d) acc += coord_diff[e * d + lane] * part;
+        }
+        if (lane < d) trans[node * d + lane] = (mean && deg > 0) ? acc * (1.0f / (float)deg) : acc;
+    }
+}
+
+// out[i, :] = scale_i * sum_e data[e, :]                                     -- unsorted_segment_sum/mean of the messages
+// (models/egnn_utils.py:11-70) for sorted segments
+__global__ __launch_bounds__(kBlock) void segment_rows_kernel(const float* __restrict__ data, const int64_t* __restrict__ offsets,
+                                                              const int64_t* __restrict__ degree, int64_t n_nodes, int H, int mean,
+                                                              float* __restrict__ out)
+{
+    const int lane = threadIdx.x % kWave;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / kWave;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) / kWave;
+    const int quads = H >> 2;
+    for (int64_t node = wave; node < n_nodes; node += n_waves) {
+        const int64_t e0 = offsets[node], deg = degree[node];
+        const float scale = (mean && deg > 0) ? 1.0f / (float)deg : 1.0f;
+        for (int q = lane; q < quads; q += kWave) {
+            float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+            for (int64_t e = e0; e < e0 + deg; ++e) {
+                const float4 v = reinterpret_cast<const float4*>(data + e * H)[q];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            if (mean) { acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale; }
+            reinterpret_cast<float4*>(out + node * H)[q] = acc;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -140,6 +201,38 @@ int mdx_egnn_message_input(const float* node_proj, const int64_t* edges, const f
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(egnn_message_input_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream),
                        node_proj, edges, radial, bias, w_radial, n_edges, H, silu, out);
+    return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
+}
+
+static unsigned node_grid(int64_t n_nodes)
+{
+    int64_t blocks = (n_nodes * kWave + kBlock - 1) / kBlock;       // one wavefront per node
+    if (blocks > 16384) blocks = 16384;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+int mdx_egnn_coord_head(const float* hidden, const float* w_out, const float* coord_diff, const int64_t* offsets,
+                        const int64_t* degree, int64_t n_nodes, int H, int spatial_dimension, int mean, float* trans,
+                        mdx_stream_t stream)
+{
+    if (n_nodes < 0 || H < 4 || spatial_dimension < 1) return MDX_ERR_INVALID_ARG;
+    if ((H & 3) || spatial_dimension > kWave) return MDX_ERR_UNSUPPORTED;      // one lane per coordinate component
+    if (n_nodes == 0) return MDX_OK;
+    if (!hidden || !w_out || !coord_diff || !offsets || !degree || !trans) return MDX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(egnn_coord_head_kernel, dim3(node_grid(n_nodes)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream),
+                       hidden, w_out, coord_diff, offsets, degree, n_nodes, H, spatial_dimension, mean, trans);
+    return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
+}
+
+int mdx_segment_rows(const float* data, const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int H, int mean,
+                     float* out, mdx_stream_t stream)
+{
+    if (n_nodes < 0 || H < 4) return MDX_ERR_INVALID_ARG;
+    if (H & 3) return MDX_ERR_UNSUPPORTED;
+    if (n_nodes == 0) return MDX_OK;
+    if (!data || !offsets || !degree || !out) return MDX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(segment_rows_kernel, dim3(node_grid(n_nodes)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream),
+                       data, offsets, degree, n_nodes, H, mean, out);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 

@@ -397,6 +397,31 @@ def egnn_message_input(node_proj, edges, radial, bias, w_radial, silu: bool = Tr
     return out
 
 
+def egnn_coord_head(hidden, w_out, coord_diff, offsets, degree, mean: bool) -> torch.Tensor:
+    """Last coordinate-MLP layer (H -> 1, no bias) x coord_diff, summed (or averaged) over each node's sorted edges."""
+    n_nodes, H, d = degree.shape[0], hidden.shape[1], coord_diff.shape[1]
+    if hidden.shape[0] == 0:                                   # no edges at all
+        return torch.zeros(n_nodes, d, dtype=F32, device=hidden.device)
+    trans = torch.empty(n_nodes, d, dtype=F32, device=hidden.device)
+    rc = lib().mdx_egnn_coord_head(ptr(hidden, F32, "hidden"), ptr(w_out, F32, "w_out"), ptr(coord_diff, F32, "coord_diff"),
+                                   ptr(offsets, I64, "offsets"), ptr(degree, I64, "degree"), n_nodes, H, d,
+                                   int(bool(mean)), ptr(trans, F32, "trans"), stream_handle())
+    check(rc, "mdx_egnn_coord_head")
+    return trans
+
+
+def segment_rows(data, offsets, degree, mean: bool) -> torch.Tensor:
+    """Sum (or mean) of the rows of data [E,H] over each node's sorted edge segment -> [n_nodes, H]."""
+    n_nodes, H = degree.shape[0], data.shape[1]
+    if data.shape[0] == 0:
+        return torch.zeros(n_nodes, H, dtype=F32, device=data.device)
+    out = torch.empty(n_nodes, H, dtype=F32, device=data.device)
+    rc = lib().mdx_segment_rows(ptr(data, F32, "data"), ptr(offsets, I64, "offsets"), ptr(degree, I64, "degree"), n_nodes,
+                                H, int(bool(mean)), ptr(out, F32, "out"), stream_handle())
+    check(rc, "mdx_segment_rows")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # RNG fills / probes
 # ----------------------------------------------------------------------------------------------------------------

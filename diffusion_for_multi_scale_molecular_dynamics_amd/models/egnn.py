@@ -6,7 +6,10 @@ Written for sorted edge lists (edges grouped by source node, which is what the H
 get_edges_batch produce):
   * segment sums over sorted edges use torch.segment_reduce -- no atomics, run-to-run deterministic;
   * the first message layer is applied per NODE and gathered per edge (W [h_i | h_j | r] = W_i h_i + W_j h_j + w_r r),
-    which removes the [E, 2H+1] concatenation and 2/5 of the message-MLP FLOPs.
+    which removes the [E, 2H+1] concatenation and 2/5 of the message-MLP FLOPs;
+  * on device tensors the two per-node reductions run as one-wavefront-per-node HIP kernels over the sorted segments
+    (kernels.segment_rows for the messages; kernels.egnn_coord_head = last coordinate layer H -> 1, product with
+    coord_diff and segment mean in one pass over the [E, H] activations).
 """
 from typing import Callable, Optional, Tuple
 
@@ -111,9 +114,16 @@ class E_GCL(nn.Module):
             out = out * self.att_mlp(out)
         return out
 
+    def _coord_head_is_plain(self) -> bool:
+        last = self.coord_mlp[-1]
+        return isinstance(last, nn.Linear) and last.out_features == 1 and last.bias is None and \
+            last.in_features % 4 == 0 and len(self.coord_mlp) >= 2 and isinstance(self.coord_mlp[-2], nn.SiLU)
+
     def forward(self, h: torch.Tensor, edge_index: torch.Tensor, coord: torch.Tensor,
-                degree: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """h [n_nodes, F]; edge_index [E, 2] sorted by column 0; coord [n_nodes, D]; degree [n_nodes] edge counts."""
+                degree: Optional[torch.Tensor] = None, offsets: Optional[torch.Tensor] = None
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """h [n_nodes, F]; edge_index [E, 2] sorted by column 0; coord [n_nodes, D]; degree [n_nodes] edge counts;
+        offsets [n_nodes] = exclusive scan of degree (enables the segment kernels on device tensors)."""
         row, col = edge_index[:, 0], edge_index[:, 1]
         if degree is None:
             degree = torch.bincount(row, minlength=h.shape[0])
@@ -127,12 +137,23 @@ class E_GCL(nn.Module):
         fused = self.use_fused_ops and h.is_cuda
         messages = self._messages(h, edge_index, radial, fused)
 
-        trans = segment_sum_sorted(coord_diff * run_mlp(self.coord_mlp, messages, fused), degree)
-        coord = coord + (trans * inv_deg if self.coords_mean else trans)
+        segments = fused and offsets is not None and messages.shape[1] % 4 == 0
+        if segments and self._coord_head_is_plain():
+            from .. import kernels
+            hidden = run_mlp(list(self.coord_mlp)[:-1], messages, fused)
+            coord = coord + kernels.egnn_coord_head(hidden.contiguous(), self.coord_mlp[-1].weight.reshape(-1),
+                                                    coord_diff.contiguous(), offsets, degree, self.coords_mean)
+        else:
+            trans = segment_sum_sorted(coord_diff * run_mlp(self.coord_mlp, messages, fused), degree)
+            coord = coord + (trans * inv_deg if self.coords_mean else trans)
 
-        agg = segment_sum_sorted(messages, degree)
-        if self.message_mean:
-            agg = agg * inv_deg
+        if segments:
+            from .. import kernels
+            agg = kernels.segment_rows(messages.contiguous(), offsets, degree, self.message_mean)
+        else:
+            agg = segment_sum_sorted(messages, degree)
+            if self.message_mean:
+                agg = agg * inv_deg
         out = run_mlp(self.node_mlp, torch.cat([h, agg], dim=1), fused)
         if self.residual:
             out = h + out
@@ -170,6 +191,7 @@ class EGNN(nn.Module):
         h = self.embedding_in(h)
         if degree is None:
             degree = torch.bincount(edges[:, 0], minlength=h.shape[0])
+        offsets = (torch.cumsum(degree, 0) - degree) if h.is_cuda else None
         for layer in self.graph_layers:
-            h, x = layer(h, edges, x, degree)
+            h, x = layer(h, edges, x, degree, offsets)
         return AXL(A=self.node_classification_layer(h), X=x, L=torch.zeros_like(x))

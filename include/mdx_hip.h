@@ -282,6 +282,21 @@ MDX_API int mdx_egnn_message_input(const float* node_proj, const int64_t* edges,
                                    const float* w_radial, int64_t n_edges, int H, int silu, float* out,
                                    mdx_stream_t stream);
 
+/* Segment operations on the radius graph's SORTED edge list: the edges of node i are rows
+ * [offsets[i], offsets[i] + degree[i]) (what mdx_radius_graph_fill produces).  One wavefront per node, no atomics,
+ * fixed summation order.  H % 4 == 0.
+ * mdx_egnn_coord_head: trans[i,:] = (1/degree_i if mean) * sum_e coord_diff[e,:] * (hidden[e,:] . w_out) -- the last
+ *   layer of E_GCL.coord_model (nn.Linear(H, 1, bias=False), models/egnn.py:162-200), the product with coord_diff and
+ *   unsorted_segment_sum / _mean (models/egnn_utils.py:11-70) in one pass over hidden [E,H]; coord_diff [E,d] with
+ *   d <= 64 (the EGNN works on uplifted coordinates, d = 6 for three spatial dimensions).
+ * mdx_segment_rows: out[i,:] = (1/degree_i if mean) * sum_e data[e,:] -- the message aggregation of E_GCL.node_model
+ *   (models/egnn.py:202-230). */
+MDX_API int mdx_egnn_coord_head(const float* hidden, const float* w_out, const float* coord_diff, const int64_t* offsets,
+                                const int64_t* degree, int64_t n_nodes, int H, int spatial_dimension, int mean,
+                                float* trans, mdx_stream_t stream);
+MDX_API int mdx_segment_rows(const float* data, const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int H,
+                             int mean, float* out, mdx_stream_t stream);
+
 /* Device-RNG draws as stand-alone fills (trajectory initialisation, tests of the RNG specification).
  * kind 0 = uniform (0,1), 1 = standard normal, 2 = Gumbel(0,1).  out [n_items, width]. */
 MDX_API int mdx_rng_fill(int kind, uint64_t seed, uint32_t call, uint32_t draw, uint32_t tag, int64_t n_items, int width,
