@@ -73,17 +73,26 @@ __global__ __launch_bounds__(kBlock) void egnn_coord_head_kernel(const float* __
     for (int64_t node = wave; node < n_nodes; node += n_waves) {
         const int64_t e0 = offsets[node], deg = degree[node];
         float acc = 0.0f;                                   // lane k < d: component k of the node's translation
-        for (int64_t e = e0; e < e0 + deg; ++e) {
+        auto row_dot = [&](int64_t e) {                     // this lane's share of hidden[e, :] . w
             float part = 0.0f;
             for (int q = lane; q < quads; q += kWave) {
                 const float4 hv = reinterpret_cast<const float4*>(hidden + e * H)[q];
                 const float4 wv = reinterpret_cast<const float4*>(w)[q];
                 part += (hv.x * wv.x + hv.y * wv.y) + (hv.z * wv.z + hv.w * wv.w);
             }
+            return part;
+        };
+        auto finish = [&](int64_t e, float part) {
 #pragma unroll
             for (int o = kWave / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
             if (lane < d) acc += coord_diff[e * d + lane] * part;
+        };
+        int64_t e = e0;
+        for (; e + 4 <= e0 + deg; e += 4) {                 // four rows in flight; edges still accumulated in order
+            const float p0 = row_dot(e), p1 = row_dot(e + 1), p2 = row_dot(e + 2), p3 = row_dot(e + 3);
+            finish(e, p0); finish(e + 1, p1); finish(e + 2, p2); finish(e + 3, p3);
         }
+        for (; e < e0 + deg; ++e) finish(e, row_dot(e));
         if (lane < d) trans[node * d + lane] = (mean && deg > 0) ? acc * (1.0f / (float)deg) : acc;
     }
 }
