@@ -188,7 +188,16 @@ class EGNN(nn.Module):
 
     def forward(self, h: torch.Tensor, edges: torch.Tensor, x: torch.Tensor,
                 degree: Optional[torch.Tensor] = None) -> AXL:
-        h = self.embedding_in(h)
+        emb = self.embedding_in
+        if h.is_cuda and emb.in_features <= 8:
+            # [sigma | one-hot type] -> hidden: with 2-4 input features the library GEMM spends 0.45 ms on a K = 3
+            # problem; as rank-1 updates it is a few elementwise passes over [n_nodes, hidden]
+            out = emb.bias.unsqueeze(0) + h[:, :1] * emb.weight[:, 0].unsqueeze(0)
+            for k in range(1, emb.in_features):
+                out = torch.addcmul(out, h[:, k:k + 1], emb.weight[:, k].unsqueeze(0))
+            h = out
+        else:
+            h = emb(h)
         if degree is None:
             degree = torch.bincount(edges[:, 0], minlength=h.shape[0])
         offsets = (torch.cumsum(degree, 0) - degree) if h.is_cuda else None
