@@ -1,4 +1,8 @@
-"""Generator factory (src/.../generators/instantiate_generator.py:25-82)."""
+"""From a `sampling.algorithm` string to a generator object (reference: generators/instantiate_generator.py:25-82).
+
+The MI355X hot path covers the predictor-corrector family; the reference's torchsde / ODE samplers are named in the
+accepted list (so that a typo and an unsupported choice give different errors) but are not built here.
+"""
 from typing import Optional
 
 from ..models.score_networks.score_network import ScoreNetwork
@@ -10,24 +14,20 @@ from .langevin_generator import LangevinGenerator
 from .sampling_constraint import SamplingConstraint
 from .trajectory_initializer import TrajectoryInitializer
 
+_KNOWN_ALGORITHMS = ("ode", "sde", "predictor_corrector", "adaptive_corrector")
+_BUILT = {"predictor_corrector": LangevinGenerator, "adaptive_corrector": AdaptiveCorrectorGenerator}
+
 
 def instantiate_generator(sampling_parameters: SamplingParameters, noise_parameters: NoiseParameters,
                           axl_network: ScoreNetwork, trajectory_initializer: TrajectoryInitializer,
                           sampling_constraints: Optional[SamplingConstraint] = None):
-    assert sampling_parameters.algorithm in ["ode", "sde", "predictor_corrector", "adaptive_corrector"], \
-        "Unknown algorithm. Possible choices are 'ode', 'sde', 'predictor_corrector' and 'adaptive_corrector'"
-    if sampling_constraints is not None:
-        assert sampling_parameters.algorithm == "predictor_corrector", \
-            "Only the 'predictor_corrector' scheme supports sampling constraints."
-        return ConstrainedLangevinGenerator(noise_parameters=noise_parameters,
-                                            sampling_parameters=sampling_parameters, axl_network=axl_network,
-                                            sampling_constraints=sampling_constraints,
-                                            trajectory_initializer=trajectory_initializer)
-    if sampling_parameters.algorithm == "predictor_corrector":
-        return LangevinGenerator(sampling_parameters=sampling_parameters, noise_parameters=noise_parameters,
-                                 axl_network=axl_network, trajectory_initializer=trajectory_initializer)
-    if sampling_parameters.algorithm == "adaptive_corrector":
-        return AdaptiveCorrectorGenerator(sampling_parameters=sampling_parameters, noise_parameters=noise_parameters,
-                                          axl_network=axl_network, trajectory_initializer=trajectory_initializer)
-    raise NotImplementedError(f"algorithm '{sampling_parameters.algorithm}' is outside the MI355X hot path "
-                              "(SURVEY.md section 8)")
+    algorithm = sampling_parameters.algorithm
+    assert algorithm in _KNOWN_ALGORITHMS, f"Unknown algorithm '{algorithm}'; choose one of {_KNOWN_ALGORITHMS}."
+    common = dict(noise_parameters=noise_parameters, sampling_parameters=sampling_parameters, axl_network=axl_network,
+                  trajectory_initializer=trajectory_initializer)
+    if sampling_constraints is not None:        # repaint
+        assert algorithm == "predictor_corrector", "sampling constraints need the 'predictor_corrector' algorithm."
+        return ConstrainedLangevinGenerator(sampling_constraints=sampling_constraints, **common)
+    if algorithm not in _BUILT:
+        raise NotImplementedError(f"algorithm '{algorithm}' is outside the MI355X hot path (SURVEY.md section 8)")
+    return _BUILT[algorithm](**common)

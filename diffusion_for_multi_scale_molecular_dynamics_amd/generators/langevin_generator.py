@@ -283,10 +283,7 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
 
     def sample_from_noisy_composition(self, starting_noisy_composition: AXL, starting_step_index: int,
                                       ending_step_index: int) -> AXL:
-        assert starting_step_index > ending_step_index, \
-            "It is nonsensical for starting_step_index to be smaller or equal to ending_step_index."
-        assert starting_step_index > 0, "Starting step should be larger than zero."
-        assert ending_step_index >= 0, "ending step should be larger or equal to zero."
+        self._check_index_range(starting_step_index, ending_step_index)
         self._prepare(starting_noisy_composition.X.device)
         if self.noise_source is None:
             self._begin_call(starting_noisy_composition.X.device)

@@ -37,55 +37,60 @@ class PredictorCorrectorSamplingParameters(SamplingParameters):
 
 
 class PredictorCorrectorAXLGenerator(AXLGenerator):
-    """for i in T-1..0: predictor(i+1); M x corrector(i)."""
+    """Skeleton of the sampler: walk the time index down from the initialiser's start to its end; at each index take one
+    predictor step (i+1 -> i) followed by the corrector steps at i.  Subclasses provide the two steps."""
 
     def __init__(self, number_of_discretization_steps: int, number_of_corrector_steps: int, spatial_dimension: int,
                  num_atom_types: int, number_of_atoms: int, use_fixed_lattice_parameters: bool = False,
                  fixed_lattice_parameters: Optional[torch.Tensor] = None,
                  trajectory_initializer: Optional[TrajectoryInitializer] = None, **kwargs):
-        assert number_of_discretization_steps > 1, "The number of discretization steps should be larger than one"
-        assert number_of_corrector_steps >= 0, "The number of corrector steps should be non-negative"
+        assert number_of_discretization_steps > 1, "at least two discretization steps are needed"
+        assert number_of_corrector_steps >= 0, "the number of corrector steps cannot be negative"
         self.number_of_discretization_steps = number_of_discretization_steps
         self.number_of_corrector_steps = number_of_corrector_steps
         self.spatial_dimension = spatial_dimension
-        self.num_classes = num_atom_types + 1
+        self.num_classes = num_atom_types + 1                       # the real types + MASK
         self.num_lattice_parameters = get_number_of_lattice_parameters(spatial_dimension)
-        if trajectory_initializer is not None:
-            self.trajectory_initializer = trajectory_initializer
-        else:
-            self.trajectory_initializer = FullRandomTrajectoryInitializer(TrajectoryInitializerParameters(
+        if trajectory_initializer is None:                          # default start: pure noise at index T
+            trajectory_initializer = FullRandomTrajectoryInitializer(TrajectoryInitializerParameters(
                 spatial_dimension=spatial_dimension, num_atom_types=num_atom_types, number_of_atoms=number_of_atoms,
                 use_fixed_lattice_parameters=use_fixed_lattice_parameters,
                 fixed_lattice_parameters=fixed_lattice_parameters))
+        self.trajectory_initializer = trajectory_initializer
 
     def initialize(self, number_of_samples: int, device: torch.device) -> AXL:
         return self.trajectory_initializer.initialize(number_of_samples, device)
 
     def sample(self, number_of_samples: int, device: torch.device) -> AXL:
-        start = self.initialize(number_of_samples, device)
-        first = self.trajectory_initializer.create_start_time_step_index(self.number_of_discretization_steps)
-        last = self.trajectory_initializer.create_end_time_step_index()
-        return self.sample_from_noisy_composition(starting_noisy_composition=start, starting_step_index=first,
-                                                  ending_step_index=last)
+        initializer = self.trajectory_initializer
+        return self.sample_from_noisy_composition(
+            starting_noisy_composition=self.initialize(number_of_samples, device),
+            starting_step_index=initializer.create_start_time_step_index(self.number_of_discretization_steps),
+            ending_step_index=initializer.create_end_time_step_index())
+
+    @staticmethod
+    def _check_index_range(starting_step_index: int, ending_step_index: int):
+        assert starting_step_index > ending_step_index, "the starting index must be above the ending index."
+        assert starting_step_index > 0, "the starting index must be positive."
+        assert ending_step_index >= 0, "the ending index cannot be negative."
 
     def sample_from_noisy_composition(self, starting_noisy_composition: AXL, starting_step_index: int,
                                       ending_step_index: int) -> AXL:
-        assert starting_step_index > ending_step_index, \
-            "It is nonsensical for starting_step_index to be smaller or equal to ending_step_index."
-        assert starting_step_index > 0, "Starting step should be larger than zero."
-        assert ending_step_index >= 0, "ending step should be larger or equal to zero."
+        self._check_index_range(starting_step_index, ending_step_index)
         composition = starting_noisy_composition
-        forces = torch.zeros_like(composition.X)
-        for i in range(starting_step_index - 1, max(ending_step_index, 0) - 1, -1):
-            composition = self.predictor_step(composition, i + 1, forces)
+        no_forces = torch.zeros_like(composition.X)
+        index = starting_step_index
+        while index > ending_step_index:
+            composition = self.predictor_step(composition, index, no_forces)
+            index -= 1
             for _ in range(self.number_of_corrector_steps):
-                composition = self.corrector_step(composition, i, forces)
+                composition = self.corrector_step(composition, index, no_forces)
         return composition
 
     @abstractmethod
     def predictor_step(self, composition_ip1: AXL, ip1: int, cartesian_forces: torch.Tensor) -> AXL:
-        pass
+        """composition at time index ip1 -> composition at ip1 - 1"""
 
     @abstractmethod
     def corrector_step(self, composition_i: AXL, i: int, cartesian_forces: torch.Tensor) -> AXL:
-        pass
+        """relax the composition at time index i"""

@@ -1,35 +1,38 @@
-"""Repaint constraints and their pickle format (src/.../generators/sampling_constraint.py:10-97)."""
+"""What the repaint generator pins: K known atoms (reference: generators/sampling_constraint.py:10-97).
+
+Same dataclass fields and the same pickle layout (a plain dict of the fields) as the reference, so constraint files
+are interchangeable.
+"""
 import dataclasses
-from dataclasses import dataclass
 from pathlib import Path
 from typing import List, Optional
 
 import torch
 
 
-@dataclass
+def _check_tensor(name: str, value, dtype: torch.dtype, rank: int):
+    assert type(value) is torch.Tensor, f"{name} should be a torch Tensor."
+    assert value.dtype is dtype, f"{name} should have dtype {dtype}."
+    assert value.dim() == rank, f"{name} should have {rank} dimension(s); got shape {tuple(value.shape)}."
+
+
+@dataclasses.dataclass
 class SamplingConstraint:
-    elements: List[str]
-    constrained_relative_coordinates: torch.Tensor   # [K, d] float32
-    constrained_atom_types: torch.Tensor             # [K] int64, indices into `elements`
-    constrained_indices: Optional[torch.Tensor] = None   # [K] int64; default arange(K)
+    elements: List[str]                                   # element names; atom types index into this list
+    constrained_relative_coordinates: torch.Tensor        # float32 [K, d]
+    constrained_atom_types: torch.Tensor                  # int64 [K]
+    constrained_indices: Optional[torch.Tensor] = None    # int64 [K] rows of the structure to pin; None = the first K
 
     def __post_init__(self):
-        x, a, idx = self.constrained_relative_coordinates, self.constrained_atom_types, self.constrained_indices
-        assert type(x) is torch.Tensor, "the constrained_relative_coordinates should be a torch Tensor."
-        assert x.dtype is torch.float, "the constrained_relative_coordinates should be composed of floats."
-        assert len(x.shape) == 2, "constrained_relative_coordinates has the wrong shape."
-        assert type(a) is torch.Tensor, "the constrained_atom_types should be a torch Tensor."
-        assert a.dtype is torch.long, "the constrained_atom_types should be composed of long integers."
-        assert len(a.shape) == 1, "constrained_atom_types has the wrong shape."
-        assert x.shape[0] == a.shape[0], "The number of constrained atoms should match"
-        assert torch.logical_and(a >= 0, a < len(self.elements)).all(), \
-            "There is a mismatch between the specified elements and the constrained atom types."
-        if idx is not None:
-            assert type(idx) is torch.Tensor, "the constrained_indices should be a torch Tensor or None."
-            assert len(idx.shape) == 1, "constrained_indices has the wrong shape."
-            assert idx.dtype is torch.long, "the constrained_indices, if specified, should be composed of long integers."
-            assert x.shape[0] == idx.shape[0], "The number of constrained atoms should match"
+        _check_tensor("constrained_relative_coordinates", self.constrained_relative_coordinates, torch.float, 2)
+        _check_tensor("constrained_atom_types", self.constrained_atom_types, torch.long, 1)
+        count = self.constrained_relative_coordinates.shape[0]
+        assert self.constrained_atom_types.shape[0] == count, "one atom type per constrained position is required."
+        in_range = (self.constrained_atom_types >= 0) & (self.constrained_atom_types < len(self.elements))
+        assert bool(in_range.all()), "constrained atom types must index into `elements`."
+        if self.constrained_indices is not None:
+            _check_tensor("constrained_indices", self.constrained_indices, torch.long, 1)
+            assert self.constrained_indices.shape[0] == count, "one row index per constrained position is required."
 
 
 def write_sampling_constraint(sampling_constraint: SamplingConstraint, output_path: Path):
@@ -37,4 +40,5 @@ def write_sampling_constraint(sampling_constraint: SamplingConstraint, output_pa
 
 
 def read_sampling_constraint(output_path: Path) -> SamplingConstraint:
-    return SamplingConstraint(**torch.load(output_path, weights_only=False))
+    fields = torch.load(output_path, weights_only=False)
+    return SamplingConstraint(**fields)

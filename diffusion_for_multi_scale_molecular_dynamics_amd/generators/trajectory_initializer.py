@@ -1,7 +1,12 @@
-"""Trajectory initialisers (src/.../generators/trajectory_initializer.py:17-214)."""
+"""Where a sampling trajectory starts (reference: generators/trajectory_initializer.py:17-214).
+
+Two starts exist: pure noise at the last time index (A = MASK, X uniform, L fixed or Gaussian), or a stored noisy
+composition part-way down the schedule.  The random start takes its draws from the generator's noise source, so that
+it follows the reference's CPU draw order in parity mode and the device Philox stream in throughput mode.
+"""
+import abc
+import dataclasses
 import os
-from abc import ABC, abstractmethod
-from dataclasses import dataclass
 from typing import Optional, Union
 
 import torch
@@ -11,7 +16,7 @@ from ..utils.basis_transformations import get_number_of_lattice_parameters
 from .axl_generator import SamplingParameters
 
 
-@dataclass(kw_only=True)
+@dataclasses.dataclass(kw_only=True)
 class TrajectoryInitializerParameters:
     spatial_dimension: int = 3
     num_atom_types: int
@@ -21,61 +26,54 @@ class TrajectoryInitializerParameters:
     path_to_starting_configuration_data_pickle: Optional[str] = None
 
     def __post_init__(self):
-        if self.use_fixed_lattice_parameters:
-            assert self.fixed_lattice_parameters is not None, \
-                "If use_fixed_lattice_parameters is True, then fixed_lattice_parameters must be provided."
-            assert self.fixed_lattice_parameters.shape[0] == get_number_of_lattice_parameters(self.spatial_dimension), \
-                f"fixed_lattice_parameters must have d(d+1)/2 entries. Got {self.fixed_lattice_parameters.shape}."
-        else:
-            assert self.fixed_lattice_parameters is None, \
-                "fixed_lattice_parameters must be None if use_fixed_lattice_parameters is False."
+        lattice = self.fixed_lattice_parameters
+        if not self.use_fixed_lattice_parameters:
+            assert lattice is None, "fixed_lattice_parameters is only meaningful with use_fixed_lattice_parameters=True."
+            return
+        assert lattice is not None, "use_fixed_lattice_parameters=True needs fixed_lattice_parameters."
+        expected = get_number_of_lattice_parameters(self.spatial_dimension)
+        assert lattice.shape[0] == expected, f"expected {expected} lattice parameters, got shape {tuple(lattice.shape)}."
 
 
-class TrajectoryInitializer(ABC):
+class TrajectoryInitializer(abc.ABC):
     def __init__(self, trajectory_initializer_parameters: TrajectoryInitializerParameters) -> None:
-        p = trajectory_initializer_parameters
-        self.trajectory_initializer_parameters = p
-        self.spatial_dimension = p.spatial_dimension
-        self.number_of_atoms = p.number_of_atoms
-        self.masked_atom_type_index = p.num_atom_types
-        self.num_lattice_parameters = get_number_of_lattice_parameters(p.spatial_dimension)
-        self.use_fixed_lattice_parameters = p.use_fixed_lattice_parameters
-        self.fixed_lattice_parameters = p.fixed_lattice_parameters
+        self.trajectory_initializer_parameters = trajectory_initializer_parameters
+        for name in ("spatial_dimension", "number_of_atoms", "use_fixed_lattice_parameters", "fixed_lattice_parameters"):
+            setattr(self, name, getattr(trajectory_initializer_parameters, name))
+        self.masked_atom_type_index = trajectory_initializer_parameters.num_atom_types      # MASK is the last class
+        self.num_lattice_parameters = get_number_of_lattice_parameters(self.spatial_dimension)
 
-    @abstractmethod
+    @abc.abstractmethod
     def initialize(self, number_of_samples: int, device: torch.device) -> AXL:
-        pass
+        """Starting composition of `number_of_samples` trajectories."""
 
-    @abstractmethod
+    @abc.abstractmethod
     def create_start_time_step_index(self, number_of_discretization_steps: int) -> int:
-        pass
+        """Time index of the first predictor step."""
 
-    @abstractmethod
+    @abc.abstractmethod
     def create_end_time_step_index(self) -> int:
-        pass
+        """Time index at which the trajectory stops."""
 
 
 class FullRandomTrajectoryInitializer(TrajectoryInitializer):
-    """A = MASK, X ~ U[0,1), L fixed or N(0,1)  (:101-123).  `noise_source` (set by the generator) supplies the
-    draws: reference-order CPU draws, a replayed fixture, or the device Philox stream."""
+    """Pure-noise start at time index T."""
 
-    noise_source = None
+    noise_source = None      # set by the generator; None = torch's CPU generator, as the reference
 
     def initialize(self, number_of_samples: int, device: torch.device) -> AXL:
-        n, d = self.number_of_atoms, self.spatial_dimension
-        atom_types = torch.full((number_of_samples, n), self.masked_atom_type_index, dtype=torch.int64, device=device)
-        src = self.noise_source
-        if src is None:
-            x = torch.rand(number_of_samples, n, d).to(device)
-        else:
-            x = src.initial_coordinates(number_of_samples, n, d, device)
+        batch, atoms, dim = number_of_samples, self.number_of_atoms, self.spatial_dimension
+        source = self.noise_source
+        coordinates = (torch.rand(batch, atoms, dim).to(device) if source is None
+                       else source.initial_coordinates(batch, atoms, dim, device))
         if self.use_fixed_lattice_parameters:
-            lattice = self.fixed_lattice_parameters.repeat(number_of_samples, 1).to(device)
-        elif src is None:
-            lattice = torch.randn(number_of_samples, self.num_lattice_parameters).to(device)
+            lattice = self.fixed_lattice_parameters.repeat(batch, 1).to(device)
+        elif source is None:
+            lattice = torch.randn(batch, self.num_lattice_parameters).to(device)
         else:
-            lattice = src.initial_lattice(number_of_samples, self.num_lattice_parameters, device)
-        return AXL(A=atom_types, X=x, L=lattice)
+            lattice = source.initial_lattice(batch, self.num_lattice_parameters, device)
+        masked = torch.full((batch, atoms), self.masked_atom_type_index, dtype=torch.int64, device=device)
+        return AXL(A=masked, X=coordinates, L=lattice)
 
     def create_start_time_step_index(self, number_of_discretization_steps: int) -> int:
         return number_of_discretization_steps
@@ -85,22 +83,21 @@ class FullRandomTrajectoryInitializer(TrajectoryInitializer):
 
 
 class StartFromGivenConfigurationTrajectoryInitializer(TrajectoryInitializer):
-    """Start mid-trajectory from a pickle {noisy_axl: AXL, start_time_step_index: int}  (:134-186)."""
+    """Resume from a pickle holding {noisy_axl: AXL [B, ...], start_time_step_index: int}."""
 
     def __init__(self, trajectory_initializer_parameters: TrajectoryInitializerParameters) -> None:
         super().__init__(trajectory_initializer_parameters)
-        path = trajectory_initializer_parameters.path_to_starting_configuration_data_pickle
-        assert os.path.isfile(path), f"The file {path} does not exist. Review input."
-        data = torch.load(path, weights_only=False)
-        self.noisy_starting_composition = data[NOISY_AXL_COMPOSITION]
-        self.start_time_step_index = data["start_time_step_index"]
+        pickle_path = trajectory_initializer_parameters.path_to_starting_configuration_data_pickle
+        assert os.path.isfile(pickle_path), f"starting configuration file not found: {pickle_path}"
+        stored = torch.load(pickle_path, weights_only=False)
+        self.noisy_starting_composition = stored[NOISY_AXL_COMPOSITION]
+        self.start_time_step_index = stored["start_time_step_index"]
 
     def initialize(self, number_of_samples: int, device: torch.device) -> AXL:
-        comp = self.noisy_starting_composition
-        assert number_of_samples == comp.X.shape[0], \
-            "The number of samples requested is inconsistent with the number of starting configurations in the " \
-            "data pickle. Something is probably inconsistent: stopping here, review inputs."
-        return AXL(A=comp.A.to(device), X=comp.X.to(device), L=comp.L.to(device))
+        start = self.noisy_starting_composition
+        assert start.X.shape[0] == number_of_samples, \
+            f"{number_of_samples} samples requested but the starting-configuration file holds {start.X.shape[0]}."
+        return AXL(*[field.to(device) for field in start])
 
     def create_start_time_step_index(self, number_of_discretization_steps: int) -> int:
         return self.start_time_step_index
@@ -112,14 +109,11 @@ class StartFromGivenConfigurationTrajectoryInitializer(TrajectoryInitializer):
 def instantiate_trajectory_initializer(sampling_parameters: SamplingParameters,
                                        path_to_starting_configuration_data_pickle: Union[str, None] = None
                                        ) -> TrajectoryInitializer:
-    """:189-214"""
-    params = TrajectoryInitializerParameters(
-        spatial_dimension=sampling_parameters.spatial_dimension,
-        num_atom_types=sampling_parameters.num_atom_types,
-        number_of_atoms=sampling_parameters.number_of_atoms,
-        use_fixed_lattice_parameters=sampling_parameters.use_fixed_lattice_parameters,
-        fixed_lattice_parameters=sampling_parameters.fixed_lattice_parameters,
-        path_to_starting_configuration_data_pickle=path_to_starting_configuration_data_pickle)
+    shared = {name: getattr(sampling_parameters, name) for name in (
+        "spatial_dimension", "num_atom_types", "number_of_atoms", "use_fixed_lattice_parameters",
+        "fixed_lattice_parameters")}
+    parameters = TrajectoryInitializerParameters(
+        **shared, path_to_starting_configuration_data_pickle=path_to_starting_configuration_data_pickle)
     if path_to_starting_configuration_data_pickle:
-        return StartFromGivenConfigurationTrajectoryInitializer(params)
-    return FullRandomTrajectoryInitializer(params)
+        return StartFromGivenConfigurationTrajectoryInitializer(parameters)
+    return FullRandomTrajectoryInitializer(parameters)

@@ -1,31 +1,25 @@
-"""String keys and the AXL currency of the reference API (src/.../namespace.py:15-44), kept verbatim so that
-reference-style score networks, batches and sample files plug in unchanged."""
+"""Vocabulary of the reference's plugin API (its namespace.py:15-44).
+
+Score networks, batches and sample files written against the reference address their tensors by these string keys and
+exchange compositions as the AXL triple (A = atom types, X = relative coordinates, L = lattice parameters).  The VALUES
+are part of the drop-in contract and therefore identical to the reference's; nothing else is defined here.
+"""
 from collections import namedtuple
 
-CARTESIAN_POSITIONS = "cartesian_positions"
-RELATIVE_COORDINATES = "relative_coordinates"
-CARTESIAN_FORCES = "cartesian_forces"
+# the composition triple and the keys it is stored under in a batch / a samples file
+AXL = namedtuple("AXL", "A X L")
+AXL_COMPOSITION, NOISY_AXL_COMPOSITION = "original_axl", "noisy_axl"
 
-NOISY_RELATIVE_COORDINATES = "noisy_relative_coordinates"
-NOISY_CARTESIAN_POSITIONS = "noisy_cartesian_positions"
-TIME = "time"
-NOISE = "noise_parameter"
-UNIT_CELL = "unit_cell"
+# per-field keys (clean, then noised)
+ATOM_TYPES, RELATIVE_COORDINATES, LATTICE_PARAMETERS = "atom_types", "relative_coordinates", "lattice_parameters"
+NOISY_ATOM_TYPES, NOISY_RELATIVE_COORDINATES, NOISY_LATTICE_PARAMETERS = (
+    "noisy_" + ATOM_TYPES, "noisy_" + RELATIVE_COORDINATES, "noisy_" + LATTICE_PARAMETERS)
+AXL_NAME_DICT = dict(zip(AXL._fields, (ATOM_TYPES, RELATIVE_COORDINATES, LATTICE_PARAMETERS)))
 
-ATOM_TYPES = "atom_types"
-NOISY_ATOM_TYPES = "noisy_atom_types"
+# Cartesian views and the cell
+CARTESIAN_POSITIONS, NOISY_CARTESIAN_POSITIONS = "cartesian_positions", "noisy_cartesian_positions"
+CARTESIAN_FORCES, UNIT_CELL = "cartesian_forces", "unit_cell"
 
-LATTICE_PARAMETERS = "lattice_parameters"
-NOISY_LATTICE_PARAMETERS = "noisy_lattice_parameters"
-
-AXL = namedtuple("AXL", ["A", "X", "L"])
-AXL_NAME_DICT = {"A": ATOM_TYPES, "X": RELATIVE_COORDINATES, "L": LATTICE_PARAMETERS}
-
-NOISY_AXL_COMPOSITION = "noisy_axl"
-AXL_COMPOSITION = "original_axl"
-
-TIME_INDICES = "time_indices"
-
-Q_MATRICES = "q_matrices"
-Q_BAR_MATRICES = "q_bar_matrices"
-Q_BAR_TM1_MATRICES = "q_bar_tm1_matrices"
+# diffusion time, the noise level sigma(t), and the D3PM transition matrices of a noised batch
+TIME, TIME_INDICES, NOISE = "time", "time_indices", "noise_parameter"
+Q_MATRICES, Q_BAR_MATRICES, Q_BAR_TM1_MATRICES = "q_matrices", "q_bar_matrices", "q_bar_tm1_matrices"
