@@ -47,43 +47,43 @@ __device__ __forceinline__ float logf_(float x)
 }
 
 // exp, binary32: x = k ln2 + r; exp(r) = 1 + r + r c / (2 - c)
+// The sequence of oracle/mdx_oracle.c (fdlibm's branches) evaluated WITHOUT divergent branches -- lanes of a wavefront
+// hold arguments of every magnitude (SiLU over 64 neurons), so each branch of the original would be executed by
+// every wavefront.  Equivalences used, all exact in IEEE-754:
+//   * |x| < 1.5 ln2: the original sets k = +-1, hi = x -+ ln2HI, lo = +-ln2LO; the general formulas
+//     hi = x - t ln2HI, lo = t ln2LO give the same bits for t = +-1 (t ln2HI is exact, x - (-a) == x + a);
+//   * k = 0: 1 - ((x c)/(c - 2) - x) == 1 - (-(x c)/(2 - c) - x), a/(-b) == -(a/b): one division serves both forms.
+// Special cases are selected at the end in the original's order of precedence.
 __device__ __forceinline__ float expf_(float x)
 {
     const float o_threshold = 8.8721679688e+01f, u_threshold = -1.0397208405e+02f;
     const float ln2HI = 6.9314575195e-01f, ln2LO = 1.4286067653e-06f, invln2 = 1.4426950216e+00f;
     const float P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
-    uint32_t hx = f2u(x);
-    const int xsb = (int)(hx >> 31);
-    hx &= 0x7fffffff;
-    if (hx > 0x7f800000) return x + x;
-    if (hx == 0x7f800000) return xsb ? 0.0f : x;
-    if (x > o_threshold) return __builtin_huge_valf();
-    if (x < u_threshold) return 0.0f;
-    float hi = 0.0f, lo = 0.0f;
-    int32_t k = 0;
-    if (hx > 0x3eb17218) {
-        if (hx < 0x3F851592) {
-            if (xsb) { hi = x + ln2HI; lo = -ln2LO; k = -1; }
-            else     { hi = x - ln2HI; lo = ln2LO;  k = 1; }
-        } else {
-            k = (int32_t)(invln2 * x + (xsb ? -0.5f : 0.5f));
-            const float t = (float)k;
-            hi = x - t * ln2HI;
-            lo = t * ln2LO;
-        }
-        x = hi - lo;
-    } else if (hx < 0x39000000) {
-        return 1.0f + x;
-    }
-    const float t = x * x;
-    const float c = x - t * (P1 + t * P2);
-    if (k == 0) return 1.0f - ((x * c) / (c - 2.0f) - x);
-    const float y = 1.0f - ((lo - (x * c) / (2.0f - c)) - hi);
-    if (k >= -125) {
-        if (k == 128) return (y * 2.0f) * 1.7014118346e+38f;
-        return y * u2f((uint32_t)(0x7f + k) << 23);
-    }
-    return (y * u2f((uint32_t)(0x7f + (k + 100)) << 23)) * 7.8886090522e-31f;
+    const uint32_t ux = f2u(x);
+    const bool neg = (ux >> 31) != 0;
+    const uint32_t hx = ux & 0x7fffffff;
+    const bool reduce = hx > 0x3eb17218;                          // |x| > 0.5 ln2
+    const bool unit = hx < 0x3F851592;                            // ... and |x| < 1.5 ln2: k = +-1
+    const int32_t k_general = (int32_t)(invln2 * x + (neg ? -0.5f : 0.5f));
+    const int32_t k = reduce ? (unit ? (neg ? -1 : 1) : k_general) : 0;
+    const float t = (float)k;
+    const float hi = x - t * ln2HI;
+    const float lo = t * ln2LO;
+    const float r = reduce ? hi - lo : x;
+    const float tt = r * r;
+    const float c = r - tt * (P1 + tt * P2);
+    const float q = (r * c) / (2.0f - c);
+    const float y0 = 1.0f - (-q - r);                             // k == 0
+    const float y = 1.0f - ((lo - q) - hi);                       // k != 0
+    const float scaled = (k >= -125) ? ((k == 128) ? (y * 2.0f) * 1.7014118346e+38f : y * u2f((uint32_t)(0x7f + k) << 23))
+                                     : (y * u2f((uint32_t)(0x7f + (k + 100)) << 23)) * 7.8886090522e-31f;
+    float out = (k == 0) ? y0 : scaled;
+    if (!reduce && hx < 0x39000000) out = 1.0f + x;               // |x| < 2^-13
+    if (x < u_threshold) out = 0.0f;
+    if (x > o_threshold) out = __builtin_huge_valf();
+    if (hx == 0x7f800000) out = neg ? 0.0f : x;
+    if (hx > 0x7f800000) out = x + x;
+    return out;
 }
 
 // natural log, binary64, finite normal positive arguments

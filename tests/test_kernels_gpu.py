@@ -36,6 +36,15 @@ def test_math_sequences_bit_exact(K, oracle, cuda):
     x_log = np.concatenate([np.exp(rng.uniform(-80, 80, 200000)), [0.0, 1.0, 1e-45, 1e-38, 3e38, np.inf, 2.0 ** -24]]
                            ).astype(np.float32)
     x_exp = np.concatenate([rng.uniform(-110, 90, 200000), [0.0, -np.inf, -103.9, 88.7, 1e-5, -1e-5]]).astype(np.float32)
+    # every threshold of the exp sequence (both signs, +-3 ulp), NaN/inf, the k = +-1 / 0 / 128 / < -125 regimes densely
+    edges = np.array([0x3eb17218, 0x3F851592, 0x39000000, 0x42b17218, 0x42cff1b5, 0x7f800000, 0x00800000, 0x00000001],
+                     dtype=np.int64)
+    bits = (edges[:, None] + np.arange(-3, 4)[None, :]).ravel()
+    bits = np.concatenate([bits, bits | 0x80000000, [0x7fc00000, 0xffc00000, 0x7f800001, 0x80000000]]).astype(np.uint32)
+    x_exp = np.concatenate([x_exp, bits.view(np.float32), rng.uniform(-3, 3, 200000).astype(np.float32),
+                            rng.uniform(-104.5, -86.5, 50000).astype(np.float32),
+                            rng.uniform(88.0, 89.0, 20000).astype(np.float32),
+                            (rng.uniform(-1, 1, 20000) * 2.0 ** -12).astype(np.float32)])
     v = np.concatenate([rng.uniform(0, 2, 200000), [0.0, 0.5, 1.0, 1.5, 2.0, 0.25, 1.75]]).astype(np.float32)
     L = oracle.lib()
     got = K.math_probe(0, dev(x_log, cuda)).cpu().numpy()
@@ -43,7 +52,8 @@ def test_math_sequences_bit_exact(K, oracle, cuda):
     assert np.array_equal(got.view(np.int32), want.view(np.int32))
     got = K.math_probe(1, dev(x_exp, cuda)).cpu().numpy()
     want = np.array([L.mdxo_expf(float(t)) for t in x_exp], dtype=np.float32)
-    assert np.array_equal(got.view(np.int32), want.view(np.int32))
+    same = (got.view(np.int32) == want.view(np.int32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), x_exp[~same][:10]
     sc = oracle.sincospif(v)
     assert np.array_equal(K.math_probe(2, dev(v, cuda)).cpu().numpy().view(np.int32), sc[:, 0].copy().view(np.int32))
     assert np.array_equal(K.math_probe(3, dev(v, cuda)).cpu().numpy().view(np.int32), sc[:, 1].copy().view(np.int32))
