@@ -701,3 +701,127 @@ def test_segment_kernels_against_torch(cuda, n_nodes, H, mean):
     assert float((got_rows - want_rows).abs().max()) <= 2e-6 * max(1.0, float(want_rows.abs().max()))
     assert float((got_trans - want_trans).abs().max()) <= 2e-6 * max(1.0, float(want_trans.abs().max()))
     assert (got_rows[0] == 0).all() and (got_trans[0] == 0).all()        # empty segment
+
+
+def _random_config(seed):
+    rng = np.random.default_rng(seed)
+    N = int(rng.choice([1, 2, 3, 5, 8, 13, 31, 32, 33, 64, 65, 100, 216]))
+    nat = int(rng.integers(1, 6))
+    d = int(rng.choice([1, 2, 3, 3, 3]))
+    M = int(rng.choice([0, 1, 2, 3]))
+    T = int(rng.integers(3, 8))
+    fixed = bool(rng.random() < 0.6)
+    noise_kw = cases.noise_ns(T, schedule_type=str(rng.choice(["exponential", "linear"])),
+                              sigma_min=float(rng.choice([1e-3, 5e-3])), sigma_max=float(rng.choice([0.2, 0.5])))
+    sampling_kw = cases.sampling_ns(N, nat, M=M, greedy=bool(rng.random() < 0.5), one=bool(rng.random() < 0.5),
+                                    in_corr=bool(rng.random() < 0.4), eps=float(rng.choice([1e-8, 1e-6])), fixed=fixed,
+                                    cell=[float(c) for c in rng.uniform(4.0, 12.0, d)], d=d)
+    return noise_kw, sampling_kw, int(rng.choice([1, 3, 17]))
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_configurations_device_rng_bitwise(cuda, seed):
+    """Seeded random sampler configurations (atoms 1..216, 2..6 classes, 1..3 spatial dimensions, 0..3 correctors, all
+    flag combinations, fixed and free lattice) with the echo network, whose forward is exact on both sides: the GPU
+    generator in device-RNG mode -- eager and hipGraph replay -- must equal the oracle in every bit."""
+    P = _pkg()
+    noise_kw, sampling_kw, batch = _random_config(seed)
+    import warnings
+    outs = []
+    for use_graph in (False, True):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            npar = P["Noise"](**noise_kw)
+            spar = P["Sampling"](**sampling_kw, rng_mode="device", seed=1000 + seed, use_hip_graph=use_graph)
+        net = nets.fake_net(spar.num_atom_types, d=spar.spatial_dimension).to(cuda)
+        gen = P["Langevin"](npar, spar, net)
+        with torch.no_grad():
+            outs.append(_np(gen.sample(batch, cuda)))
+    ora = RS.OracleLangevinGenerator(npar, spar, nets.fake_net(spar.num_atom_types, d=spar.spatial_dimension),
+                                     noise=RS.PhiloxNoise(1000 + seed, 0)).sample(batch)
+    for out in outs:
+        assert np.array_equal(out.A, ora.A), (noise_kw, sampling_kw, batch)
+        assert np.array_equal(out.X.view(np.int32), ora.X.view(np.int32)), (noise_kw, sampling_kw, batch)
+        assert np.array_equal(out.L.view(np.int32), ora.L.view(np.int32)), (noise_kw, sampling_kw, batch)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_sampler_random_shapes_predrawn_equals_in_kernel(cuda, seed):
+    """Generic instantiations of the persistent sampler on random network / structure shapes (records longer than one
+    64-lane fetch included): the noise pre-pass and the in-kernel draws give the same bits, and one launch equals two."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    import warnings
+    P = _pkg()
+    rng = np.random.default_rng(100 + seed)
+    N, nat = int(rng.choice([1, 3, 8, 17, 40, 64])), int(rng.integers(1, 5))
+    hidden, n_hidden = int(rng.choice([32, 48, 64, 96])), int(rng.integers(1, 5))
+    M, T, batch = int(rng.integers(0, 3)), int(rng.integers(3, 7)), int(rng.choice([1, 5, 9]))
+    in_corr = bool(rng.random() < 0.5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = P["Noise"](**cases.noise_ns(T, **cases.LIN))
+        spar = P["Sampling"](**cases.sampling_ns(N, nat, M=M, greedy=bool(rng.random() < 0.5), one=bool(rng.random() < 0.5),
+                                                 in_corr=in_corr, fixed=bool(rng.random() < 0.7)),
+                             rng_mode="device", seed=seed, fused_score_network=True)
+    torch.manual_seed(seed)
+    net = nets.mlp_net(N, nat, hidden=hidden, n_hidden=n_hidden).to(cuda)
+    gen = P["Langevin"](npar, spar, net)
+    with torch.no_grad():
+        gen._prepare(cuda)
+        gen._begin_call(cuda)
+        start = gen.initialize(batch, cuda)
+        sched, pack = gen._prepare(cuda), gen.fused_pack(cuda)
+        outs = []
+        for mode in ("in_kernel", "predrawn", "two_launches"):
+            comp = RS.AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
+            segments = ((T, T),) if mode != "two_launches" else ((T, 2), (T - 2, T - 2))
+            for first, n in segments:
+                kernels.mlp_pc_sample(sched, pack, gen._flags(True), M, in_corr, first, n, gen._rng(0), comp.A, comp.X,
+                                      comp.L, gen._status, predrawn_noise=mode != "in_kernel")
+            outs.append(comp)
+    for other in outs[1:]:
+        assert torch.equal(outs[0].A, other.A), (N, nat, hidden, n_hidden, M, T, batch)
+        assert torch.equal(outs[0].X.view(torch.int32), other.X.view(torch.int32))
+        assert torch.equal(outs[0].L.view(torch.int32), other.L.view(torch.int32))
+    assert torch.isfinite(outs[0].X).all() and (outs[0].A != nat).all()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_repaint_configurations_bitwise(cuda, seed):
+    """Random repaint set-ups (constraint count / rows, resampling passes 0..2, correctors, flags) with the echo network:
+    GPU device-RNG generator -- eager and graph replay -- equals the oracle bit for bit; constrained rows are pinned."""
+    import warnings
+    P = _pkg()
+    rng = np.random.default_rng(500 + seed)
+    N, nat = int(rng.choice([4, 8, 13, 40, 70])), int(rng.integers(1, 4))
+    K = int(rng.integers(1, N + 1))
+    M, T, batch = int(rng.integers(0, 3)), int(rng.integers(3, 7)), int(rng.choice([1, 4, 9]))
+    resampling = int(rng.integers(0, 3))
+    cx = rng.random((K, 3), dtype=np.float32)
+    ca = rng.integers(0, nat, K)
+    cidx = rng.permutation(N)[:K] if rng.random() < 0.7 else None
+    constraint = P["Constraint"](elements=["Si", "Ge", "C"][:nat], constrained_relative_coordinates=torch.from_numpy(cx),
+                                 constrained_atom_types=torch.from_numpy(ca),
+                                 constrained_indices=None if cidx is None else torch.from_numpy(cidx))
+    noise_kw = cases.noise_ns(T, schedule_type=str(rng.choice(["exponential", "linear"])))
+    sampling_kw = cases.sampling_ns(N, nat, M=M, greedy=bool(rng.random() < 0.5), one=bool(rng.random() < 0.5),
+                                    in_corr=bool(rng.random() < 0.3))
+    outs = []
+    for use_graph in (False, True):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            npar = P["Noise"](**noise_kw)
+            spar = P["Sampling"](**sampling_kw, rng_mode="device", seed=77 + seed, use_hip_graph=use_graph,
+                                 repaint_resampling_steps=resampling)
+        gen = P["Constrained"](npar, spar, nets.fake_net(nat).to(cuda), constraint)
+        with torch.no_grad():
+            outs.append(_np(gen.sample(batch, cuda)))
+    ora = RS.OracleLangevinGenerator(npar, spar, nets.fake_net(nat), noise=RS.PhiloxNoise(77 + seed, 0),
+                                     constraint=dict(constrained_relative_coordinates=cx, constrained_atom_types=ca,
+                                                     constrained_indices=cidx)).sample(batch)
+    rows = np.arange(K) if cidx is None else cidx
+    for out in outs:
+        assert np.array_equal(out.A, ora.A), (N, nat, K, M, T, batch, resampling)
+        assert np.array_equal(out.X.view(np.int32), ora.X.view(np.int32)), (N, nat, K, M, T, batch, resampling)
+        assert np.array_equal(out.X[:, rows], np.broadcast_to(cx, (batch, K, 3)))
+        assert np.array_equal(out.A[:, rows], np.broadcast_to(ca, (batch, K)))
