@@ -1,0 +1,26 @@
+"""One full C3 job end to end: generator.sample(512) with the EGNN (4 x 256, rc 7.5), 1000 iterations x (1 predictor +
+2 correctors), wall clock; checks the result's properties.  ~2 minutes."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+device = torch.device("cuda:0")
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+w = bench.WORKLOADS[name]
+gen, noise, sampling, net = bench.build_generator(w, device, 0, w["batch"], False)
+with torch.no_grad():
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = gen.sample(w["batch"], device)
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+assert (out.A != w["num_atom_types"]).all() and torch.isfinite(out.X).all() and (out.X >= 0).all() and (out.X < 1).all()
+print(json.dumps({"job": f"{name} generator.sample({w['batch']}), {w['noise']['total_time_steps']} iterations, end to end",
+                  "seconds": round(seconds, 2), "structures_per_s": round(w["batch"] / seconds, 4)}))
