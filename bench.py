@@ -19,6 +19,7 @@ The JSON line also carries
                 timed on this host's cores over a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -185,9 +186,13 @@ def time_launches(launch, device, launches):
         launch()
     torch.cuda.synchronize(device)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        for _ in range(launches):
-            launch()
+    gc.disable()                        # a collection during capture may free device objects and abort the capture
+    try:
+        with torch.cuda.graph(graph):
+            for _ in range(launches):
+                launch()
+    finally:
+        gc.enable()
     graph.replay()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)

@@ -47,7 +47,7 @@ __device__ __forceinline__ float logf_(float x)
 }
 
 // exp, binary32: x = k ln2 + r; exp(r) = 1 + r + r c / (2 - c)
-// The sequence of oracle/mdx_oracle.c (fdlibm's branches) evaluated WITHOUT divergent branches -- lanes of a wavefront
+// The sequence of DESIGN.md's arithmetic contract (fdlibm's branches) evaluated WITHOUT divergent branches -- lanes of a wavefront
 // hold arguments of every magnitude (SiLU over 64 neurons), so each branch of the original would be executed by
 // every wavefront.  Equivalences used, all exact in IEEE-754:
 //   * |x| < 1.5 ln2: the original sets k = +-1, hi = x -+ ln2HI, lo = +-ln2LO; the general formulas

@@ -15,6 +15,7 @@ Same class name, constructor, step methods and behaviour as the reference's Lang
 There is no CPU fallback: calling this generator with device="cpu" raises.
 """
 import dataclasses
+import gc
 from typing import Optional
 
 import torch
@@ -414,8 +415,17 @@ class IterationLoop:
             comp.L.copy_(saved.L)
             gen._status.zero_()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                gen._iteration_on_device_index(comp, self.forces, self.d_index)
+            # no Python garbage collection while the stream is capturing: a collected object that owns device
+            # resources (an older generator's graph, a library handle) would call into HIP in the middle of the
+            # capture and abort the process
+            gc_was_enabled = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(self.graph):
+                    gen._iteration_on_device_index(comp, self.forces, self.d_index)
+            finally:
+                if gc_was_enabled:
+                    gc.enable()
         kernels.index_set(self.d_index, starting_step_index - 1)
 
     def advance(self, iterations: int):
