@@ -52,3 +52,7 @@ ADAPTIVE = {
     "traj_adaptive_mlp": (noise_ns(10, sigma_min=1e-3, sigma_max=0.2, schedule_type="linear"),
                           dict(sampling_ns(8, 1), algorithm="adaptive_corrector"), lambda eb: nets.mlp_net(8, 1)),
 }
+
+
+# BASELINE configs[0] at its exact settings (tests/golden/traj_c1_exact.npz): T = 100, batch 16, MLP template
+C1_EXACT = (noise_ns(100, sigma_min=1e-4, sigma_max=0.25), sampling_ns(8, 1), lambda eb: nets.mlp_net(8, 1))

@@ -686,6 +686,35 @@ def golden_distances():
     save("distances.npz", **out)
 
 
+def golden_c1_exact():
+    """BASELINE configs[0] at its exact settings: Si 1x1x1 (N = 8, one atom type), the MLP of
+    config_diffusion_mlp.yaml:41-53, T = 100, sigma 1e-4 .. 0.25 exponential (:21-24), M = 1, batch 16, on the
+    reference's CPU path.  Stored: every draw, the final composition, and the composition after every predictor and
+    corrector step (atom types as int8) -- inputs and model predictions are not stored (each step's input is the
+    previous step's output)."""
+    net = _mlp(8, 1)
+    gen, npar, spar = make_generator(record=True, net=net, T=100, N=8, num_atom_types=1, M=1,
+                                     noise_kw=dict(sigma_min=1e-4, sigma_max=0.25))
+    B = 16
+    torch.manual_seed(31)
+    with torch.no_grad(), DrawRecorder() as rec:
+        axl = gen.sample(B, torch.device("cpu"))
+    data = gen.sample_trajectory_recorder._internal_data
+    out = dict(final_A=_np(axl.A), final_X=_np(axl.X), final_L=_np(axl.L), batch=np.array(B))
+    out.update(rec.pack())
+    pred, corr = data["predictor_step"], data["corrector_step"]
+    out["pred_index"] = np.array([e["time_step_index"] for e in pred], dtype=np.int64)
+    out["corr_index"] = np.array([e["time_step_index"] for e in corr], dtype=np.int64)
+    out["start_A"] = _np(pred[0]["composition_i"].A).astype(np.int8)
+    out["start_X"] = _np(pred[0]["composition_i"].X)
+    out["pred_out_A"] = np.stack([_np(e["composition_im1"].A) for e in pred]).astype(np.int8)
+    out["pred_out_X"] = np.stack([_np(e["composition_im1"].X) for e in pred])
+    out["corr_out_A"] = np.stack([_np(e["corrected_composition_i"].A) for e in corr]).astype(np.int8)
+    out["corr_out_X"] = np.stack([_np(e["corrected_composition_i"].X) for e in corr])
+    out.update(_state_dict_np(net))
+    save("traj_c1_exact.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -701,3 +730,5 @@ if __name__ == "__main__":
         golden_next()
     if which in ("all", "distances"):
         golden_distances()
+    if which in ("all", "c1"):
+        golden_c1_exact()
