@@ -387,6 +387,8 @@ def main():
         if dist is not None:
             parts = [coll(t.contiguous()) for t in comp]
             outs = [torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in parts]
+            for o, t in zip(outs, parts):          # untimed: RCCL sets up its rings / channels at the first collective
+                dist.all_gather_into_tensor(o, t)
             barrier()
             g0 = time.perf_counter()
             for o, t in zip(outs, parts):
