@@ -358,14 +358,18 @@ def main():
     gen, noise, sampling, net = build_generator(w, device, rank, batch, use_graph, resampling=resampling)
     gen.fused_score_network = forward == "fused"
 
-    def barrier():
-        """dist.barrier + torch.cuda.synchronize.  The GPU is first awaited by polling an event: a blocking synchronize
-        wakes the host tens of microseconds late, which matters when K steps take ~100 us."""
+    def wait_for_gpu():
+        """The GPU is awaited by polling an event before the blocking synchronize: a blocking synchronize alone wakes
+        the host tens of microseconds late, which matters when K steps take ~1 ms."""
         done = torch.cuda.Event()
         done.record()
         while not done.query():
             pass
         torch.cuda.synchronize(device)
+
+    def barrier():
+        """torch.cuda.synchronize + dist.barrier + torch.cuda.synchronize."""
+        wait_for_gpu()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize(device)
@@ -379,8 +383,12 @@ def main():
         barrier()
         t0 = time.perf_counter()
         advance(loop, steps, T)
-        barrier()
+        # each rank stamps its clock when its own K steps are complete, then joins the closing barrier; the reported
+        # time is the MAX over ranks (= when the last rank finished), so the barrier's own latency -- an RCCL
+        # all-reduce of ~50 us, a quarter of the timed region at K = 20 -- is not booked as sampling time
+        wait_for_gpu()
         elapsed = time.perf_counter() - t0
+        barrier()
         # the single collective of the job: gather of the final compositions
         comp = loop.composition
         gather_ms = 0.0
@@ -393,8 +401,9 @@ def main():
             g0 = time.perf_counter()
             for o, t in zip(outs, parts):
                 dist.all_gather_into_tensor(o, t)
-            barrier()
+            wait_for_gpu()                         # the collective itself is the synchronisation point
             gather_ms = (time.perf_counter() - g0) * 1e3
+            barrier()
         gen.check_status()
         if dist is not None:
             t = coll(torch.tensor([elapsed, gather_ms], dtype=torch.float64, device=device))
