@@ -301,6 +301,7 @@ def mlp_forward(pack: MlpPack, atom_types, x, l, time, sigma):
 
 _NOISE_WORKSPACE = {}                       # device -> float32 buffer reused by every fused-sampler launch
 NOISE_WORKSPACE_MAX_FLOATS = 1 << 28        # 1 GiB cap; longer segments are split into several launches by the library
+NOISE_WORKSPACE_MIN_ITERATIONS = 1024       # first allocation holds at least this many iterations (within the cap)
 
 
 def noise_workspace(pack: "MlpPack", number_of_corrector_steps: int, atom_type_transition_in_corrector: bool,
@@ -316,7 +317,10 @@ def noise_workspace(pack: "MlpPack", number_of_corrector_steps: int, atom_type_t
     key = torch.device(device)
     buf = _NOISE_WORKSPACE.get(key)
     if buf is None or buf.numel() < need:
-        buf = _NOISE_WORKSPACE[key] = torch.empty(need, dtype=F32, device=device)
+        # allocate with headroom (a device allocation costs ~100 us, more than a short segment's kernels): room for
+        # NOISE_WORKSPACE_MIN_ITERATIONS iterations of this shape, within the cap
+        roomy = min(max(need, NOISE_WORKSPACE_MIN_ITERATIONS * per_iteration), max(NOISE_WORKSPACE_MAX_FLOATS, need))
+        buf = _NOISE_WORKSPACE[key] = torch.empty(roomy, dtype=F32, device=device)
     return buf
 
 
