@@ -1104,6 +1104,8 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
             v.a_out = (int64_t*)r.a; v.x_out = (float*)r.x; v.l_out = (float*)r.l; v.p_out = nullptr;
             v.item0 = b * N;
             v.b = b;
+            PcArgs pc_types_only = p.pc;                                   // P2 + P3 only (P1 done one lane per component)
+            pc_types_only.do_coords = 0;
             constexpr int kPre = SPEC == 1 ? 1 : (MDX_MAX_CLASSES + 4);   // 64-lane fetches covering N (d + C + 1) floats
             const int rec_total = p.rec0 + p.M * p.rec1;
             for (int it = 0; it < p.n_iterations; ++it) {
@@ -1139,7 +1141,15 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
                         v.gumbel = (const float*)(r.noise + N * d);
                         v.u = p.pc.greedy ? (const float*)(r.noise + N * d + N * p.pc.C) : nullptr;
                     }
-                    if (lane < G && !(p.diag_skip & 2)) pc_update_structure<G>(p.pc, st, v, lane, types);
+                    if (p.noise && !(p.diag_skip & 2)) {
+                        // with pre-drawn noise the coordinate update is elementwise over the N d components: one lane
+                        // per component (24 lanes at C2) instead of three components in sequence on each atom's lane
+                        for (int e = lane; e < N * d; e += kWave)
+                            r.x[e] = coord_update(r.x[e], r.sx[e], r.noise[e], st.sc.w, st.sc.n, st.sc.sigma);
+                        if (lane < G) pc_update_structure<G>(pc_types_only, st, v, lane, types);
+                    } else if (lane < G && !(p.diag_skip & 2)) {
+                        pc_update_structure<G>(p.pc, st, v, lane, types);
+                    }
                     wave_sync();
                 }
             }
