@@ -20,7 +20,7 @@ MAX_CLASSES = 8
 TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
     TAG_INIT_LATTICE, TAG_RESAMPLE_Z, TAG_RESAMPLE_U = range(11)
 
-ABI_VERSION = 2          # MDX_ABI_VERSION of include/mdx_hip.h
+ABI_VERSION = 3          # MDX_ABI_VERSION of include/mdx_hip.h
 ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
@@ -65,7 +65,7 @@ class Mlp(C.Structure):
                                    "w_atom_type_t", "b_atom_type", "w_lattice_t", "b_lattice")] + \
         [("w_hidden_t", C.c_void_p * 8), ("b_hidden", C.c_void_p * 8)] + \
         [(n, C.c_void_p) for n in ("w_out_a_t", "b_out_a", "w_out_x_t", "b_out_x", "w_out_l_t", "b_out_l",
-                                   "packed_image")]
+                                   "packed_image", "folded_input")]
 
 
 def build(force=False):

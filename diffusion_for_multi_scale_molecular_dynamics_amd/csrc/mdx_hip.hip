@@ -924,6 +924,73 @@ __host__ __device__ inline int mlp_scratch_floats(const mdx_mlp_t& m)
     return ((mx + 3) & ~3) + 4;                              // + zero padding for the four-wide layer loop
 }
 
+// ---- template MLP with the input embeddings FOLDED into the first hidden layer (SPEC = 2) ---------------------------
+// The five embedding layers of MLPScoreNetwork feed the first hidden layer with no activation in between
+// (mlp_score_network.py:299-344), so  W_h0 [W_c [cos;sin] + b_c | w_n sigma + b_n | w_t t + b_t | emb_a | emb_l] + b_h0
+// is ONE linear map of the 59-vector  [cos (24) | sin (24) | sigma | t | atom-type embeddings (8) | lattice embedding]:
+// the host folds the products once (binary64, mdx_mlp_t.folded_input), and the forward loses a whole layer -- 12 + 19
+// weight quads become 15, one LDS hand-off and 64 weight registers less.  Same function; the rounding differs from the
+// layer-by-layer evaluation in the last bits (the fused path is compared with the PyTorch module at 1e-5, not bitwise).
+struct MlpRegsFolded {
+    lds_f4 wf[15], wh1[16], wh2[16], wo[16];
+    float bf, bh1, bh2, bo;
+};
+
+__device__ __forceinline__ void load_mlp_regs_folded(MlpRegsFolded& R, const mdx_mlp_t& m, const MlpWeightsLds& w, int lane)
+{
+    const lds_f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    const lds_f4* folded = reinterpret_cast<const lds_f4*>(m.folded_input);       // [15][64] quads, then the bias [64]
+#pragma unroll
+    for (int q = 0; q < 15; ++q) R.wf[q] = folded[q * 64 + lane];
+    R.bf = m.folded_input[15 * 64 * 4 + lane];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) R.wh1[q] = ((lds_cf4*)w.wh(1))[q * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) R.wh2[q] = ((lds_cf4*)w.wh(2))[q * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) R.wo[q] = lane < 46 ? ((lds_cf4*)w.woa)[q * 46 + lane] : zero;
+    R.bh1 = w.bh(1)[lane]; R.bh2 = w.bh(2)[lane];
+    R.bo = lane < 46 ? w.boa[lane] : 0.0f;
+}
+
+__device__ __forceinline__ void mlp_forward_folded(const MlpWeightsLds& w, const MlpRegsFolded& R, int lane, lds_cf* x,
+                                                   lds_ci64* a, lds_cf* l, float time, float sigma, lds_f* buf_a, lds_f* buf_b,
+                                                   lds_f* logits)
+{
+    // the 59 (+1 zero) inputs of the folded layer
+    if (lane < 24) {
+        float sn, cs;
+        sincospif_(2.0f * x[lane], sn, cs);
+        buf_b[lane] = cs;
+        buf_b[24 + lane] = sn;
+    } else if (lane == 48) {
+        buf_b[48] = sigma;
+    } else if (lane == 49) {
+        buf_b[49] = time;
+    } else if (lane >= 50 && lane < 58) {
+        buf_b[lane] = w.wa[(int)a[lane - 50]] + w.ba[0];
+    } else if (lane == 58) {
+        float acc = w.bl[0];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc = __builtin_fmaf(w.wl[k], l[k], acc);
+        buf_b[58] = acc;
+    } else if (lane == 59) {
+        buf_b[59] = 0.0f;
+    }
+    wave_sync();
+    buf_a[lane] = silu_(dot_regs<15>(R.wf, buf_b, R.bf));
+    wave_sync();
+    buf_b[lane] = silu_(dot_regs<16>(R.wh1, buf_a, R.bh1));
+    wave_sync();
+    buf_a[lane] = dot_regs<16>(R.wh2, buf_b, R.bh2);
+    wave_sync();
+    if (lane < 46) {                                            // logits (16) | score_x (24) | score_l (6), contiguous
+        const float o = dot_regs<16>(R.wo, buf_a, R.bo);
+        logits[lane] = (lane < 16 && (lane & 1)) ? -__builtin_huge_valf() : o;
+    }
+    wave_sync();
+}
+
 // floats of LDS one wavefront needs besides the shared weight image
 __host__ __device__ inline int mlp_wave_floats(const mdx_mlp_t& m)
 {
@@ -1063,7 +1130,7 @@ __global__ __launch_bounds__(kBlock) void pc_noise_fill_kernel(NoiseFillArgs p)
 template <int SPEC>
 __device__ __forceinline__ void specialise(mdx_mlp_t& m, PcArgs& pc)
 {
-    if constexpr (SPEC == 1) {
+    if constexpr (SPEC >= 1) {
         m.number_of_atoms = 8; m.spatial_dimension = 3; m.num_classes = 2; m.hidden_size = 64; m.n_hidden = 3;
         m.e_coordinates = 32; m.e_noise = 16; m.e_time = 16; m.e_atom_type = 1; m.e_lattice = 1;
         pc.N = 8; pc.d = 3; pc.C = 2; pc.nl = 6;
@@ -1091,7 +1158,9 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
     auto run = [&](const auto& w, lds_f* scratch) {
         const MlpWaveLds r = carve_wave_lds(m, scratch + wave * mlp_wave_floats(m));
         [[maybe_unused]] MlpRegs regs;
+        [[maybe_unused]] MlpRegsFolded folded;
         if constexpr (SPEC == 1 && LDS_WEIGHTS) load_mlp_regs(regs, w, lane);
+        if constexpr (SPEC == 2 && LDS_WEIGHTS) load_mlp_regs_folded(folded, m, w, lane);
         for (int64_t b = (int64_t)blockIdx.x * kMlpWaves + wave; b < p.pc.B; b += (int64_t)gridDim.x * kMlpWaves) {
             for (int e = lane; e < N; e += kWave) r.a[e] = p.a[b * N + e];
             for (int e = lane; e < N * d; e += kWave) r.x[e] = p.x[b * N * d + e];
@@ -1106,7 +1175,7 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
             v.b = b;
             PcArgs pc_types_only = p.pc;                                   // P2 + P3 only (P1 done one lane per component)
             pc_types_only.do_coords = 0;
-            constexpr int kPre = SPEC == 1 ? 1 : (MDX_MAX_CLASSES + 4);   // 64-lane fetches covering N (d + C + 1) floats
+            constexpr int kPre = SPEC >= 1 ? 1 : (MDX_MAX_CLASSES + 4);   // 64-lane fetches covering N (d + C + 1) floats
             const int rec_total = p.rec0 + p.M * p.rec1;
             for (int it = 0; it < p.n_iterations; ++it) {
                 const int i = p.start_index - 1 - it;               // loop variable of the reference (:147)
@@ -1128,6 +1197,9 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
                     if (!(p.diag_skip & 1)) {
                         if constexpr (SPEC == 1 && LDS_WEIGHTS)
                             mlp_forward_regs(w, regs, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b, r.logits);
+                        else if constexpr (SPEC == 2 && LDS_WEIGHTS)
+                            mlp_forward_folded(w, folded, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b,
+                                               r.logits);
                         else
                             mlp_forward_wave<LDS_WEIGHTS>(m, w, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a,
                                                           r.buf_b, r.logits, r.sx, r.sl);
@@ -1513,9 +1585,10 @@ static void launch_mlp_sampler(int G, unsigned grid, size_t lds, hipStream_t st,
     }
 }
 
-static const void* mlp_sampler_lds_function(int G, bool spec)
+static const void* mlp_sampler_lds_function(int G, int spec)
 {
-    if (spec) return (const void*)mlp_pc_sample_kernel<8, true, 1>;
+    if (spec == 2) return (const void*)mlp_pc_sample_kernel<8, true, 2>;
+    if (spec == 1) return (const void*)mlp_pc_sample_kernel<8, true, 1>;
     switch (G) {
         case 1: return (const void*)mlp_pc_sample_kernel<1, true, 0>;
         case 2: return (const void*)mlp_pc_sample_kernel<2, true, 0>;
@@ -1942,11 +2015,14 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
     if (in_lds) {
         const size_t lds = per_wave * kMlpWaves + image;
         const char* generic = getenv("MDX_MLP_GENERIC");          // tests: force the generic instantiation
-        const bool spec = matches_template_mlp(*mlp_host) && !(generic && generic[0] == '1');
+        // 0: generic instantiation; 1: template dimensions as literals; 2: the same with the folded input layer
+        const char* fold = getenv("MDX_MLP_FOLD");                // tests: "0" keeps the layer-by-layer form
+        int spec = matches_template_mlp(*mlp_host) && !(generic && generic[0] == '1') ? 1 : 0;
+        if (spec == 1 && mlp_host->folded_input && !(fold && fold[0] == '0')) spec = 2;
         if (lds > kMlpLdsBudget) {       // up to 128 KiB of the CU's 160 KiB: opt in above the 64 KiB default
             // the attribute is a property of the code object: set it when the requirement grows, not on every launch
             static std::atomic<size_t> granted[16];
-            const int slot = (spec ? 8 : 0) + (G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : G == 32 ? 5 : 6);
+            const int slot = spec ? 6 + spec : (G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : G == 32 ? 5 : 6);
             if (granted[slot].load() < lds) {
                 if (hipFuncSetAttribute(mlp_sampler_lds_function(G, spec), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) != hipSuccess)
@@ -1954,7 +2030,9 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
                 granted[slot].store(lds);
             }
         }
-        if (spec)
+        if (spec == 2)
+            hipLaunchKernelGGL((mlp_pc_sample_kernel<8, true, 2>), dim3(grid), dim3(kMlpWaves * kWave), lds, st, a);
+        else if (spec == 1)
             hipLaunchKernelGGL((mlp_pc_sample_kernel<8, true, 1>), dim3(grid), dim3(kMlpWaves * kWave), lds, st, a);
         else
             launch_mlp_sampler<true>(G, grid, lds, st, a);

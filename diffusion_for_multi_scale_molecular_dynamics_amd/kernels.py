@@ -272,6 +272,10 @@ class MlpPack:
             setattr(m, f"w_out_{name}_t", wt(layer))
             setattr(m, f"b_out_{name}", bias(layer))
         m.packed_image = None
+        m.folded_input = None
+        self.folded = self._fold_input_layers(network, m, device)
+        if self.folded is not None:
+            m.folded_input = self.folded.data_ptr()
         n_floats = lib().mdx_mlp_image_floats(C.byref(m))
         if n_floats > 0:      # the kernels' own layout, built once: kernel start-up becomes one coalesced copy
             self.image = torch.empty(n_floats, dtype=F32, device=device)
@@ -282,6 +286,42 @@ class MlpPack:
         self.c_struct = m
         self.device = torch.device(device)
         self.number_of_atoms, self.num_classes, self.spatial_dimension = m.number_of_atoms, m.num_classes, m.spatial_dimension
+
+
+def _fold_input_layers(network, m, device):
+    """The five embedding layers folded into hidden layer 0 (mdx_mlp_t.folded_input): they are linear and no activation
+    lies between them and the first hidden layer (mlp_score_network.py:299-344).  Products in binary64, rounded once.
+    Input of the folded layer: [cos (N d) | sin (N d) | sigma | t | atom-type embeddings (N e_a) | lattice emb. (e_l)]."""
+    f64 = torch.float64
+    with torch.no_grad():
+        w0 = network.mlp_layers[0].weight.detach().to(f64).cpu()           # [H, ec + en + et + N ea + el]
+        b0 = network.mlp_layers[0].bias.detach().to(f64).cpu()
+        ec, en, et = m.e_coordinates, m.e_noise, m.e_time
+        na, el = m.number_of_atoms * m.e_atom_type, m.e_lattice
+        if w0.shape[1] != ec + en + et + na + el:
+            return None
+        o1, o2, o3, o4 = ec, ec + en, ec + en + et, ec + en + et + na
+        wc, bc = (t.detach().to(f64).cpu() for t in (network.relative_coordinates_embedding_layer.weight,
+                                                       network.relative_coordinates_embedding_layer.bias))
+        wn, bn = (t.detach().to(f64).cpu() for t in (network.noise_embedding_layer.weight,
+                                                       network.noise_embedding_layer.bias))
+        wt_, bt = (t.detach().to(f64).cpu() for t in (network.time_embedding_layer.weight,
+                                                        network.time_embedding_layer.bias))
+        columns = torch.cat([w0[:, :o1] @ wc,                     # [H, 2 N d]: cos block then sin block, as the module
+                             w0[:, o1:o2] @ wn,                   # [H, 1]  sigma
+                             w0[:, o2:o3] @ wt_,                  # [H, 1]  time
+                             w0[:, o3:o4],                        # [H, N ea]
+                             w0[:, o4:]], dim=1)                  # [H, el]
+        bias = b0 + w0[:, :o1] @ bc + w0[:, o1:o2] @ bn + w0[:, o2:o3] @ bt
+        H, F = columns.shape
+        quads = (F + 3) // 4
+        padded = torch.zeros(H, quads * 4, dtype=f64)
+        padded[:, :F] = columns
+        image = padded.t().reshape(quads, 4, H).permute(0, 2, 1).contiguous().reshape(-1)     # [q][neuron][4]
+        return torch.cat([image, bias]).to(device=device, dtype=F32).contiguous()
+
+
+MlpPack._fold_input_layers = staticmethod(_fold_input_layers)
 
 
 def mlp_forward(pack: MlpPack, atom_types, x, l, time, sigma):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 2
+#define MDX_ABI_VERSION 3
 
 /* status codes */
 #define MDX_OK 0
@@ -230,6 +230,14 @@ typedef struct mdx_mlp {
     const float* packed_image;                           /* optional (NULL allowed): all of the above re-laid out by
                                                             mdx_mlp_pack_image; lets a kernel stage the weights into
                                                             LDS with one coalesced copy */
+    const float* folded_input;                           /* optional (NULL allowed): the five embedding layers folded
+                                                            into hidden layer 0 (no activation lies between them), for the
+                                                            input vector [cos 2 pi x (N d) | sin 2 pi x (N d) | sigma | t |
+                                                            atom-type embeddings (N e_atom_type) | lattice embedding
+                                                            (e_lattice)] of length F: ceil(F/4) x hidden_size weight
+                                                            quads [q][neuron][4] (zero-padded), then the folded bias
+                                                            [hidden_size].  Used by mdx_mlp_pc_sample for the template
+                                                            network; same function, last-bit different rounding */
 } mdx_mlp_t;
 
 /* Size (in floats) and construction of the packed weight image referenced by mdx_mlp_t.packed_image. */

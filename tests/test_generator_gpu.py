@@ -623,6 +623,7 @@ def test_fused_sampler_specialised_equals_generic(cuda, monkeypatch):
     from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
     P = _pkg()
     outs = []
+    monkeypatch.setenv("MDX_MLP_FOLD", "0")                   # layer-by-layer form on both sides
     for generic in ("1", "0"):
         monkeypatch.setenv("MDX_MLP_GENERIC", generic)
         torch.manual_seed(1234)
@@ -633,6 +634,44 @@ def test_fused_sampler_specialised_equals_generic(cuda, monkeypatch):
             outs.append(_np(LangevinGenerator(npar, spar, net).sample(300, cuda)))
     assert np.array_equal(outs[0].A, outs[1].A)
     assert np.array_equal(outs[0].X.view(np.int32), outs[1].X.view(np.int32))
+
+
+def test_fused_sampler_folded_input_layer(cuda, monkeypatch):
+    """The template network with its five (linear) embedding layers folded into the first hidden layer against the
+    layer-by-layer form: the same function, rounding differs in the last bits.  One iteration from the same state
+    (nothing to amplify a difference): atom types exact, coordinates within 1e-6; a whole trajectory of a neutral
+    configuration (linear schedule): atom types exact, coordinates within 1e-5."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+    P = _pkg()
+    torch.manual_seed(1234)
+    net = nets.mlp_net(8, 1).to(cuda)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = P["Noise"](**cases.noise_ns(40, **cases.LIN))
+        spar = P["Sampling"](**cases.sampling_ns(8, 1), rng_mode="device", seed=3, fused_score_network=True)
+    gen = LangevinGenerator(npar, spar, net)
+    with torch.no_grad():
+        gen._prepare(cuda)
+        gen._begin_call(cuda)
+        start = gen.initialize(200, cuda)
+        sched, pack = gen._prepare(cuda), gen.fused_pack(cuda)
+        assert pack.folded is not None and pack.c_struct.folded_input
+        results = {}
+        for fold in ("1", "0"):
+            monkeypatch.setenv("MDX_MLP_FOLD", fold)
+            for n_iterations in (1, 40):
+                comp = RS.AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
+                kernels.mlp_pc_sample(sched, pack, gen._flags(True), 1, False, 40, n_iterations, gen._rng(0), comp.A,
+                                      comp.X, comp.L, gen._status)
+                results[fold, n_iterations] = _np(comp)
+    for n_iterations, tol in ((1, 1e-6), (40, 1e-5)):
+        a, b = results["1", n_iterations], results["0", n_iterations]
+        assert np.array_equal(a.A, b.A), n_iterations
+        assert torus_rel_l2(a.X, b.X) < tol, (n_iterations, torus_rel_l2(a.X, b.X))
+    assert not np.array_equal(results["1", 40].X, results["0", 40].X) or True    # (they may even coincide)
+    assert (results["1", 40].A != 1).all()
 
 
 # -------------------------------------------------------------------------------------------------------------
