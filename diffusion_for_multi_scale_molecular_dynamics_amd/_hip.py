@@ -65,7 +65,7 @@ class Mlp(C.Structure):
                                    "w_atom_type_t", "b_atom_type", "w_lattice_t", "b_lattice")] + \
         [("w_hidden_t", C.c_void_p * 8), ("b_hidden", C.c_void_p * 8)] + \
         [(n, C.c_void_p) for n in ("w_out_a_t", "b_out_a", "w_out_x_t", "b_out_x", "w_out_l_t", "b_out_l",
-                                   "packed_image", "folded_input")]
+                                   "packed_image", "folded_input", "folded_output")]
 
 
 def build(force=False):

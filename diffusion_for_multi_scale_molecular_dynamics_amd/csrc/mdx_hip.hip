@@ -931,9 +931,12 @@ __host__ __device__ inline int mlp_scratch_floats(const mdx_mlp_t& m)
 // the host folds the products once (binary64, mdx_mlp_t.folded_input), and the forward loses a whole layer -- 12 + 19
 // weight quads become 15, one LDS hand-off and 64 weight registers less.  Same function; the rounding differs from the
 // layer-by-layer evaluation in the last bits (the fused path is compared with the PyTorch module at 1e-5, not bitwise).
+// The same holds at the other end: the last hidden layer has no activation (:337-344), so it and the three output heads
+// are one 64 -> 46 linear map (mdx_mlp_t.folded_output).  The template network is then three layers -- 15 + 16 + 16
+// weight quads = 188 registers, no AGPR traffic -- instead of five.
 struct MlpRegsFolded {
-    lds_f4 wf[15], wh1[16], wh2[16], wo[16];
-    float bf, bh1, bh2, bo;
+    lds_f4 wf[15], wh1[16], wfo[16];
+    float bf, bh1, bfo;
 };
 
 __device__ __forceinline__ void load_mlp_regs_folded(MlpRegsFolded& R, const mdx_mlp_t& m, const MlpWeightsLds& w, int lane)
@@ -945,12 +948,11 @@ __device__ __forceinline__ void load_mlp_regs_folded(MlpRegsFolded& R, const mdx
     R.bf = m.folded_input[15 * 64 * 4 + lane];
 #pragma unroll
     for (int q = 0; q < 16; ++q) R.wh1[q] = ((lds_cf4*)w.wh(1))[q * 64 + lane];
+    const lds_f4* out = reinterpret_cast<const lds_f4*>(m.folded_output);        // [16][46] quads, then the bias [46]
 #pragma unroll
-    for (int q = 0; q < 16; ++q) R.wh2[q] = ((lds_cf4*)w.wh(2))[q * 64 + lane];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) R.wo[q] = lane < 46 ? ((lds_cf4*)w.woa)[q * 46 + lane] : zero;
-    R.bh1 = w.bh(1)[lane]; R.bh2 = w.bh(2)[lane];
-    R.bo = lane < 46 ? w.boa[lane] : 0.0f;
+    for (int q = 0; q < 16; ++q) R.wfo[q] = lane < 46 ? out[q * 46 + lane] : zero;
+    R.bh1 = w.bh(1)[lane];
+    R.bfo = lane < 46 ? m.folded_output[16 * 46 * 4 + lane] : 0.0f;
 }
 
 __device__ __forceinline__ void mlp_forward_folded(const MlpWeightsLds& w, const MlpRegsFolded& R, int lane, lds_cf* x,
@@ -982,10 +984,8 @@ __device__ __forceinline__ void mlp_forward_folded(const MlpWeightsLds& w, const
     wave_sync();
     buf_b[lane] = silu_(dot_regs<16>(R.wh1, buf_a, R.bh1));
     wave_sync();
-    buf_a[lane] = dot_regs<16>(R.wh2, buf_b, R.bh2);
-    wave_sync();
     if (lane < 46) {                                            // logits (16) | score_x (24) | score_l (6), contiguous
-        const float o = dot_regs<16>(R.wo, buf_a, R.bo);
+        const float o = dot_regs<16>(R.wfo, buf_b, R.bfo);
         logits[lane] = (lane < 16 && (lane & 1)) ? -__builtin_huge_valf() : o;
     }
     wave_sync();
@@ -2018,7 +2018,7 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
         // 0: generic instantiation; 1: template dimensions as literals; 2: the same with the folded input layer
         const char* fold = getenv("MDX_MLP_FOLD");                // tests: "0" keeps the layer-by-layer form
         int spec = matches_template_mlp(*mlp_host) && !(generic && generic[0] == '1') ? 1 : 0;
-        if (spec == 1 && mlp_host->folded_input && !(fold && fold[0] == '0')) spec = 2;
+        if (spec == 1 && mlp_host->folded_input && mlp_host->folded_output && !(fold && fold[0] == '0')) spec = 2;
         if (lds > kMlpLdsBudget) {       // up to 128 KiB of the CU's 160 KiB: opt in above the 64 KiB default
             // the attribute is a property of the code object: set it when the requirement grows, not on every launch
             static std::atomic<size_t> granted[16];

@@ -274,8 +274,11 @@ class MlpPack:
         m.packed_image = None
         m.folded_input = None
         self.folded = self._fold_input_layers(network, m, device)
-        if self.folded is not None:
+        m.folded_output = None
+        self.folded_out = _fold_output_layers(network, device) if self.folded is not None else None
+        if self.folded is not None and self.folded_out is not None:
             m.folded_input = self.folded.data_ptr()
+            m.folded_output = self.folded_out.data_ptr()
         n_floats = lib().mdx_mlp_image_floats(C.byref(m))
         if n_floats > 0:      # the kernels' own layout, built once: kernel start-up becomes one coalesced copy
             self.image = torch.empty(n_floats, dtype=F32, device=device)
@@ -319,6 +322,32 @@ def _fold_input_layers(network, m, device):
         padded[:, :F] = columns
         image = padded.t().reshape(quads, 4, H).permute(0, 2, 1).contiguous().reshape(-1)     # [q][neuron][4]
         return torch.cat([image, bias]).to(device=device, dtype=F32).contiguous()
+
+
+def _quad_image(matrix64: torch.Tensor) -> torch.Tensor:
+    """[outputs, inputs] matrix -> the kernels' [ceil(inputs/4)][outputs][4] layout (inputs zero-padded)."""
+    n_out, n_in = matrix64.shape
+    quads = (n_in + 3) // 4
+    padded = torch.zeros(n_out, quads * 4, dtype=matrix64.dtype)
+    padded[:, :n_in] = matrix64
+    return padded.t().reshape(quads, 4, n_out).permute(0, 2, 1).contiguous().reshape(-1)
+
+
+def _fold_output_layers(network, device):
+    """The last hidden layer (no activation follows it, mlp_score_network.py:337-344) folded into the three output
+    heads (mdx_mlp_t.folded_output): outputs ordered logits | score_x | score_l.  Needs >= 2 hidden layers."""
+    if len(network.mlp_layers) < 2:
+        return None
+    f64 = torch.float64
+    with torch.no_grad():
+        last = network.mlp_layers[-1]
+        w_last, b_last = last.weight.detach().to(f64).cpu(), last.bias.detach().to(f64).cpu()
+        heads = (network.output_A_layer, network.output_X_layer, network.output_L_layer)
+        w_heads = torch.cat([h.weight.detach().to(f64).cpu() for h in heads], dim=0)        # [N C + N d + nl, H]
+        b_heads = torch.cat([h.bias.detach().to(f64).cpu() for h in heads], dim=0)
+        folded = w_heads @ w_last                                                           # [outputs, H_in of last]
+        bias = w_heads @ b_last + b_heads
+        return torch.cat([_quad_image(folded), bias]).to(device=device, dtype=F32).contiguous()
 
 
 MlpPack._fold_input_layers = staticmethod(_fold_input_layers)

@@ -238,6 +238,11 @@ typedef struct mdx_mlp {
                                                             quads [q][neuron][4] (zero-padded), then the folded bias
                                                             [hidden_size].  Used by mdx_mlp_pc_sample for the template
                                                             network; same function, last-bit different rounding */
+    const float* folded_output;                          /* optional, used together with folded_input: the last hidden
+                                                            layer (no activation follows it) folded into the three heads:
+                                                            ceil(hidden_size/4) x (N C + N d + d(d+1)/2) weight quads
+                                                            [q][output][4] (outputs: logits | score_x | score_l), then the
+                                                            folded bias */
 } mdx_mlp_t;
 
 /* Size (in floats) and construction of the packed weight image referenced by mdx_mlp_t.packed_image. */

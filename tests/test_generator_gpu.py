@@ -657,7 +657,7 @@ def test_fused_sampler_folded_input_layer(cuda, monkeypatch):
         gen._begin_call(cuda)
         start = gen.initialize(200, cuda)
         sched, pack = gen._prepare(cuda), gen.fused_pack(cuda)
-        assert pack.folded is not None and pack.c_struct.folded_input
+        assert pack.c_struct.folded_input and pack.c_struct.folded_output
         results = {}
         for fold in ("1", "0"):
             monkeypatch.setenv("MDX_MLP_FOLD", fold)
