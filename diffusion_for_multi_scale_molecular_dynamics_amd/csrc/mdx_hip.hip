@@ -332,12 +332,44 @@ __device__ __forceinline__ void posterior(const float* __restrict__ logits, int 
     }
 }
 
-template <int G>
+// The value of a partner lane at "distance" O inside a group of lanes, for all-to-all reductions over the group
+// (AND, arg-max over a total order: any complete exchange pattern gives every lane the same result).  O = 1, 2: DPP
+// quad permutes; O = 4, 8: DPP mirrors inside 8 / 16 lanes (lane i <-> 7-i / 15-i pairs the two halves once the halves
+// are reduced); O = 16, 32: cross-row, through ds_bpermute.  The DPP forms are register moves; a ds_bpermute goes
+// through the LDS crossbar and costs ~100 cycles of latency each on a lone wavefront.
+template <int O>
+__device__ __forceinline__ int partner(int v)
+{
+    if constexpr (O == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if constexpr (O == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if constexpr (O == 4) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    else if constexpr (O == 8) return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false);  // row_mirror
+    else return __shfl_xor(v, O, kWave);
+}
+template <int O>
+__device__ __forceinline__ float partner(float v) { return __int_as_float(partner<O>(__float_as_int(v))); }
+
+template <int G, int O = G / 2>
 __device__ __forceinline__ int group_and(int v)
 {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v &= __shfl_xor(v, o, kWave);
+    if constexpr (O > 0) {
+        // smallest distance first, so that the mirror steps pair fully reduced halves
+        v = group_and<G, O / 2>(v);
+        v &= partner<O>(v);
+    }
     return v;
+}
+
+template <int G, int O = G / 2>
+__device__ __forceinline__ void group_argmax(float& best_v, int& best_n, int& best_prop)
+{
+    if constexpr (O > 0) {
+        group_argmax<G, O / 2>(best_v, best_n, best_prop);
+        const float ov = partner<O>(best_v);
+        const int on = partner<O>(best_n);
+        const int op = partner<O>(best_prop);
+        if (ov > best_v || (ov == best_v && on < best_n)) { best_v = ov; best_n = on; best_prop = op; }
+    }
 }
 
 // Per-step, wave-uniform data of one update
@@ -478,14 +510,9 @@ __device__ __forceinline__ void pc_update_structure(const PcArgs& p, const PcSte
         }
     }
     if (update_types && one) {
-        // arg-max over the atoms of the structure: larger value wins, ties go to the smaller atom index
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best_v, o, kWave);
-            const int on = __shfl_xor(best_n, o, kWave);
-            const int op = __shfl_xor(best_prop, o, kWave);
-            if (ov > best_v || (ov == best_v && on < best_n)) { best_v = ov; best_n = on; best_prop = op; }
-        }
+        // arg-max over the atoms of the structure: larger value wins, ties go to the smaller atom index (a total
+        // order, so the exchange pattern does not matter)
+        group_argmax<G>(best_v, best_n, best_prop);
         if (lane == 0 && best_n < N) v.a_out[best_n] = best_prop;
     }
     if (p.do_lattice) {                                          // :475-490
