@@ -300,12 +300,9 @@ struct PcArgs {
 // bound MDX_MAX_CLASSES with a (c < C) predicate so that e[] / p[] stay in registers (no scratch); the operations
 // performed, and their order, are those of the runtime-bound loops.
 #define MDX_FOR_CLASSES(c) _Pragma("unroll") for (int c = 0; c < MDX_MAX_CLASSES; ++c) if (c < C)
-__device__ __forceinline__ void posterior(const float* __restrict__ logits, int a_t, const float* __restrict__ q,
-                                          const float* __restrict__ qbar, const float* __restrict__ qbar_tm1, int C,
-                                          float small_eps, float* p)
+// softmax -> clip at small_epsilon -> renormalise: the class probabilities the posterior starts from
+__device__ __forceinline__ void clipped_softmax(const float* lg, int C, float small_eps, float* e)
 {
-    float e[MDX_MAX_CLASSES], lg[MDX_MAX_CLASSES];
-    MDX_FOR_CLASSES(c) lg[c] = logits[c];
     float m = lg[0];
     MDX_FOR_CLASSES(c) if (c > 0) m = (lg[c] > m) ? lg[c] : m;
     float S = 0.0f;
@@ -322,6 +319,36 @@ __device__ __forceinline__ void posterior(const float* __restrict__ logits, int 
         S2 = S2 + r;
     }
     MDX_FOR_CLASSES(c) e[c] = e[c] / S2;
+}
+
+// With ONE atom type (C = 2) the logits are (l0, -inf) -- the network API forces the MASK logit to -inf
+// (score_network.py:183-185) -- and clipped_softmax does not depend on l0 as long as it is finite: l0 - max = 0 exactly,
+// exp(0) = 1, exp(-inf) = 0.  Its result is then a per-launch constant: the same operations on (0, -inf), evaluated once
+// (the persistent sampler does this outside its loop) instead of two exp and three divisions per atom and step.
+struct FixedSoftmaxC2 {
+    float e0, e1;
+    int valid;
+};
+
+__device__ __forceinline__ FixedSoftmaxC2 fixed_softmax_c2(float small_eps)
+{
+    constexpr int C = 2;
+    float lg[MDX_MAX_CLASSES] = {0.0f, -__builtin_huge_valf()}, e[MDX_MAX_CLASSES];
+    clipped_softmax(lg, C, small_eps, e);
+    return FixedSoftmaxC2{e[0], e[1], 1};
+}
+
+__device__ __forceinline__ void posterior(const float* __restrict__ logits, int a_t, const float* __restrict__ q,
+                                          const float* __restrict__ qbar, const float* __restrict__ qbar_tm1, int C,
+                                          float small_eps, float* p, const FixedSoftmaxC2& fixed = FixedSoftmaxC2{0.0f, 0.0f, 0})
+{
+    float e[MDX_MAX_CLASSES], lg[MDX_MAX_CLASSES];
+    MDX_FOR_CLASSES(c) lg[c] = logits[c];
+    if (C == 2 && fixed.valid && lg[1] == -__builtin_huge_valf() && __builtin_fabsf(lg[0]) < __builtin_huge_valf()) {
+        MDX_FOR_CLASSES(c) e[c] = c == 0 ? fixed.e0 : fixed.e1;
+    } else {
+        clipped_softmax(lg, C, small_eps, e);
+    }
     float den = 0.0f;
     MDX_FOR_CLASSES(j) den = den + e[j] * qbar[j * C + a_t];
     MDX_FOR_CLASSES(i) {
@@ -378,6 +405,7 @@ struct PcStep {
     const float *q, *qbar, *qbar_tm1;
     int one, last_predictor_step;
     uint32_t draw, k0, k1, call8;
+    FixedSoftmaxC2 fixed_c2;     // valid = 0 unless the caller evaluated it (persistent sampler, one atom type)
 };
 
 // Pointers of ONE structure (already offset to it); item0 = global index of its atom 0 in the Philox stream.
@@ -409,6 +437,7 @@ __device__ __forceinline__ PcStep make_step(const PcArgs& p, int mode, int index
     st.k0 = (uint32_t)p.rng.seed;
     st.k1 = (uint32_t)(p.rng.seed >> 32);
     st.call8 = p.rng.call << 8;
+    st.fixed_c2 = FixedSoftmaxC2{0.0f, 0.0f, 0};
     return st;
 }
 
@@ -439,7 +468,7 @@ __device__ __forceinline__ void pc_update_structure(const PcArgs& p, const PcSte
         if (update_types) {
             const int a_t = (int)v.a[n];
             float pr[MDX_MAX_CLASSES], gm[MDX_MAX_CLASSES];
-            posterior(v.logits + n * C, a_t, st.q, st.qbar, st.qbar_tm1, C, p.small_eps, pr);
+            posterior(v.logits + n * C, a_t, st.q, st.qbar, st.qbar_tm1, C, p.small_eps, pr, st.fixed_c2);
             if (v.gumbel) {
                 MDX_FOR_CLASSES(c) gm[c] = v.gumbel[n * C + c];
             } else {
@@ -1089,7 +1118,7 @@ struct MlpSampleArgs {
     PcArgs pc;               // flags, schedule, rng, dims (pointers unused)
     mdx_mlp_t mlp;
     int M, types_in_corrector, start_index, n_iterations;
-    int diag_skip;           // diagnostic builds of the timing breakdown only (MDX_DIAG_SKIP): 1 = no forward, 2 = no update
+    int diag_skip;           // diagnostics / tests (MDX_DIAG_SKIP bits): 1 = no forward, 2 = no update, 8 = no hoisted softmax
     int64_t* a;
     float *x, *l;
     // pre-drawn noise (pc_noise_fill_kernel): records [iteration][structure][predictor rec0 | M x corrector rec1];
@@ -1200,6 +1229,9 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
             v.a_out = (int64_t*)r.a; v.x_out = (float*)r.x; v.l_out = (float*)r.l; v.p_out = nullptr;
             v.item0 = b * N;
             v.b = b;
+            // one atom type: the clipped softmax of (l0, -inf) is a constant of the launch
+            const FixedSoftmaxC2 fixed_c2 = (p.pc.C == 2 && !(p.diag_skip & 8)) ? fixed_softmax_c2(p.pc.small_eps)
+                                                                                : FixedSoftmaxC2{0.0f, 0.0f, 0};
             PcArgs pc_types_only = p.pc;                                   // P2 + P3 only (P1 done one lane per component)
             pc_types_only.do_coords = 0;
             constexpr int kPre = SPEC >= 1 ? 1 : (MDX_MAX_CLASSES + 4);   // 64-lane fetches covering N (d + C + 1) floats
@@ -1208,7 +1240,8 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
                 const int i = p.start_index - 1 - it;               // loop variable of the reference (:147)
                 for (int sub = 0; sub <= p.M; ++sub) {
                     const int mode = sub == 0 ? MDX_PREDICTOR : MDX_CORRECTOR;
-                    const PcStep st = make_step(p.pc, mode, sub == 0 ? i + 1 : i, (uint32_t)sub);
+                    PcStep st = make_step(p.pc, mode, sub == 0 ? i + 1 : i, (uint32_t)sub);
+                    st.fixed_c2 = fixed_c2;
                     const int types = sub == 0 ? 1 : p.types_in_corrector;
                     // this step's pre-drawn noise: fetched now, needed after the forward (the load's latency is hidden
                     // behind it), handed to the update through LDS
