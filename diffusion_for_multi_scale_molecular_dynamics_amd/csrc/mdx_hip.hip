@@ -412,6 +412,7 @@ struct PcStep {
 struct PcView {
     const int64_t* a;
     const float *x, *l, *logits, *score_x, *score_l, *z_coord, *gumbel, *u, *z_lat;
+    const float* p2_table = nullptr;   // one atom type: this step's posterior in closed form (kP2Table floats), see below
     int64_t* a_out;
     float *x_out, *l_out, *p_out;
     int64_t item0, b;
@@ -467,8 +468,25 @@ __device__ __forceinline__ void pc_update_structure(const PcArgs& p, const PcSte
         const uint32_t item = (uint32_t)(v.item0 + n);
         if (update_types) {
             const int a_t = (int)v.a[n];
-            float pr[MDX_MAX_CLASSES], gm[MDX_MAX_CLASSES];
-            posterior(v.logits + n * C, a_t, st.q, st.qbar, st.qbar_tm1, C, p.small_eps, pr, st.fixed_c2);
+            float pr[MDX_MAX_CLASSES], gm[MDX_MAX_CLASSES], lv[MDX_MAX_CLASSES];
+            // One atom type, logits (finite, -inf): the posterior depends on the step and on a_t only, and the pre-pass
+            // has evaluated it for both values of a_t (p2_table: p[MASK] and log(p[c] + eps)); otherwise evaluate it here.
+            bool tabulated = false;
+            float pr_mask = 0.0f, log_eps = 0.0f;
+            if (C == 2 && v.p2_table && !v.p_out) {
+                const float l0 = v.logits[n * C], l1 = v.logits[n * C + 1];
+                if (l1 == -__builtin_huge_valf() && __builtin_fabsf(l0) < __builtin_huge_valf()) {
+                    tabulated = true;
+                    const int sel = a_t != 0;
+                    pr_mask = v.p2_table[sel];
+                    MDX_FOR_CLASSES(c) lv[c] = v.p2_table[2 + 2 * sel + c];
+                    log_eps = v.p2_table[6];
+                }
+            }
+            if (!tabulated) {
+                posterior(v.logits + n * C, a_t, st.q, st.qbar, st.qbar_tm1, C, p.small_eps, pr, st.fixed_c2);
+                MDX_FOR_CLASSES(c) if (c == M) pr_mask = pr[c];
+            }
             if (v.gumbel) {
                 MDX_FOR_CLASSES(c) gm[c] = v.gumbel[n * C + c];
             } else {
@@ -481,23 +499,27 @@ __device__ __forceinline__ void pc_update_structure(const PcArgs& p, const PcSte
                             if (sub * 4 + l < C) gm[sub * 4 + l] = gumbel_from_u(u01(r.v[l]));
                     }
             }
-            float pr_mask = 0.0f;
-            MDX_FOR_CLASSES(c) if (c == M) pr_mask = pr[c];
+            bool zero_mask = false;
             if (p.greedy) {                                      // :382-439
                 float uu;
                 if (v.u) uu = v.u[n];
                 else uu = u01(philox4x32_10(item, st.call8, st.draw, MDX_TAG_BINARY, st.k0, st.k1).v[0]);
                 const int unmask = uu > pr_mask;
-                const bool zero_mask = !all_masked && unmask && a_t == M;
+                zero_mask = !all_masked && unmask && a_t == M;
                 MDX_FOR_CLASSES(c) {
                     if (zero_mask && c == M) pr[c] = 0.0f;
                     if (!all_masked) gm[c] = 0.0f;
                 }
             }
+            if (tabulated) {
+                MDX_FOR_CLASSES(c) if (zero_mask && c == M) lv[c] = log_eps;      // log(0 + eps)
+            } else {
+                MDX_FOR_CLASSES(c) lv[c] = logf_(pr[c] + p.small_eps);
+            }
             float v_best = 0.0f;
             int prop = 0;
             MDX_FOR_CLASSES(c) {                                 // :311-315, first maximal index
-                const float val = logf_(pr[c] + p.small_eps) + gm[c];
+                const float val = lv[c] + gm[c];
                 if (c == 0 || val > v_best) { v_best = val; prop = c; }
                 if (v.p_out) v.p_out[n * C + c] = pr[c];
             }
@@ -1052,7 +1074,7 @@ __host__ __device__ inline int mlp_wave_floats(const mdx_mlp_t& m)
 {
     const int N = m.number_of_atoms, d = m.spatial_dimension, C = m.num_classes, nl = d * (d + 1) / 2;
     const int f = 2 * mlp_scratch_floats(m) + 2 * N + N * d + ((nl + 3) & ~3) + N * C + N * d + ((nl + 3) & ~3) +
-                  N * (d + C + 1);
+                  N * (d + C + 1) + 8;           // 8 = kP2Table
     return (f + 3) & ~3;
 }
 
@@ -1132,8 +1154,11 @@ struct MlpSampleArgs {
 // fills the chip (one lane per atom and step) instead of inside the persistent kernel, where a structure's N atoms
 // occupy N of the wavefront's 64 lanes and the ~600-instruction Philox / Box-Muller / Gumbel sequence sits on the
 // critical path of every step.  Same counters, same functions => the same bits as the in-kernel draws.
+constexpr int kP2Table = 8;   // per type-update record: p[MASK | a_t = 0, 1], log(p[c] + eps | a_t = 0, 1), log(eps), 1
 struct NoiseFillArgs {
     mdx_rng_t rng;
+    SchedDev sched;
+    float small_eps;
     int start_index, n_iterations, types_in_corrector, greedy;
     int64_t B;
     int N, d, C, rec0, rec1, M;
@@ -1172,6 +1197,28 @@ __global__ __launch_bounds__(kBlock) void pc_noise_fill_kernel(NoiseFillArgs p)
             }
             if (p.greedy)
                 rec[N * d + N * C + n] = u01(philox4x32_10((uint32_t)item, call8, draw, MDX_TAG_BINARY, k0, k1).v[0]);
+            if (n == 0) {
+                // One atom type: with logits (finite, -inf) the posterior p(a_{t-1} | a_t) of this step is a function of
+                // a_t alone -- evaluated here once per step for a_t = 0 and a_t = MASK with the update's own functions
+                // (same bits), so that the update only selects.  Other class counts: table marked invalid.
+                float* t = rec + N * (d + C + 1);
+                t[7] = 0.0f;
+                if (C == 2) {
+                    const int idx = sub == 0 ? i : (i > 0 ? i - 1 : 0);         // the step's row of the Q tables
+                    const float lgc[2] = {0.0f, -__builtin_huge_valf()};
+                    const FixedSoftmaxC2 fixed = fixed_softmax_c2(p.small_eps);
+                    for (int sel = 0; sel < 2; ++sel) {
+                        float pr[MDX_MAX_CLASSES];
+                        posterior(lgc, sel, p.sched.q + idx * 4, p.sched.qbar + idx * 4, p.sched.qbar_tm1 + idx * 4, 2,
+                                  p.small_eps, pr, fixed);
+                        t[sel] = pr[1];
+                        t[2 + 2 * sel] = logf_(pr[0] + p.small_eps);
+                        t[3 + 2 * sel] = logf_(pr[1] + p.small_eps);
+                    }
+                    t[6] = logf_(0.0f + p.small_eps);
+                    t[7] = 1.0f;
+                }
+            }
         }
     }
 }
@@ -1234,7 +1281,7 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
                                                                                 : FixedSoftmaxC2{0.0f, 0.0f, 0};
             PcArgs pc_types_only = p.pc;                                   // P2 + P3 only (P1 done one lane per component)
             pc_types_only.do_coords = 0;
-            constexpr int kPre = SPEC >= 1 ? 1 : (MDX_MAX_CLASSES + 4);   // 64-lane fetches covering N (d + C + 1) floats
+            constexpr int kPre = SPEC >= 1 ? 1 : (MDX_MAX_CLASSES + 5);   // 64-lane fetches covering N (d + C + 1) floats
             const int rec_total = p.rec0 + p.M * p.rec1;
             for (int it = 0; it < p.n_iterations; ++it) {
                 const int i = p.start_index - 1 - it;               // loop variable of the reference (:147)
@@ -1272,6 +1319,8 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
                         v.z_coord = (const float*)r.noise;
                         v.gumbel = (const float*)(r.noise + N * d);
                         v.u = p.pc.greedy ? (const float*)(r.noise + N * d + N * p.pc.C) : nullptr;
+                        v.p2_table = (types && r.noise[N * (d + p.pc.C + 1) + 7] == 1.0f && !(p.diag_skip & 16))
+                                         ? (const float*)(r.noise + N * (d + p.pc.C + 1)) : nullptr;
                     }
                     if (p.noise && !(p.diag_skip & 2)) {
                         // with pre-drawn noise the coordinate update is elementwise over the N d components: one lane
@@ -1992,7 +2041,7 @@ int64_t mdx_mlp_pc_sample_workspace_floats(const mdx_mlp_t* mlp_host, int number
 {
     if (!mlp_host || number_of_corrector_steps < 0 || n_iterations < 0 || batch < 0) return -1;
     const int64_t N = mlp_host->number_of_atoms, d = mlp_host->spatial_dimension, C = mlp_host->num_classes;
-    const int64_t rec0 = N * (d + C + 1), rec1 = atom_type_transition_in_corrector ? rec0 : N * d;
+    const int64_t rec0 = N * (d + C + 1) + kP2Table, rec1 = atom_type_transition_in_corrector ? rec0 : N * d;
     return (rec0 + number_of_corrector_steps * rec1) * batch * n_iterations;
 }
 
@@ -2052,7 +2101,7 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
     a.start_index = start_index;
     a.n_iterations = n_iterations;
     a.a = atom_types; a.x = x; a.l = l;
-    a.rec0 = pc.N * (pc.d + pc.C + 1);
+    a.rec0 = pc.N * (pc.d + pc.C + 1) + kP2Table;
     a.rec1 = a.types_in_corrector ? a.rec0 : pc.N * pc.d;
     a.noise = noise_workspace;
     if (const char* diag = getenv("MDX_DIAG_SKIP")) a.diag_skip = atoi(diag);
@@ -2064,6 +2113,7 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
     if (noise_workspace) {
         NoiseFillArgs nf{};
         nf.rng = pc.rng;
+        nf.sched = pc.sched; nf.small_eps = pc.small_eps;
         nf.start_index = start_index; nf.n_iterations = n_iterations;
         nf.types_in_corrector = a.types_in_corrector; nf.greedy = pc.greedy;
         nf.B = batch; nf.N = pc.N; nf.d = pc.d; nf.C = pc.C; nf.rec0 = a.rec0; nf.rec1 = a.rec1; nf.M = a.M;

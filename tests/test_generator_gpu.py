@@ -488,8 +488,9 @@ def test_fused_sampler_predrawn_noise_equals_in_kernel_draws(cuda, name, in_corr
             outs.append(comp)
         monkeypatch.undo()
         kernels._NOISE_WORKSPACE.clear()
-        floats = T * 19 * spar.number_of_atoms * ((3 + gen.num_classes + 1) * (1 + (M if in_corrector else 0))
-                                                  + (0 if in_corrector else 3 * M))
+        rec0 = spar.number_of_atoms * (3 + gen.num_classes + 1) + 8      # z | gumbel | u | tabulated posterior (8)
+        rec1 = rec0 if in_corrector else spar.number_of_atoms * 3
+        floats = T * 19 * (rec0 + M * rec1)
         assert kernels.lib().mdx_mlp_pc_sample_workspace_floats(pack.c_struct, M, int(in_corrector), T, 19) == floats
         assert kernels.noise_workspace(pack, M, in_corrector, T, 19, cuda).numel() >= floats
     for other in outs[1:]:
@@ -636,14 +637,16 @@ def test_fused_sampler_specialised_equals_generic(cuda, monkeypatch):
     assert np.array_equal(outs[0].X.view(np.int32), outs[1].X.view(np.int32))
 
 
+@pytest.mark.parametrize("in_corrector", [False, True])
 @pytest.mark.parametrize("small_epsilon", [1e-8, 1e-6, 1e-3])
-def test_fused_sampler_hoisted_softmax_is_exact(cuda, monkeypatch, small_epsilon):
-    """One atom type: the clipped softmax of (l0, -inf) is evaluated once per launch instead of per atom and step.
-    Same bits as the per-atom evaluation (MDX_DIAG_SKIP bit 8 switches the hoisting off), any small_epsilon."""
+def test_fused_sampler_hoisted_softmax_is_exact(cuda, monkeypatch, small_epsilon, in_corrector):
+    """One atom type: the clipped softmax of (l0, -inf) is evaluated once per launch, and the whole posterior of a
+    step -- a function of a_t alone -- once per step by the noise pre-pass, instead of per atom and step.  Same bits as
+    the per-atom evaluation (MDX_DIAG_SKIP bits 8 and 16 switch the two off), any small_epsilon, greedy or not."""
     from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
     P = _pkg()
     outs = []
-    for flag in ("8", "0"):
+    for flag in ("24", "16", "8", "0"):
         monkeypatch.setenv("MDX_DIAG_SKIP", flag)
         torch.manual_seed(1234)
         net = nets.mlp_net(8, 1).to(cuda)
@@ -651,13 +654,19 @@ def test_fused_sampler_hoisted_softmax_is_exact(cuda, monkeypatch, small_epsilon
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             npar = P["Noise"](**cases.noise_ns(30, **cases.LIN))
-            spar = P["Sampling"](**cases.sampling_ns(8, 1, eps=small_epsilon), rng_mode="device", seed=3,
-                                 fused_score_network=True)
+            spar = P["Sampling"](**cases.sampling_ns(8, 1, eps=small_epsilon, in_corr=in_corrector,
+                                                     greedy=not in_corrector, one=not in_corrector, M=2),
+                                 rng_mode="device", seed=3, fused_score_network=True)
+        gen = LangevinGenerator(npar, spar, net)
         with torch.no_grad():
-            outs.append(_np(LangevinGenerator(npar, spar, net).sample(300, cuda)))
+            gen._prepare(cuda)
+            gen._begin_call(cuda)
+            start = gen.initialize(300, cuda)
+            outs.append(_np(gen._sample_fused(start, 30, 0)))       # no status check: a MASK may legitimately survive
     monkeypatch.delenv("MDX_DIAG_SKIP")
-    assert np.array_equal(outs[0].A, outs[1].A)
-    assert np.array_equal(outs[0].X.view(np.int32), outs[1].X.view(np.int32))
+    for other in outs[1:]:
+        assert np.array_equal(outs[0].A, other.A)
+        assert np.array_equal(outs[0].X.view(np.int32), other.X.view(np.int32))
 
 
 def test_fused_sampler_folded_input_layer(cuda, monkeypatch):
