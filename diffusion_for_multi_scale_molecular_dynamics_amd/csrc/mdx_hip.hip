@@ -670,6 +670,11 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// SiLU of the fused network forward: hardware exp2 / reciprocal (~1e-7 relative).  The forward is compared with the
+// PyTorch module at 1e-5 (it is not part of the bit-exact MDX arithmetic contract, which covers the update kernels and
+// the RNG); the IEEE sequence a / (1 + expf_(-a)) cost ~50 dependent instructions per layer on the critical path.
+__device__ __forceinline__ float silu_(float a) { return __fdividef(a, 1.0f + __expf(-a)); }
+
 // out[j] = bias[j] + sum_k in[k] * W[k][j]; lanes are output neurons, the input vector is broadcast from LDS four
 // values at a time.  Four interleaved partial sums (k mod 4) shorten the dependent fmaf chain; they are added as
 // ((s0+s1)+(s2+s3))+bias.  QUAD = true: the weights are the LDS image layout [k/4][j][k%4] (one 16-byte read per
@@ -710,7 +715,7 @@ __device__ __forceinline__ void linear_wave(WP wt, WP bias, lds_cf* in, int in_d
             }
         }
         float acc = ((s0 + s1) + (s2 + s3)) + bias[j];
-        if (silu_out) acc = acc / (1.0f + expf_(-acc));      // SiLU
+        if (silu_out) acc = silu_(acc);
         out[j] = acc;
     }
 }
@@ -953,7 +958,7 @@ __device__ __forceinline__ float dot_regs(const lds_f4 (&wq)[KQ], lds_cf* in, fl
     return ((s01.x + s01.y) + (s23.x + s23.y)) + bias;
 }
 
-__device__ __forceinline__ float silu_(float a) { return a / (1.0f + expf_(-a)); }
+
 
 // mlp_forward_wave for the template dimensions (N 8, d 3, C 2, embeddings 32/16/16/1/1, hidden 64 x 3)
 __device__ __forceinline__ void mlp_forward_regs(const MlpWeightsLds& w, const MlpRegs& R, int lane, lds_cf* x, lds_ci64* a,
