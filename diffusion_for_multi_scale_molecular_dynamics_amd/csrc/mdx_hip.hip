@@ -1268,7 +1268,14 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
         [[maybe_unused]] MlpRegs regs;
         [[maybe_unused]] MlpRegsFolded folded;
         if constexpr (SPEC == 1 && LDS_WEIGHTS) load_mlp_regs(regs, w, lane);
-        if constexpr (SPEC == 2 && LDS_WEIGHTS) load_mlp_regs_folded(folded, m, w, lane);
+        if constexpr (SPEC == 2 && LDS_WEIGHTS) {
+            load_mlp_regs_folded(folded, m, w, lane);
+            // The folded weights come from global memory.  Complete those loads HERE: left pending into the loop, the
+            // compiler must assume them outstanding at the loop head and guards the first FMAs of every iteration with
+            // vmcnt waits -- which, the counter being in-order, also wait for the noise record requested just before,
+            // i.e. expose its whole latency in every sub-step.
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+        }
         for (int64_t b = (int64_t)blockIdx.x * kMlpWaves + wave; b < p.pc.B; b += (int64_t)gridDim.x * kMlpWaves) {
             for (int e = lane; e < N; e += kWave) r.a[e] = p.a[b * N + e];
             for (int e = lane; e < N * d; e += kWave) r.x[e] = p.x[b * N * d + e];
