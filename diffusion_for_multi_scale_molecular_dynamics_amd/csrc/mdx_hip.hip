@@ -1071,7 +1071,7 @@ __device__ __forceinline__ void mlp_forward_folded(const MlpWeightsLds& w, const
         const float o = dot_regs<16>(R.wfo, buf_b, R.bfo);
         logits[lane] = (lane < 16 && (lane & 1)) ? -__builtin_huge_valf() : o;
     }
-    wave_sync();
+    // no hand-off here: the caller stores the step's noise record next to these outputs and synchronises once
 }
 
 // floats of LDS one wavefront needs besides the shared weight image
@@ -1327,7 +1327,9 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
 #pragma unroll
                         for (int j = 0; j < kPre; ++j)
                             if (j * kWave + lane < rec_len) r.noise[j * kWave + lane] = pre[j];
-                        wave_sync();
+                    }
+                    wave_sync();                                     // network outputs + noise record visible to the update
+                    if (p.noise) {
                         v.z_coord = (const float*)r.noise;
                         v.gumbel = (const float*)(r.noise + N * d);
                         v.u = p.pc.greedy ? (const float*)(r.noise + N * d + N * p.pc.C) : nullptr;
