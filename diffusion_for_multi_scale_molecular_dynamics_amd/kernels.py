@@ -273,7 +273,7 @@ class MlpPack:
             setattr(m, f"b_out_{name}", bias(layer))
         m.packed_image = None
         m.folded_input = None
-        self.folded = self._fold_input_layers(network, m, device)
+        self.folded = _fold_input_layers(network, m, device)
         m.folded_output = None
         self.folded_out = _fold_output_layers(network, device) if self.folded is not None else None
         if self.folded is not None and self.folded_out is not None:
@@ -316,12 +316,7 @@ def _fold_input_layers(network, m, device):
                              w0[:, o3:o4],                        # [H, N ea]
                              w0[:, o4:]], dim=1)                  # [H, el]
         bias = b0 + w0[:, :o1] @ bc + w0[:, o1:o2] @ bn + w0[:, o2:o3] @ bt
-        H, F = columns.shape
-        quads = (F + 3) // 4
-        padded = torch.zeros(H, quads * 4, dtype=f64)
-        padded[:, :F] = columns
-        image = padded.t().reshape(quads, 4, H).permute(0, 2, 1).contiguous().reshape(-1)     # [q][neuron][4]
-        return torch.cat([image, bias]).to(device=device, dtype=F32).contiguous()
+        return torch.cat([_quad_image(columns), bias]).to(device=device, dtype=F32).contiguous()
 
 
 def _quad_image(matrix64: torch.Tensor) -> torch.Tensor:
@@ -349,8 +344,6 @@ def _fold_output_layers(network, device):
         bias = w_heads @ b_last + b_heads
         return torch.cat([_quad_image(folded), bias]).to(device=device, dtype=F32).contiguous()
 
-
-MlpPack._fold_input_layers = staticmethod(_fold_input_layers)
 
 
 def mlp_forward(pack: MlpPack, atom_types, x, l, time, sigma):
