@@ -348,8 +348,9 @@ def main():
     batch = args.batch or w["batch"]
     T = w["noise"]["total_time_steps"]
     mlp = w["net"] == "mlp"
-    steps = args.steps if args.steps is not None else (200 if mlp else 3)
-    warmup = args.warmup if args.warmup is not None else (20 if mlp else 1)
+    # defaults: the MLP workload runs its whole T-step trajectory (what the product does in one launch); the EGNN ones 3
+    steps = args.steps if args.steps is not None else (T if mlp else 3)
+    warmup = args.warmup if args.warmup is not None else (T if mlp else 1)
     forward = args.forward or ("fused" if mlp else "pytorch")
     assert forward == "pytorch" or mlp, "the fused forward exists for the MLP score network only"
     use_graph = w["graph"] and not args.no_graph and forward == "pytorch"
