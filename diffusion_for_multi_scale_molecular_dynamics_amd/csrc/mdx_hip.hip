@@ -1044,10 +1044,10 @@ __device__ __forceinline__ void mlp_forward_folded(const MlpWeightsLds& w, const
 {
     // the 59 (+1 zero) inputs of the folded layer
     if (lane < 24) {
-        float sn, cs;
-        sincospif_(2.0f * x[lane], sn, cs);
-        buf_b[lane] = cs;
-        buf_b[24 + lane] = sn;
+        // hardware sin / cos take their argument in revolutions: cos(2 pi x), sin(2 pi x) directly
+        const float xv = x[lane];
+        buf_b[lane] = __builtin_amdgcn_cosf(xv);
+        buf_b[24 + lane] = __builtin_amdgcn_sinf(xv);
     } else if (lane == 48) {
         buf_b[48] = sigma;
     } else if (lane == 49) {
