@@ -154,14 +154,17 @@ def advance(loop, iterations, total):
             loop.remaining = total
 
 
-def time_fused_kernel(gen, loop, batch, w, device, iterations=100):
-    """Duration of the persistent kernel per sampler iteration (HIP events around one launch of `iterations`)."""
+def time_fused_kernel(gen, loop, batch, w, device, iterations=None):
+    """Duration of one launch of the persistent sampler over the whole trajectory (noise pre-pass + persistent kernel,
+    HIP events on the launch stream) -- the launch shape of the timed run, so that the rocprofv3 per-launch average of the
+    same command is directly comparable."""
     n, c, m = w["n_atoms"], w["num_atom_types"] + 1, w["M"]
     comp = type(loop.composition)(*[t.clone() for t in loop.composition])
     T = w["noise"]["total_time_steps"]
+    iterations = T if iterations is None else iterations
 
     def launch():
-        kernels.mlp_pc_sample(loop.sched, loop.pack, gen._flags(True), m, False, T // 2 + iterations, iterations,
+        kernels.mlp_pc_sample(loop.sched, loop.pack, gen._flags(True), m, False, T, iterations,
                               gen._rng(0), comp.A, comp.X, comp.L, gen._status)
     launch()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
