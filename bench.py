@@ -8,9 +8,16 @@ A "step" is one sampler iteration -- score-network forward + fused predictor upd
 corrector update) -- over one batch of synthetic structures resident in HBM.  K steps are timed between
 barrier + synchronize pairs, the MAX over ranks is taken, and the whole-job throughput is derived for the
 workload's full trajectory:  value = structures / (T * ms_per_step + gather_ms).
-Workloads: C2 = BASELINE configs[1] (Si 1x1x1, MLP, T=1000, M=1, B=1024 per GPU) is the
-default; C3/C4/C5 are the EGNN radius-graph configurations.  Weak scaling: every rank samples its own batch with
-Philox seed base+rank; the only collective is one all-gather of the final compositions.
+Workloads: C3 = BASELINE configs[2] (Si 2x2x2, EGNN 4x256 with the radius graph, T=1000, M=2,
+B=512 per GPU) is the default -- the largest single-GPU configuration and the one north_star's target is quoted on;
+C2 = configs[1] (Si 1x1x1, MLP); C4/C5 are the other EGNN configurations.  Weak scaling: every rank samples its own
+batch with Philox seed base+rank; the only collective is ONE all-gather of the final compositions (A, X, L packed
+into one byte buffer per rank).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own ranks: the parent -- before anything has
+touched the GPU -- runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process, relays
+its output and exits with its code.  For the MLP workloads the job is a single 4 ms launch, so `value` comes from a
+timed region that is one whole T-iteration trajectory whatever --steps says (`ms_per_step` is still the K-step figure).
 
 The JSON line also carries
   roofline      the dominant hand-written kernel of the workload: algorithmic bytes per launch / average launch
@@ -45,6 +52,8 @@ from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn
 from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.mlp_score_network import (  # noqa: E402
     MLPScoreNetwork, MLPScoreNetworkParameters)
 from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters  # noqa
+from diffusion_for_multi_scale_molecular_dynamics_amd.sampling.diffusion_sampling import (  # noqa: E402
+    pack_compositions, unpack_compositions)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BASE_SEED = 20250815
@@ -134,7 +143,7 @@ class FusedLoop:
             n = min(iterations, self.remaining)
             kernels.mlp_pc_sample(self.sched, self.pack, g._flags(True), g.number_of_corrector_steps,
                                   g.atom_type_transition_in_corrector, self.remaining, n, g._rng(0), c.A, c.X, c.L,
-                                  g._status)
+                                  g._status, workspace=g._noise_workspace, options=g.fused_sampler_options)
             iterations -= n
             self.remaining -= n
             if self.remaining == 0:
@@ -165,7 +174,7 @@ def time_fused_kernel(gen, loop, batch, w, device, iterations=None):
 
     def launch():
         kernels.mlp_pc_sample(loop.sched, loop.pack, gen._flags(True), m, False, T, iterations,
-                              gen._rng(0), comp.A, comp.X, comp.L, gen._status)
+                              gen._rng(0), comp.A, comp.X, comp.L, gen._status, workspace=gen._noise_workspace)
     launch()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)
@@ -310,12 +319,51 @@ def cpu_baseline(w, name, budget_s=15.0, resampling=0):
                        f"({elapsed:.1f} s, {per_iter * 1e3:.2f} ms/iteration), extrapolated to the {T}-step job")
 
 
+def rehearse_launch(args, w, world, rank):
+    """The multi-rank control flow of the job on host tensors: what the CPU test of `--gpus N` exercises."""
+    import torch.distributed as dist
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import AXL
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    batch, n = 4, w["n_atoms"]
+    gen = torch.Generator().manual_seed(BASE_SEED + rank)
+    comp = AXL(A=torch.randint(0, 2, (batch, n), generator=gen), X=torch.rand(batch, n, 3, generator=gen),
+               L=torch.rand(batch, 6, generator=gen))
+    rows = pack_compositions(comp)
+    out = torch.empty((world * batch, rows.shape[1]), dtype=torch.uint8)
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.all_gather_into_tensor(out, rows)
+    else:
+        out.copy_(rows)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    gathered = unpack_compositions(out, n, 3)
+    ok = True
+    for r in range(world):                        # every rank's block equals what that rank's seed generates
+        g = torch.Generator().manual_seed(BASE_SEED + r)
+        a = torch.randint(0, 2, (batch, n), generator=g)
+        x = torch.rand(batch, n, 3, generator=g)
+        ok = ok and torch.equal(gathered.A[r * batch:(r + 1) * batch], a) and \
+            torch.equal(gathered.X[r * batch:(r + 1) * batch], x)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "gather_ok": bool(ok), "gather_ms": float(t[0]) * 1e3,
+                          "collectives": 1, "workload": args.workload}), flush=True)
+    if not ok:
+        raise SystemExit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="C2", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the iteration into a hipGraph")
     ap.add_argument("--forward", choices=["fused", "pytorch"], default=None,
@@ -328,11 +376,27 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (with ranks sharing a GPU) exists to rehearse the multi-rank control "
                          "flow on a one-GPU box")
+    ap.add_argument("--master-port", type=int, default=29541, help="rendezvous port when bench.py starts its own ranks")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="no GPU work: the ranks only run the job's control flow on host tensors (gloo) -- rendezvous, the "
+                         "packed all-gather of synthetic compositions, the MAX reduction, rank 0's JSON line; used by the "
+                         "CPU test of the launcher")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Start the ranks as a CHILD process.  Nothing in this process has initialised the GPU yet (importing torch and
+        # this package does not), and it never will: it only relays the child's output and return code.
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     w = WORKLOADS[args.workload]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.rehearse_launch:
+        return rehearse_launch(args, w, world, rank)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py measures the GPU hot path: no GPU is visible (there is no CPU fallback)")
@@ -378,43 +442,67 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    def timed(fn):
+        """barrier + synchronize | fn | each rank stamps its clock when its own work is complete | barrier; the time is
+        the MAX over ranks (= when the last rank finished), so the closing barrier's own latency -- an RCCL all-reduce of
+        ~50 us -- is not booked as sampling time."""
+        barrier()
+        t0 = time.perf_counter()
+        fn()
+        wait_for_gpu()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        if dist is not None:
+            t = coll(torch.tensor([elapsed], dtype=torch.float64, device=device))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+        return elapsed
+
     with torch.no_grad():
         gen._prepare(device)
         gen._begin_call(device)                      # Philox seed = BASE_SEED + rank
         start = gen.initialize(batch, device)
-        loop = FusedLoop(gen, start, T) if forward == "fused" else IterationLoop(gen, start, T, use_graph=use_graph)
+
+        def new_loop():
+            return FusedLoop(gen, start, T) if forward == "fused" else IterationLoop(gen, start, T, use_graph=use_graph)
+        loop = new_loop()
         advance(loop, warmup, T)
-        barrier()
-        t0 = time.perf_counter()
-        advance(loop, steps, T)
-        # each rank stamps its clock when its own K steps are complete, then joins the closing barrier; the reported
-        # time is the MAX over ranks (= when the last rank finished), so the barrier's own latency -- an RCCL
-        # all-reduce of ~50 us, a quarter of the timed region at K = 20 -- is not booked as sampling time
-        wait_for_gpu()
-        elapsed = time.perf_counter() - t0
-        barrier()
-        # the single collective of the job: gather of the final compositions
+        elapsed = timed(lambda: advance(loop, steps, T))
+        ms_per_step = elapsed * 1e3 / steps
+        # MLP workloads: the product runs the whole trajectory as ONE launch (4 ms); K iterations of it pay the launch's
+        # fixed cost once per K.  So the job time is measured directly: one whole T-iteration trajectory, timed the same way.
+        trajectory_ms = None
+        if mlp:
+            loop = new_loop()
+            trajectory_ms = timed(lambda: advance(loop, T, T)) * 1e3
+        # the single collective of the job: ONE all-gather of the packed final compositions
         comp = loop.composition
         gather_ms = 0.0
         if dist is not None:
-            parts = [coll(t.contiguous()) for t in comp]
-            outs = [torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in parts]
-            for o, t in zip(outs, parts):          # untimed: RCCL sets up its rings / channels at the first collective
-                dist.all_gather_into_tensor(o, t)
-            barrier()
-            g0 = time.perf_counter()
-            for o, t in zip(outs, parts):
-                dist.all_gather_into_tensor(o, t)
-            wait_for_gpu()                         # the collective itself is the synchronisation point
-            gather_ms = (time.perf_counter() - g0) * 1e3
-            barrier()
+            rows = coll(pack_compositions(comp))
+            out = torch.empty((world * rows.shape[0], rows.shape[1]), dtype=torch.uint8, device=rows.device)
+            dist.all_gather_into_tensor(out, rows)      # untimed: RCCL sets up its rings / channels at the first collective
+            gather_ms = timed(lambda: dist.all_gather_into_tensor(out, rows)) * 1e3
+            gathered = unpack_compositions(out, w["n_atoms"], 3)
+            mine = slice(rank * batch, (rank + 1) * batch)
+            assert torch.equal(gathered.A[mine].to(device), comp.A) and torch.equal(gathered.X[mine].to(device), comp.X)
         gen.check_status()
-        if dist is not None:
-            t = coll(torch.tensor([elapsed, gather_ms], dtype=torch.float64, device=device))
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, gather_ms = float(t[0]), float(t[1])
-        ms_per_step = elapsed * 1e3 / steps
-        value = (batch * world) / ((T * ms_per_step + gather_ms) * 1e-3)
+        job_ms = (trajectory_ms if trajectory_ms is not None else T * ms_per_step) + gather_ms
+        value = (batch * world) / (job_ms * 1e-3)
+        generic_path = None
+        if forward == "fused":
+            # the same job through the generic instantiation of the persistent kernel (any MLP shape takes this path;
+            # the dimension-specialised, folded instantiation above is selected when the network matches a template)
+            from diffusion_for_multi_scale_molecular_dynamics_amd import _hip
+            gen.fused_sampler_options = _hip.MLP_SAMPLE_GENERIC_KERNEL | _hip.MLP_SAMPLE_UNFOLDED
+            loop_g = new_loop()
+            advance(loop_g, T, T)
+            loop_g = new_loop()
+            generic_ms = timed(lambda: advance(loop_g, T, T)) * 1e3
+            gen.fused_sampler_options = 0
+            generic_path = dict(kernel="mlp_pc_sample_kernel<G,true,0> (generic instantiation, layer-by-layer forward)",
+                                trajectory_ms=round(generic_ms, 4),
+                                value=round((batch * world) / ((generic_ms + gather_ms) * 1e-3), 2), unit="structures/s")
 
         roofline = forward_gemm = None
         if rank == 0:
@@ -428,7 +516,11 @@ def main():
             achieved = m["bytes"] / (m["ms"] * 1e-3) / 1e9
             traffic = None          # HBM bytes per launch measured with PMC counters in a separate rocprofv3 pass
             try:
-                table = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+                table = {}
+                for name in ("traffic_r01.json", "traffic_r02.json"):        # later rounds override
+                    path = os.path.join(ROOT, "profiles", name)
+                    if os.path.exists(path):
+                        table.update(json.load(open(path)))
                 entry = table[f"{args.workload}/{forward}"]
                 if entry["kernel"] == m["kernel"].split()[0].split("<")[0] and batch == w["batch"]:
                     traffic = entry["bytes_per_launch"]
@@ -446,7 +538,10 @@ def main():
     result = {
         "metric": "sampled structures/sec (%d-step predictor-corrector SDE sampling)" % T,
         "value": round(value, 4), "unit": "structures/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 5), "job_ms": round(job_ms, 4),
+        "value_from": ("one whole %d-iteration trajectory timed end to end (trajectory_ms %.4f) + gather" % (T, trajectory_ms))
+        if trajectory_ms is not None else "total_time_steps x ms_per_step + gather",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (random-init score network, uniform-random initial structures)",
         "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": batch, "global_batch": batch * world,
                    "number_of_atoms": w["n_atoms"], "total_time_steps": T, "corrector_steps": w["M"],
@@ -454,9 +549,14 @@ def main():
                    "rng": "device Philox4x32-10", "hip_graph": bool(use_graph),
                    "score_network_forward": "fused HIP (one persistent kernel per launch of K iterations)"
                    if forward == "fused" else "PyTorch-ROCm module (plugin API)", "gather_ms": round(gather_ms, 4),
-                   "parallelism": f"independent batches x{world}, one all-gather at the end"},
+                   "parallelism": f"independent batches x{world}, one all-gather at the end",
+                   # every switch of the library is an explicit argument; MDX_* variables are not read by the product
+                   # and are listed only so that a stray one is visible
+                   "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MDX_")}},
         "roofline": roofline,
     }
+    if generic_path is not None:
+        result["generic_path"] = generic_path
     if forward_gemm is not None:      # EGNN workloads: the step is library-GEMM time; the hand-written kernels are < 1 %
         result["forward_gemm"] = forward_gemm
     if world == 1 and not args.no_cpu_baseline:

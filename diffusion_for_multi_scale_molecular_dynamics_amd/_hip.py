@@ -20,7 +20,7 @@ MAX_CLASSES = 8
 TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
     TAG_INIT_LATTICE, TAG_RESAMPLE_Z, TAG_RESAMPLE_U = range(11)
 
-ABI_VERSION = 3          # MDX_ABI_VERSION of include/mdx_hip.h
+ABI_VERSION = 4          # MDX_ABI_VERSION of include/mdx_hip.h
 ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
@@ -30,6 +30,9 @@ ABI_SYMBOLS = (
     "mdx_rng_fill", "mdx_math_probe",
 )
 MLP_MAX_HIDDEN = 8
+# options of mdx_mlp_pc_sample (include/mdx_hip.h)
+MLP_SAMPLE_GENERIC_KERNEL, MLP_SAMPLE_UNFOLDED, MLP_SAMPLE_CALLER_NOISE, MLP_SAMPLE_NO_FIXED_SOFTMAX, \
+    MLP_SAMPLE_NO_P2_TABLE, MLP_SAMPLE_DIAG_NO_FORWARD, MLP_SAMPLE_DIAG_NO_UPDATE = 1, 2, 4, 8, 16, 256, 512
 
 
 class MdxError(RuntimeError):
@@ -70,7 +73,7 @@ class Mlp(C.Structure):
 
 def build(force=False):
     """Compile csrc/mdx_hip.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("mdx_hip.hip", "mdx_math.hpp")]
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h")) or f == "Makefile"]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mdx_hip.h"))
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs)
     if force or stale:
@@ -136,7 +139,7 @@ def _declare(L):
     L.mdx_mlp_forward.argtypes = [C.POINTER(Mlp), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
     L.mdx_mlp_pc_sample.restype = i32
     L.mdx_mlp_pc_sample.argtypes = [C.POINTER(Schedule), C.POINTER(Mlp), C.POINTER(PcFlags), i32, i32, i32, i32, Rng, i64,
-                                    vp, vp, vp, vp, i64, vp, vp]
+                                    vp, vp, vp, vp, i64, u32, vp, vp]
     L.mdx_mlp_pc_sample_workspace_floats.restype = i64
     L.mdx_mlp_pc_sample_workspace_floats.argtypes = [C.POINTER(Mlp), i32, i32, i32, i64]
     L.mdx_mlp_image_floats.restype = i64

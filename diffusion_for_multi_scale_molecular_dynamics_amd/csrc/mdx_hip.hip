@@ -1748,7 +1748,7 @@ int mdx_noise_schedule_build(int T, int schedule_type, double time_delta, double
                              mdx_stream_t stream)
 {
     if (T < 2 || C < 2 || (schedule_type != 0 && schedule_type != 1)) return MDX_ERR_INVALID_ARG;
-    if (C > 2 * MDX_MAX_CLASSES) return MDX_ERR_UNSUPPORTED;
+    if (C > MDX_MAX_CLASSES) return MDX_ERR_UNSUPPORTED;      // qbar_chain keeps one row in MDX_MAX_CLASSES registers
     if (!time || !sigma || !sigma_squared || !g || !g_squared || !epsilon || !sqrt_2_epsilon || !beta || !alpha_bar ||
         !q_matrix || !q_bar_matrix || !q_bar_tm1_matrix)
         return MDX_ERR_INVALID_ARG;
@@ -2003,6 +2003,7 @@ static int mlp_ok(const mdx_mlp_t* m)
 }
 
 constexpr size_t kMlpLdsBudget = 64 * 1024;      // default dynamic-LDS limit per workgroup
+constexpr int kMaxDevices = 64;                  // per-device bookkeeping of hipFuncSetAttribute opt-ins
 
 int64_t mdx_mlp_image_floats(const mdx_mlp_t* mlp_host)
 {
@@ -2062,7 +2063,8 @@ int64_t mdx_mlp_pc_sample_workspace_floats(const mdx_mlp_t* mlp_host, int number
 int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_host, const mdx_pc_flags_t* f,
                       int number_of_corrector_steps, int atom_type_transition_in_corrector, int start_index,
                       int n_iterations, mdx_rng_t rng, int64_t batch, int64_t* atom_types, float* x, float* l,
-                      float* noise_workspace, int64_t workspace_floats, uint32_t* status, mdx_stream_t stream)
+                      float* noise_workspace, int64_t workspace_floats, uint32_t options, uint32_t* status,
+                      mdx_stream_t stream)
 {
     const int ok = mlp_ok(mlp_host);
     if (ok != MDX_OK) return ok;
@@ -2071,6 +2073,15 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
     if (sched_host->num_classes != mlp_host->num_classes) return MDX_ERR_INVALID_ARG;
     if (mlp_host->number_of_atoms > kWave) return MDX_ERR_UNSUPPORTED;      // one lane per atom in the update
     if ((int64_t)batch * mlp_host->number_of_atoms > 0xffffffffLL) return MDX_ERR_UNSUPPORTED;
+    constexpr uint32_t kKnownOptions = MDX_MLP_SAMPLE_GENERIC_KERNEL | MDX_MLP_SAMPLE_UNFOLDED | MDX_MLP_SAMPLE_CALLER_NOISE |
+                                       MDX_MLP_SAMPLE_NO_FIXED_SOFTMAX | MDX_MLP_SAMPLE_NO_P2_TABLE |
+                                       MDX_MLP_SAMPLE_DIAG_NO_FORWARD | MDX_MLP_SAMPLE_DIAG_NO_UPDATE;
+    if (options & ~kKnownOptions) return MDX_ERR_INVALID_ARG;
+#ifndef MDX_DIAGNOSTICS
+    if (options & (MDX_MLP_SAMPLE_DIAG_NO_FORWARD | MDX_MLP_SAMPLE_DIAG_NO_UPDATE)) return MDX_ERR_UNSUPPORTED;
+#endif
+    const bool caller_noise = (options & MDX_MLP_SAMPLE_CALLER_NOISE) != 0;
+    if (caller_noise && !noise_workspace) return MDX_ERR_INVALID_ARG;
     if (batch == 0 || n_iterations == 0) return MDX_OK;
     if (!atom_types || !x || !l) return MDX_ERR_INVALID_ARG;
     if (noise_workspace) {
@@ -2078,13 +2089,13 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
         const int64_t per_iteration = mdx_mlp_pc_sample_workspace_floats(mlp_host, number_of_corrector_steps,
                                                                          atom_type_transition_in_corrector, 1, batch);
         const int64_t fit = workspace_floats / per_iteration;
-        if (fit < 1) return MDX_ERR_INVALID_ARG;
+        if (fit < 1 || (caller_noise && fit < n_iterations)) return MDX_ERR_INVALID_ARG;
         if (fit < n_iterations) {
             for (int done = 0; done < n_iterations;) {
                 const int n = (int)(n_iterations - done < fit ? n_iterations - done : fit);
                 const int rc = mdx_mlp_pc_sample(sched_host, mlp_host, f, number_of_corrector_steps,
                                                  atom_type_transition_in_corrector, start_index - done, n, rng, batch,
-                                                 atom_types, x, l, noise_workspace, workspace_floats, status, stream);
+                                                 atom_types, x, l, noise_workspace, workspace_floats, options, status, stream);
                 if (rc != MDX_OK) return rc;
                 done += n;
             }
@@ -2118,13 +2129,15 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
     a.rec0 = pc.N * (pc.d + pc.C + 1) + kP2Table;
     a.rec1 = a.types_in_corrector ? a.rec0 : pc.N * pc.d;
     a.noise = noise_workspace;
-    if (const char* diag = getenv("MDX_DIAG_SKIP")) a.diag_skip = atoi(diag);
+    // diag_skip bits of the kernel: 1 no forward, 2 no update (diagnostics builds only), 8 no hoisted softmax, 16 no table
+    a.diag_skip = ((options & MDX_MLP_SAMPLE_DIAG_NO_FORWARD) ? 1 : 0) | ((options & MDX_MLP_SAMPLE_DIAG_NO_UPDATE) ? 2 : 0) |
+                  ((options & MDX_MLP_SAMPLE_NO_FIXED_SOFTMAX) ? 8 : 0) | ((options & MDX_MLP_SAMPLE_NO_P2_TABLE) ? 16 : 0);
     int G = 1;
     while (G < pc.N) G <<= 1;
     const int64_t blocks = cdiv(batch, kMlpWaves);
     const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
     hipStream_t st = as_stream(stream);
-    if (noise_workspace) {
+    if (noise_workspace && !caller_noise) {
         NoiseFillArgs nf{};
         nf.rng = pc.rng;
         nf.sched = pc.sched; nf.small_eps = pc.small_eps;
@@ -2138,20 +2151,21 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
     }
     if (in_lds) {
         const size_t lds = per_wave * kMlpWaves + image;
-        const char* generic = getenv("MDX_MLP_GENERIC");          // tests: force the generic instantiation
-        // 0: generic instantiation; 1: template dimensions as literals; 2: the same with the folded input layer
-        const char* fold = getenv("MDX_MLP_FOLD");                // tests: "0" keeps the layer-by-layer form
-        int spec = matches_template_mlp(*mlp_host) && !(generic && generic[0] == '1') ? 1 : 0;
-        if (spec == 1 && mlp_host->folded_input && mlp_host->folded_output && !(fold && fold[0] == '0')) spec = 2;
+        // 0: generic instantiation; 1: template dimensions as literals; 2: the same with the folded input / output layers
+        int spec = matches_template_mlp(*mlp_host) && !(options & MDX_MLP_SAMPLE_GENERIC_KERNEL) ? 1 : 0;
+        if (spec == 1 && mlp_host->folded_input && mlp_host->folded_output && !(options & MDX_MLP_SAMPLE_UNFOLDED)) spec = 2;
         if (lds > kMlpLdsBudget) {       // up to 128 KiB of the CU's 160 KiB: opt in above the 64 KiB default
             // the attribute is a property of the code object: set it when the requirement grows, not on every launch
-            static std::atomic<size_t> granted[16];
+            // (per device: a process that samples on a second GPU must opt in there as well)
+            static std::atomic<size_t> granted[kMaxDevices][16];
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return MDX_ERR_HIP;
             const int slot = spec ? 6 + spec : (G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : G == 32 ? 5 : 6);
-            if (granted[slot].load() < lds) {
+            if (granted[dev][slot].load() < lds) {
                 if (hipFuncSetAttribute(mlp_sampler_lds_function(G, spec), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) != hipSuccess)
                     return MDX_ERR_HIP;
-                granted[slot].store(lds);
+                granted[dev][slot].store(lds);
             }
         }
         if (spec == 2)

@@ -67,6 +67,9 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         self.use_hip_graph = bool(getattr(sp, "use_hip_graph", False))
         self.fused_score_network = bool(getattr(sp, "fused_score_network", False))
         self._mlp_pack = None
+        self._noise_workspace = kernels.NoiseWorkspace()     # pre-drawn records of the fused sampler, owned per generator
+        self.fused_sampler_options = 0                       # MLP_SAMPLE_* bits of _hip.py (0 = the product path)
+        self.fused_predrawn_noise = True                     # False: every wavefront draws in-kernel (same numbers)
         self._seed = getattr(sp, "seed", None)
         self._call_counter = 0
         self.noise_source = ReferenceOrderNoise() if rng_mode == "reference" else None
@@ -348,7 +351,8 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         kernels.mlp_pc_sample(sched, pack, self._flags(True), self.number_of_corrector_steps,
                               self.atom_type_transition_in_corrector, starting_step_index,
                               starting_step_index - max(ending_step_index, 0), self._rng(0), comp.A, comp.X, comp.L,
-                              self._status)
+                              self._status, workspace=self._noise_workspace if self.fused_predrawn_noise else None,
+                              options=self.fused_sampler_options)
         return comp
 
     def _sample_with_graph(self, start: AXL, starting_step_index: int, ending_step_index: int) -> AXL:

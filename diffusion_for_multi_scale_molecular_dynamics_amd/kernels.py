@@ -361,48 +361,69 @@ def mlp_forward(pack: MlpPack, atom_types, x, l, time, sigma):
     return logits, score_x, score_l
 
 
-_NOISE_WORKSPACE = {}                       # device -> float32 buffer reused by every fused-sampler launch
 NOISE_WORKSPACE_MAX_FLOATS = 1 << 28        # 1 GiB cap; longer segments are split into several launches by the library
 NOISE_WORKSPACE_MIN_ITERATIONS = 1024       # first allocation holds at least this many iterations (within the cap)
 
 
-def noise_workspace(pack: "MlpPack", number_of_corrector_steps: int, atom_type_transition_in_corrector: bool,
-                    n_iterations: int, batch: int, device) -> torch.Tensor:
-    """The pre-drawn-noise buffer of mdx_mlp_pc_sample, sized by the library, grown on demand, owned here."""
-    need = lib().mdx_mlp_pc_sample_workspace_floats(C.byref(pack.c_struct), int(number_of_corrector_steps),
-                                                    int(bool(atom_type_transition_in_corrector)), int(n_iterations),
-                                                    int(batch))
-    if need < 0:
-        raise _hip.MdxError("mdx_mlp_pc_sample_workspace_floats: invalid argument")
-    per_iteration = need // max(int(n_iterations), 1)
-    need = max(min(need, NOISE_WORKSPACE_MAX_FLOATS), per_iteration, 1)
-    key = torch.device(device)
-    buf = _NOISE_WORKSPACE.get(key)
-    if buf is None or buf.numel() < need:
-        # allocate with headroom (a device allocation costs ~100 us, more than a short segment's kernels): room for
-        # NOISE_WORKSPACE_MIN_ITERATIONS iterations of this shape, within the cap
-        roomy = min(max(need, NOISE_WORKSPACE_MIN_ITERATIONS * per_iteration), max(NOISE_WORKSPACE_MAX_FLOATS, need))
-        buf = _NOISE_WORKSPACE[key] = torch.empty(roomy, dtype=F32, device=device)
-    return buf
+class NoiseWorkspace:
+    """The pre-drawn-noise buffer of mdx_mlp_pc_sample: sized by the library, grown on demand, owned by ONE caller (a
+    generator or a bench loop), so that two samplers on different streams never share records.  A buffer that is
+    replaced is handed to the allocator with record_stream, i.e. it is not reused before the launches that read it
+    have completed."""
+
+    def __init__(self):
+        self.buffer = None
+
+    def floats_needed(self, pack: "MlpPack", number_of_corrector_steps: int, atom_type_transition_in_corrector: bool,
+                      n_iterations: int, batch: int) -> int:
+        need = lib().mdx_mlp_pc_sample_workspace_floats(C.byref(pack.c_struct), int(number_of_corrector_steps),
+                                                        int(bool(atom_type_transition_in_corrector)), int(n_iterations),
+                                                        int(batch))
+        if need < 0:
+            raise _hip.MdxError("mdx_mlp_pc_sample_workspace_floats: invalid argument")
+        return need
+
+    def get(self, pack: "MlpPack", number_of_corrector_steps: int, atom_type_transition_in_corrector: bool,
+            n_iterations: int, batch: int, device) -> torch.Tensor:
+        need = self.floats_needed(pack, number_of_corrector_steps, atom_type_transition_in_corrector, n_iterations, batch)
+        per_iteration = need // max(int(n_iterations), 1)
+        need = max(min(need, NOISE_WORKSPACE_MAX_FLOATS), per_iteration, 1)
+        buf = self.buffer
+        if buf is None or buf.numel() < need or buf.device != torch.device(device):
+            # allocate with headroom (a device allocation costs ~100 us, more than a short segment's kernels): room for
+            # NOISE_WORKSPACE_MIN_ITERATIONS iterations of this shape, within the cap
+            roomy = min(max(need, NOISE_WORKSPACE_MIN_ITERATIONS * per_iteration), max(NOISE_WORKSPACE_MAX_FLOATS, need))
+            if buf is not None and buf.is_cuda:
+                buf.record_stream(torch.cuda.current_stream(buf.device))
+            buf = self.buffer = torch.empty(roomy, dtype=F32, device=device)
+        return buf
 
 
 def mlp_pc_sample(sched: DeviceSchedule, pack: MlpPack, flags: PcFlags, number_of_corrector_steps: int,
                   atom_type_transition_in_corrector: bool, start_index: int, n_iterations: int, rng: Rng,
-                  atom_types, x, l, status, predrawn_noise: bool = True):
+                  atom_types, x, l, status, workspace: Optional[NoiseWorkspace] = None, options: int = 0,
+                  caller_records: Optional[torch.Tensor] = None):
     """n_iterations x (predictor + M correctors) in one launch, composition updated in place.
 
-    predrawn_noise: generate the segment's draws with the chip-filling pre-pass kernel into a workspace (default);
-    False: every wavefront draws in-kernel.  Both evaluate the same Philox specification: identical results."""
+    workspace: the caller's NoiseWorkspace -- the segment's draws are generated by the chip-filling pre-pass kernel
+    into it (default product path); None: every wavefront draws in-kernel.  Both evaluate the same Philox
+    specification: identical results.  caller_records: a float32 device tensor already holding the records (layout in
+    include/mdx_hip.h) -- parity tests replay the reference's recorded draws this way (MLP_SAMPLE_CALLER_NOISE).
+    options: MLP_SAMPLE_* bits of _hip.py, passed through to the library."""
     B = x.shape[0]
     work = None
-    if predrawn_noise and B > 0 and n_iterations > 0:
-        work = noise_workspace(pack, number_of_corrector_steps, atom_type_transition_in_corrector, n_iterations, B,
-                               x.device)
+    if caller_records is not None:
+        work = caller_records
+        options |= _hip.MLP_SAMPLE_CALLER_NOISE
+    elif workspace is not None and B > 0 and n_iterations > 0:
+        work = workspace.get(pack, number_of_corrector_steps, atom_type_transition_in_corrector, n_iterations, B,
+                             x.device)
     rc = lib().mdx_mlp_pc_sample(C.byref(sched.c_struct), C.byref(pack.c_struct), C.byref(flags),
                                  int(number_of_corrector_steps), int(bool(atom_type_transition_in_corrector)),
                                  int(start_index), int(n_iterations), rng, B, ptr(atom_types, I64, "atom_types"),
                                  ptr(x, F32, "x"), ptr(l, F32, "l"), ptr(work, F32, "noise_workspace"),
-                                 0 if work is None else work.numel(), ptr(status, I32, "status"), stream_handle())
+                                 0 if work is None else work.numel(), int(options), ptr(status, I32, "status"),
+                                 stream_handle())
     check(rc, "mdx_mlp_pc_sample")
 
 

@@ -4,10 +4,12 @@ create_batch_of_samples            same signature and output dict as the referen
                                    sub-batches on one device.
 create_batch_of_samples_sharded    one process per GPU: the sub-batches are dealt round-robin to the ranks (samples
                                    are independent, there is no per-step communication) and the results are
-                                   gathered with ONE collective per field at the end (RCCL over xGMI under the
-                                   "nccl" backend; "gloo" in the CPU tests).
+                                   gathered with ONE collective at the end: A, X and L of a structure are packed
+                                   into one byte row, so the job has a single all_gather_into_tensor (RCCL over xGMI
+                                   under the "nccl" backend; "gloo" in the CPU tests).
 """
 import logging
+import math
 from typing import List, Tuple
 
 import torch
@@ -41,6 +43,24 @@ def create_batch_of_samples(generator: AXLGenerator, sampling_parameters: Sampli
                    torch.concat([p.L for p in parts]))
 
 
+def pack_compositions(composition: AXL) -> torch.Tensor:
+    """A [B,N] int64 | X [B,N,d] f32 | L [B,nl] f32  ->  uint8 [B, 8 N + 4 N d + 4 nl]: one row of bytes per structure."""
+    batch = composition.X.shape[0]
+    return torch.cat([t.contiguous().view(torch.uint8).reshape(batch, t.element_size() * math.prod(t.shape[1:]))
+                      for t in composition], dim=1)
+
+
+def unpack_compositions(rows: torch.Tensor, number_of_atoms: int, spatial_dimension: int) -> AXL:
+    """Inverse of pack_compositions for rows [..., bytes]."""
+    n, d = number_of_atoms, spatial_dimension
+    nl = d * (d + 1) // 2
+    lead = tuple(rows.shape[:-1])
+    a, x, lat = torch.split(rows, [8 * n, 4 * n * d, 4 * nl], dim=-1)
+    return AXL(A=a.contiguous().view(torch.int64).reshape(lead + (n,)),
+               X=x.contiguous().view(torch.float32).reshape(lead + (n, d)),
+               L=lat.contiguous().view(torch.float32).reshape(lead + (nl,)))
+
+
 def shard_of_rank(sizes: List[int], rank: int, world_size: int) -> List[Tuple[int, int]]:
     """(sub-batch position, size) pairs owned by `rank`: round-robin over the sub-batch list."""
     return [(k, n) for k, n in enumerate(sizes) if k % world_size == rank]
@@ -66,18 +86,15 @@ def create_batch_of_samples_sharded(generator: AXLGenerator, sampling_parameters
     local = AXL(A=cat([p.A for p in parts], (n_atoms,), torch.int64),
                 X=cat([p.X for p in parts], (n_atoms, d), torch.float32),
                 L=cat([p.L for p in parts], (nl,), torch.float32))
-    # ranks can own different numbers of samples: pad to the largest shard, gather once per field, trim
+    # ranks can own different numbers of samples: pad to the largest shard, ONE gather of the packed rows, trim
     counts = [sum(n for _, n in shard_of_rank(sizes, r, world)) for r in range(world)]
     width = max(counts)
-
-    def gather(t):
-        padded = torch.zeros((width,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        padded[: t.shape[0]] = t
-        out = torch.empty((world * width,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, padded, group=group)
-        return out.view((world, width) + tuple(t.shape[1:]))
-
-    gathered = AXL(A=gather(local.A), X=gather(local.X), L=gather(local.L))
+    rows = pack_compositions(local)
+    padded = torch.zeros((width, rows.shape[1]), dtype=torch.uint8, device=rows.device)
+    padded[: rows.shape[0]] = rows
+    out = torch.empty((world * width, rows.shape[1]), dtype=torch.uint8, device=rows.device)
+    dist.all_gather_into_tensor(out, padded, group=group)          # the job's single collective
+    gathered = unpack_compositions(out.view(world, width, -1), n_atoms, d)
     # restore sub-batch order
     pieces = {}
     for r in range(world):

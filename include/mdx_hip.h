@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 3
+#define MDX_ABI_VERSION 4
 
 /* status codes */
 #define MDX_OK 0
@@ -265,7 +265,22 @@ MDX_API int mdx_mlp_forward(const mdx_mlp_t* mlp_host, const int64_t* atom_types
  * are generated ahead of the loop by a chip-filling pre-pass kernel into this buffer (same Philox counters, same
  * arithmetic => the same bits) and the persistent kernel only reads them; a workspace smaller than
  * mdx_mlp_pc_sample_workspace_floats(...) splits the segment into several launches.  NULL: every wavefront draws
- * in-kernel. */
+ * in-kernel.
+ * options: OR of the MDX_MLP_SAMPLE_* bits below (0 = the product path).  There are no environment variables: every
+ * switch of this entry point is an explicit argument that the caller can print.
+ * Record layout of the workspace (what MDX_MLP_SAMPLE_CALLER_NOISE expects the caller to have written), float32:
+ *   [iteration it = 0 .. n_iterations-1][structure b][ predictor record rec0 | M corrector records rec1 ]
+ *   rec0 = [ z N*d | gumbel N*C | u N | table 8 ]  (table[7] = 0: "no per-step posterior table", always valid)
+ *   rec1 = rec0 if atom_type_transition_in_corrector else [ z N*d ]. */
+#define MDX_MLP_SAMPLE_GENERIC_KERNEL 1u    /* never select a dimension-specialised instantiation                       */
+#define MDX_MLP_SAMPLE_UNFOLDED 2u          /* layer-by-layer forward even when folded_input / folded_output are given  */
+#define MDX_MLP_SAMPLE_CALLER_NOISE 4u      /* noise_workspace already holds the records (parity tests replay the
+                                               reference's recorded draws): the pre-pass is skipped; the whole segment
+                                               must fit the workspace                                                    */
+#define MDX_MLP_SAMPLE_NO_FIXED_SOFTMAX 8u  /* evaluate the clipped softmax per atom (bit-identical; tests)              */
+#define MDX_MLP_SAMPLE_NO_P2_TABLE 16u      /* ignore the per-step posterior table of the records (bit-identical; tests) */
+#define MDX_MLP_SAMPLE_DIAG_NO_FORWARD 256u /* timing diagnostics, honoured only by a -DMDX_DIAGNOSTICS build of the     */
+#define MDX_MLP_SAMPLE_DIAG_NO_UPDATE 512u  /* library; the release build returns MDX_ERR_UNSUPPORTED for them           */
 MDX_API int64_t mdx_mlp_pc_sample_workspace_floats(const mdx_mlp_t* mlp_host, int number_of_corrector_steps,
                                                    int atom_type_transition_in_corrector, int n_iterations,
                                                    int64_t batch);
@@ -273,7 +288,7 @@ MDX_API int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t*
                               const mdx_pc_flags_t* flags_host, int number_of_corrector_steps,
                               int atom_type_transition_in_corrector, int start_index, int n_iterations, mdx_rng_t rng,
                               int64_t batch, int64_t* atom_types, float* x, float* l, float* noise_workspace,
-                              int64_t workspace_floats, uint32_t* status, mdx_stream_t stream);
+                              int64_t workspace_floats, uint32_t options, uint32_t* status, mdx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * EGNN score network helpers (the forward stays a PyTorch module; these remove passes PyTorch cannot fuse).

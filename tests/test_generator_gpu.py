@@ -459,7 +459,7 @@ def test_fused_sampler_segments_compose(cuda):
         sched, pack = gen._prepare(cuda), gen.fused_pack(cuda)
         for first, n in ((16, 5), (11, 10), (1, 1)):
             kernels.mlp_pc_sample(sched, pack, gen._flags(True), 2, False, first, n, gen._rng(0), comp.A, comp.X, comp.L,
-                                  gen._status)
+                                  gen._status, workspace=gen._noise_workspace)
     assert torch.equal(whole.A, comp.A) and torch.equal(whole.X, comp.X)
 
 
@@ -479,20 +479,22 @@ def test_fused_sampler_predrawn_noise_equals_in_kernel_draws(cuda, name, in_corr
         outs = []
         for mode in ("in_kernel", "predrawn", "predrawn_small_workspace"):
             comp = RS.AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
+            workspace = None if mode == "in_kernel" else kernels.NoiseWorkspace()
             if mode == "predrawn_small_workspace":
                 per_iteration = kernels.lib().mdx_mlp_pc_sample_workspace_floats(pack.c_struct, M, int(in_corrector), 1, 19)
                 monkeypatch.setattr(kernels, "NOISE_WORKSPACE_MAX_FLOATS", 3 * per_iteration)
-                kernels._NOISE_WORKSPACE.clear()
+                monkeypatch.setattr(kernels, "NOISE_WORKSPACE_MIN_ITERATIONS", 1)
             kernels.mlp_pc_sample(sched, pack, gen._flags(True), M, in_corrector, T, T, gen._rng(0), comp.A, comp.X,
-                                  comp.L, gen._status, predrawn_noise=mode != "in_kernel")
+                                  comp.L, gen._status, workspace=workspace)
+            if mode == "predrawn_small_workspace":
+                assert workspace.buffer.numel() == 3 * per_iteration          # the segment really was split
             outs.append(comp)
         monkeypatch.undo()
-        kernels._NOISE_WORKSPACE.clear()
         rec0 = spar.number_of_atoms * (3 + gen.num_classes + 1) + 8      # z | gumbel | u | tabulated posterior (8)
         rec1 = rec0 if in_corrector else spar.number_of_atoms * 3
         floats = T * 19 * (rec0 + M * rec1)
         assert kernels.lib().mdx_mlp_pc_sample_workspace_floats(pack.c_struct, M, int(in_corrector), T, 19) == floats
-        assert kernels.noise_workspace(pack, M, in_corrector, T, 19, cuda).numel() >= floats
+        assert kernels.NoiseWorkspace().get(pack, M, in_corrector, T, 19, cuda).numel() >= floats
     for other in outs[1:]:
         assert torch.equal(outs[0].A, other.A)
         assert torch.equal(outs[0].X.view(torch.int32), other.X.view(torch.int32))
@@ -624,15 +626,16 @@ def test_fused_sampler_specialised_equals_generic(cuda, monkeypatch):
     from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
     P = _pkg()
     outs = []
-    monkeypatch.setenv("MDX_MLP_FOLD", "0")                   # layer-by-layer form on both sides
-    for generic in ("1", "0"):
-        monkeypatch.setenv("MDX_MLP_GENERIC", generic)
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip
+    for options in (_hip.MLP_SAMPLE_UNFOLDED | _hip.MLP_SAMPLE_GENERIC_KERNEL, _hip.MLP_SAMPLE_UNFOLDED):
         torch.manual_seed(1234)
         net = nets.mlp_net(8, 1).to(cuda)                     # the template sizes: the specialised kernel applies
         npar = P["Noise"](**cases.noise_ns(30, sigma_min=1e-4, sigma_max=0.25))
         spar = P["Sampling"](**cases.sampling_ns(8, 1), rng_mode="device", seed=3, fused_score_network=True)
+        gen = LangevinGenerator(npar, spar, net)
+        gen.fused_sampler_options = options                   # layer-by-layer form on both sides; generic vs specialised
         with torch.no_grad():
-            outs.append(_np(LangevinGenerator(npar, spar, net).sample(300, cuda)))
+            outs.append(_np(gen.sample(300, cuda)))
     assert np.array_equal(outs[0].A, outs[1].A)
     assert np.array_equal(outs[0].X.view(np.int32), outs[1].X.view(np.int32))
 
@@ -642,12 +645,12 @@ def test_fused_sampler_specialised_equals_generic(cuda, monkeypatch):
 def test_fused_sampler_hoisted_softmax_is_exact(cuda, monkeypatch, small_epsilon, in_corrector):
     """One atom type: the clipped softmax of (l0, -inf) is evaluated once per launch, and the whole posterior of a
     step -- a function of a_t alone -- once per step by the noise pre-pass, instead of per atom and step.  Same bits as
-    the per-atom evaluation (MDX_DIAG_SKIP bits 8 and 16 switch the two off), any small_epsilon, greedy or not."""
+    the per-atom evaluation (options MLP_SAMPLE_NO_FIXED_SOFTMAX / _NO_P2_TABLE switch the two off), any small_epsilon,
+    greedy or not."""
     from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
     P = _pkg()
     outs = []
-    for flag in ("24", "16", "8", "0"):
-        monkeypatch.setenv("MDX_DIAG_SKIP", flag)
+    for flag in (24, 16, 8, 0):
         torch.manual_seed(1234)
         net = nets.mlp_net(8, 1).to(cuda)
         import warnings
@@ -658,12 +661,12 @@ def test_fused_sampler_hoisted_softmax_is_exact(cuda, monkeypatch, small_epsilon
                                                      greedy=not in_corrector, one=not in_corrector, M=2),
                                  rng_mode="device", seed=3, fused_score_network=True)
         gen = LangevinGenerator(npar, spar, net)
+        gen.fused_sampler_options = flag
         with torch.no_grad():
             gen._prepare(cuda)
             gen._begin_call(cuda)
             start = gen.initialize(300, cuda)
             outs.append(_np(gen._sample_fused(start, 30, 0)))       # no status check: a MASK may legitimately survive
-    monkeypatch.delenv("MDX_DIAG_SKIP")
     for other in outs[1:]:
         assert np.array_equal(outs[0].A, other.A)
         assert np.array_equal(outs[0].X.view(np.int32), other.X.view(np.int32))
@@ -692,12 +695,13 @@ def test_fused_sampler_folded_input_layer(cuda, monkeypatch):
         sched, pack = gen._prepare(cuda), gen.fused_pack(cuda)
         assert pack.c_struct.folded_input and pack.c_struct.folded_output
         results = {}
+        from diffusion_for_multi_scale_molecular_dynamics_amd import _hip
         for fold in ("1", "0"):
-            monkeypatch.setenv("MDX_MLP_FOLD", fold)
             for n_iterations in (1, 40):
                 comp = RS.AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
                 kernels.mlp_pc_sample(sched, pack, gen._flags(True), 1, False, 40, n_iterations, gen._rng(0), comp.A,
-                                      comp.X, comp.L, gen._status)
+                                      comp.X, comp.L, gen._status, workspace=gen._noise_workspace,
+                                      options=0 if fold == "1" else _hip.MLP_SAMPLE_UNFOLDED)
                 results[fold, n_iterations] = _np(comp)
     for n_iterations, tol in ((1, 1e-6), (40, 1e-5)):
         a, b = results["1", n_iterations], results["0", n_iterations]
@@ -850,7 +854,8 @@ def test_fused_sampler_random_shapes_predrawn_equals_in_kernel(cuda, seed):
             segments = ((T, T),) if mode != "two_launches" else ((T, 2), (T - 2, T - 2))
             for first, n in segments:
                 kernels.mlp_pc_sample(sched, pack, gen._flags(True), M, in_corr, first, n, gen._rng(0), comp.A, comp.X,
-                                      comp.L, gen._status, predrawn_noise=mode != "in_kernel")
+                                      comp.L, gen._status,
+                                      workspace=None if mode == "in_kernel" else gen._noise_workspace)
             outs.append(comp)
     for other in outs[1:]:
         assert torch.equal(outs[0].A, other.A), (N, nat, hidden, n_hidden, M, T, batch)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert re.search(rf"\sT\s{sym}\b", exported), f"{sym} is declared in include/mdx_hip.h but not exported"
     lib = _hip.lib()                      # loads without a GPU; no compute call is made here
-    assert lib.mdx_abi_version() == _hip.ABI_VERSION == 3
+    assert lib.mdx_abi_version() == _hip.ABI_VERSION == 4
     assert lib.mdx_status_string(-2).decode() == "unsupported size or option"
     # the shared object carries gfx950 code
     assert b"gfx950" in open(_hip.LIB_PATH, "rb").read()
@@ -238,3 +238,38 @@ def test_sharded_driver_gloo_world_size_2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert f"rank {r} ok" in o
+
+
+def test_pack_and_unpack_compositions_round_trip():
+    """A, X, L of a structure as one byte row: what the job's single all-gather moves."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import AXL
+    from diffusion_for_multi_scale_molecular_dynamics_amd.sampling.diffusion_sampling import (pack_compositions,
+                                                                                              unpack_compositions)
+    g = torch.Generator().manual_seed(3)
+    for batch, n, d in ((5, 8, 3), (0, 8, 3), (2, 1, 2), (3, 216, 3)):
+        comp = AXL(A=torch.randint(0, 3, (batch, n), generator=g), X=torch.rand(batch, n, d, generator=g),
+                   L=torch.rand(batch, d * (d + 1) // 2, generator=g))
+        rows = pack_compositions(comp)
+        assert rows.dtype == torch.uint8 and rows.shape == (batch, 8 * n + 4 * n * d + 4 * (d * (d + 1) // 2))
+        back = unpack_compositions(rows, n, d)
+        assert all(torch.equal(a, b) for a, b in zip(comp, back))
+        two = unpack_compositions(torch.stack([rows, rows]), n, d)              # leading dimensions are kept
+        assert two.X.shape == (2, batch, n, d) and torch.equal(two.A[1], comp.A)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent spawns torch.distributed.run as a child (before any GPU
+    initialisation), relays rank 0's JSON line and exits with the child's code.  Rehearsal mode: host tensors, gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch",
+                          "--master-port", "29547"], env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    import json
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["gather_ok"] and line["collectives"] == 1
+    # a failing child is reported through the exit code
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch",
+                          "--workload", "nope"], env=env, capture_output=True, text=True, timeout=240)
+    assert bad.returncode != 0

@@ -1,5 +1,6 @@
-"""Per-iteration time of the persistent sampler with parts switched off (MDX_DIAG_SKIP: 1 = no forward, 2 = no update),
-with pre-drawn or in-kernel noise.  Run once per MDX_DIAG_SKIP value (the library reads it at every call)."""
+"""Per-iteration time of the persistent sampler with parts switched off (options MDX_MLP_SAMPLE_DIAG_NO_FORWARD /
+_NO_UPDATE), with pre-drawn or in-kernel noise.  Needs a diagnostics build of the library
+(`make -C .../csrc -B DIAG=1`); the release build answers MDX_ERR_UNSUPPORTED to these options."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,12 +16,12 @@ with torch.no_grad():
     start = gen.initialize(w["batch"], dev)
     sched, pack = gen._prepare(dev), gen.fused_pack(dev)
     for predrawn in (True, False):
-        for skip in ("0", "1", "2", "3"):
-            os.environ["MDX_DIAG_SKIP"] = skip
+        for skip in (0, 1, 2, 3):
+            options = (256 if skip & 1 else 0) | (512 if skip & 2 else 0)
             comp = type(start)(*[t.clone() for t in start])
             def launch(n):
                 kernels.mlp_pc_sample(sched, pack, gen._flags(True), 1, False, 900, n, gen._rng(0), comp.A, comp.X, comp.L,
-                                      gen._status, predrawn_noise=predrawn)
+                                      gen._status, workspace=gen._noise_workspace if predrawn else None, options=options)
             launch(100)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(); a.record(); launch(400); b.record(); torch.cuda.synchronize()
