@@ -25,3 +25,20 @@ def map_unit_cell_to_lattice_parameters(unit_cell: torch.Tensor) -> torch.Tensor
     out = torch.zeros(*unit_cell.shape[:-2], get_number_of_lattice_parameters(d)).to(unit_cell)
     out[..., :d] = torch.diagonal(unit_cell, dim1=-2, dim2=-1)
     return out
+
+
+def map_relative_coordinates_to_unit_cell(relative_coordinates: torch.Tensor) -> torch.Tensor:
+    """remainder(x, 1) with the reference's fix-up 1.0 -> 0.0 (:95-119), tensor of arbitrary shape -> same shape in [0, 1).
+
+    Runs on the device through the F1 kernel (mdx_noise_relative_coordinates: wrap(x0 + sigma z) with sigma = 0 and
+    z = x0, i.e. wrap(x + 0) -- the same wrap the predictor / corrector updates apply); device tensors only."""
+    from .. import kernels
+    x = relative_coordinates.to(torch.float32).contiguous()
+    return kernels.noise_relative_coordinates(x, x, 0.0).reshape(relative_coordinates.shape)
+
+
+def map_axl_composition_to_unit_cell(composition, device: torch.device):
+    """AXL with X wrapped into the unit cell, on `device` (:122-138)."""
+    from ..namespace import AXL
+    return AXL(A=composition.A.to(device), X=map_relative_coordinates_to_unit_cell(composition.X.to(device)),
+               L=composition.L.to(device))

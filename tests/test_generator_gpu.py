@@ -953,3 +953,178 @@ def test_c1_exact_configuration(cuda):
             comp = axl(g["corr_out_A"][k], g["corr_out_X"][k], lattice)
     assert gen.noise_source.inner.exhausted()
     assert worst < 1e-5, f"worst per-step rel-L2 {worst:.2e}"
+
+
+# -------------------------------------------------------------------------------------------------------------
+# round 2: what is benchmarked is what is pinned
+# -------------------------------------------------------------------------------------------------------------
+def _reference_draw_records(gen, batch, with_corrector):
+    """One iteration's records of mdx_mlp_pc_sample (layout: include/mdx_hip.h) from the generator's reference-order
+    draw hooks (langevin_generator.py:92-111 order: Gumbel u, binary u, z, z_lattice | corrector: z, z_lattice)."""
+    n, c = gen.number_of_atoms, gen.num_classes
+    gumbel = gen._draw_gumbel_sample(batch).reshape(batch, n * c)
+    u = gen._draw_binary_sample(batch) if gen.atom_type_greedy_sampling else torch.zeros(batch, n)
+    z = gen._draw_coordinates_gaussian_sample(batch).reshape(batch, n * 3)
+    gen._draw_lattice_gaussian_sample(batch)                                  # drawn by the reference, unused (fixed lattice)
+    rec = [z, gumbel, u.reshape(batch, n), torch.zeros(batch, 8)]             # table[7] = 0: no per-step posterior table
+    if with_corrector:
+        rec.append(gen._draw_coordinates_gaussian_sample(batch).reshape(batch, n * 3))
+        gen._draw_lattice_gaussian_sample(batch)
+    return torch.cat([t.to(torch.float32) for t in rec], dim=1).contiguous()
+
+
+@pytest.mark.parametrize("options", ["product", "generic"])
+def test_fused_sampler_teacher_forced_against_c1_exact(cuda, options):
+    """The persistent fused sampler -- the kernel the C2 headline measures (folded weights, hardware exp/sin/cos) -- against
+    the REFERENCE's own run of BASELINE configs[0] (tests/golden/traj_c1_exact.npz: T = 100, batch 16, MLP template):
+    for each of the 100 iterations the reference's recorded draws are written into the noise-workspace records
+    (MDX_MLP_SAMPLE_CALLER_NOISE: the pre-pass is skipped), ONE iteration is launched from the reference's recorded
+    composition, and the result is held to the bar of test_c1_exact_configuration: atom types exact, coordinates
+    within 1e-5 rel-L2 on the torus.  Predictor alone (M = 0 launch) against the recorded predictor output, then
+    predictor + corrector (the product's iteration) against the recorded corrector output."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
+    P = _pkg()
+    g = load_golden("traj_c1_exact.npz")
+    noise_kw, sampling_kw, netf = cases.C1_EXACT
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar, spar = P["Noise"](**noise_kw), P["Sampling"](**dict(sampling_kw, fused_score_network=True))
+    net = nets.load_fixture_weights(netf(None), g).to(cuda)
+    B = int(g["batch"])
+    gen = P["Langevin"](npar, spar, net)
+    gen.noise_source = _replayed(g)
+    opt = 0 if options == "product" else _hip.MLP_SAMPLE_GENERIC_KERNEL | _hip.MLP_SAMPLE_UNFOLDED
+    with torch.no_grad():
+        sched = gen._prepare(cuda)
+        gen._begin_call(cuda)
+        lattice = gen.initialize(B, cuda).L                     # consumes the initial draws
+        pack = kernels.MlpPack(net, cuda)
+        if options == "product":
+            assert pack.c_struct.folded_input and pack.c_struct.folded_output
+
+        def launch(a, x, index, records, correctors):
+            comp = RS.AXL(A=torch.from_numpy(a.astype(np.int64)).to(cuda), X=torch.from_numpy(x).to(cuda), L=lattice.clone())
+            kernels.mlp_pc_sample(sched, pack, gen._flags(True), correctors, False, int(index), 1, gen._rng(0), comp.A,
+                                  comp.X, comp.L, gen._status, caller_records=records, options=opt)
+            return comp.A.cpu().numpy(), comp.X.cpu().numpy()
+
+        a_in, x_in = g["start_A"], g["start_X"]
+        worst_pred = worst_iter = 0.0
+        for k, index in enumerate(g["pred_index"]):
+            records = _reference_draw_records(gen, B, True).to(cuda)
+            n_pred = 8 * (3 + 2 + 1) + 8
+            a, x = launch(a_in, x_in, index, records[:, :n_pred].contiguous(), 0)          # predictor alone
+            assert np.array_equal(a, g["pred_out_A"][k]), ("pred", k)
+            worst_pred = max(worst_pred, torus_rel_l2(x, g["pred_out_X"][k]))
+            a, x = launch(a_in, x_in, index, records, 1)                                    # the product's iteration
+            assert np.array_equal(a, g["corr_out_A"][k]), ("iteration", k)
+            worst_iter = max(worst_iter, torus_rel_l2(x, g["corr_out_X"][k]))
+            a_in, x_in = g["corr_out_A"][k], g["corr_out_X"][k]
+    assert gen.noise_source.inner.exhausted()
+    assert worst_pred < 1e-5, f"predictor: worst rel-L2 {worst_pred:.2e}"
+    assert worst_iter < 1e-5, f"predictor + corrector: worst rel-L2 {worst_iter:.2e}"
+
+
+def _diamond_sites(n_cells):
+    base = torch.tensor([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0],
+                         [.25, .25, .25], [.25, .75, .75], [.75, .25, .75], [.75, .75, .25]])
+    cells = torch.cartesian_prod(*[torch.arange(n_cells)] * 3).float()
+    return ((cells[:, None, :] + base[None]) / n_cells).reshape(-1, 3)
+
+
+def _c5_generator(cuda, net, resampling, T, seed=77, use_graph=False):
+    P = _pkg()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = P["Noise"](**cases.noise_ns(T, **cases.LIN))
+        spar = P["Sampling"](**cases.sampling_ns(216, 1, M=2, greedy=False, one=False, cell=[16.29] * 3),
+                             rng_mode="device", seed=seed, repaint_resampling_steps=resampling, use_hip_graph=use_graph)
+    constraint = P["Constraint"](elements=["Si"], constrained_relative_coordinates=_diamond_sites(3)[:108].clone(),
+                                 constrained_atom_types=torch.zeros(108, dtype=torch.long))
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.constrained_langevin_generator import \
+        ConstrainedLangevinGenerator
+    return ConstrainedLangevinGenerator(npar, spar, net, constraint), npar, spar
+
+
+@pytest.mark.parametrize("resampling", [0, 1])
+def test_c5_workload_repaint_egnn_radial_graph(cuda, resampling):
+    """BASELINE configs[4] at its workload: N = 216 (Si 3x3x3, 16.29 A cell, graph cell clipped to
+    16.5 A), K = 108 diamond sites pinned (constrained_indices = arange), ConstrainedLangevinGenerator, EGNN with the HIP
+    radius graph at rc = 7.5 (reduced width), M = 2, B = 256 per GPU, without and with resampling.  Properties the domain
+    offers at this size: constrained rows pinned exactly, coordinates in [0, 1), full unmasking, determinism under the
+    seed; and the time-index sweep includes index 0 (T steps down to 0)."""
+    torch.manual_seed(4321)
+    net = nets.egnn_net(1, "radial_cutoff", 7.5, hidden=32, n_layers=2, n_hidden=1).to(cuda)
+    outs = []
+    for _ in range(2):
+        gen, npar, spar = _c5_generator(cuda, net, resampling, T=5)
+        with torch.no_grad():
+            outs.append(_np(gen.sample(256, cuda)))
+    out = outs[0]
+    sites = _diamond_sites(3)[:108].numpy()
+    assert out.X.shape == (256, 216, 3) and out.A.shape == (256, 216)
+    assert np.array_equal(out.X[:, :108], np.broadcast_to(sites, (256, 108, 3)))          # pinned bit for bit
+    assert (out.A[:, :108] == 0).all()
+    assert (out.A != 1).all(), "MASK left at the last step"
+    assert np.isfinite(out.X).all() and (out.X >= 0).all() and (out.X < 1).all()
+    assert np.array_equal(outs[0].A, outs[1].A) and np.array_equal(outs[0].X.view(np.int32), outs[1].X.view(np.int32))
+    free = out.X[:, 108:]
+    assert free.std() > 0.2                                                              # the free atoms did move around
+
+
+@pytest.mark.parametrize("resampling", [0, 1])
+def test_c5_shape_bitwise_against_oracle(cuda, resampling):
+    """The C5 shape (N = 216, K = 108, M = 2, repaint, +- resampling) at a small batch with the echo network: the GPU
+    generator equals the CPU oracle bit for bit (atom types and coordinates), index 0 included."""
+    P = _pkg()
+    net = nets.fake_net(1)
+    gen, npar, spar = _c5_generator(cuda, net.to(cuda), resampling, T=6, seed=78)
+    with torch.no_grad():
+        out = _np(gen.sample(3, cuda))
+    sites = _diamond_sites(3)[:108].numpy()
+    ora = RS.OracleLangevinGenerator(npar, spar, nets.fake_net(1), noise=RS.PhiloxNoise(78, 0),
+                                     constraint=dict(constrained_relative_coordinates=sites,
+                                                     constrained_atom_types=np.zeros(108, dtype=np.int64),
+                                                     constrained_indices=None)).sample(3)
+    assert np.array_equal(out.A, ora.A)
+    assert np.array_equal(out.X.view(np.int32), ora.X.view(np.int32))
+    assert np.array_equal(out.X[:, :108], np.broadcast_to(sites, (3, 108, 3)))
+
+
+@pytest.mark.parametrize("name", ["traj_fake_c3_m2", "traj_mlp_c3"])
+def test_start_from_given_configuration_on_the_hip_path(cuda, name, tmp_path):
+    """I2 (generators/trajectory_initializer.py:134-186): a run started from a {noisy_axl, start_time_step_index} pickle at
+    index k equals the tail of the full run.  Device RNG: a draw is a pure function of (seed, call, time index), so the
+    tail from the recorded composition at index k is bit-identical to the full run's remainder."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.trajectory_initializer import (
+        StartFromGivenConfigurationTrajectoryInitializer, instantiate_trajectory_initializer)
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import NOISY_AXL_COMPOSITION
+    gen, npar, spar, _ = _build(name, cases.TRAJECTORIES, cuda, rng_mode="device", seed=21)
+    T, k, B = npar.total_time_steps, 6, 9
+    with torch.no_grad():
+        gen._prepare(cuda)
+        gen._begin_call(cuda)
+        start = gen.initialize(B, cuda)
+        middle = gen.sample_from_noisy_composition(start, T, k)             # indices T-1 .. k
+        full = _np(gen.sample_from_noisy_composition(middle, k, 0))
+        gen.check_status()
+    path = tmp_path / "start.pickle"
+    torch.save({NOISY_AXL_COMPOSITION: RS_AXL_cpu(middle), "start_time_step_index": k}, path)
+    init = instantiate_trajectory_initializer(spar, path_to_starting_configuration_data_pickle=str(path))
+    assert isinstance(init, StartFromGivenConfigurationTrajectoryInitializer)
+    assert init.create_start_time_step_index(T) == k and init.create_end_time_step_index() == 0
+    gen2, *_ = _build(name, cases.TRAJECTORIES, cuda, rng_mode="device", seed=21)
+    gen2.trajectory_initializer = init
+    with torch.no_grad():
+        resumed = _np(gen2.sample(B, cuda))                                  # call index 0, as the first run
+    assert np.array_equal(resumed.A, full.A)
+    assert np.array_equal(resumed.X.view(np.int32), full.X.view(np.int32))
+    with pytest.raises(AssertionError):
+        gen2.sample(B + 1, cuda)                                             # the file holds B samples (:176-180)
+
+
+def RS_AXL_cpu(comp):
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import AXL
+    return AXL(A=comp.A.cpu(), X=comp.X.cpu(), L=comp.L.cpu())
