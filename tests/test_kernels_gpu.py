@@ -434,22 +434,36 @@ def test_compute_distances_in_batch_against_golden(cuda):
         np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
 
 
-def test_bench_contract(cuda):
-    """bench.py prints ONE JSON line with the contract's keys (tiny run: 20 steps of the default workload)."""
+@pytest.mark.parametrize("workload", [None, "C2"])
+def test_bench_contract(cuda, workload):
+    """bench.py prints ONE JSON line with the contract's keys: the default workload (C3 = the headline configuration) and
+    C2, whose `value` comes from one whole trajectory timed end to end whatever --steps says."""
     import json
     import subprocess
     import sys as _sys
     from conftest import ROOT
-    out = subprocess.run([_sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    steps, warmup = (2, 1) if workload is None else (20, 5)
+    cmd = [_sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline"] + ([] if workload is None else ["--workload", workload])
+    env = dict(os.environ, MDX_STRAY_VARIABLE="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "job_ms", "value_from"):
         assert key in d, key
-    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0 and d["vs_baseline"] is None
-    assert d["config"]["workload"].startswith("C2") and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup and d["value"] > 0 and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith(workload or "C3") and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["config"]["env"] == {"MDX_STRAY_VARIABLE": "1"}          # stray MDX_* variables are visible, and unused
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(d["value"] - d["config"]["global_batch"] / (d["job_ms"] * 1e-3)) < 1e-3 * d["value"]
+    if workload == "C2":
+        # the job is ONE launch of 1000 iterations: value is measured on it, not extrapolated from the 20-step region
+        assert d["value_from"].startswith("one whole 1000-iteration trajectory")
+        assert d["job_ms"] < 1000 * d["ms_per_step"]
+        assert d["generic_path"]["value"] > 0 and d["generic_path"]["value"] <= d["value"] * 1.05
+    else:
+        assert abs(d["job_ms"] - 1000 * d["ms_per_step"]) < 1e-6 * d["job_ms"] + 1e-3
