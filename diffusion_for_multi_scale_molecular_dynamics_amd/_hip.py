@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(CSRC, "libmdx_hip.so")
 
 MDX_OK = 0
 MDX_PREDICTOR, MDX_CORRECTOR = 0, 1
-STATUS_CUTOFF_TOO_LARGE, STATUS_MASK_AT_LAST_STEP = 1, 2
+STATUS_CUTOFF_TOO_LARGE, STATUS_MASK_AT_LAST_STEP, STATUS_EGNN_F16_RANGE, STATUS_GRAPH_CAPACITY = 1, 2, 4, 8
+EGNN_CHAIN_MAX_LAYERS = 16
 MAX_CLASSES = 8
 TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
     TAG_INIT_LATTICE, TAG_RESAMPLE_Z, TAG_RESAMPLE_U = range(11)
@@ -27,6 +28,7 @@ ABI_SYMBOLS = (
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
     "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_mlp_forward",
     "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
+    "mdx_egnn_chain_image_bytes", "mdx_egnn_chain_pack", "mdx_egnn_edge_chain", "mdx_egnn_coord_aggregate",
     "mdx_rng_fill", "mdx_math_probe",
 )
 MLP_MAX_HIDDEN = 8
@@ -69,6 +71,12 @@ class Mlp(C.Structure):
         [("w_hidden_t", C.c_void_p * 8), ("b_hidden", C.c_void_p * 8)] + \
         [(n, C.c_void_p) for n in ("w_out_a_t", "b_out_a", "w_out_x_t", "b_out_x", "w_out_l_t", "b_out_l",
                                    "packed_image", "folded_input", "folded_output")]
+
+
+class EgnnChain(C.Structure):
+    """mdx_egnn_chain_t"""
+    _fields_ = [(n, C.c_int32) for n in ("hidden", "n_message_layers", "n_coord_layers", "precision")] + \
+        [(n, C.c_void_p) for n in ("weight_image", "biases", "bias_in", "w_radial", "w_out")]
 
 
 def build(force=False):
@@ -158,6 +166,14 @@ def _declare(L):
     L.mdx_egnn_coord_head.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]
     L.mdx_segment_rows.restype = i32
     L.mdx_segment_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp]
+    L.mdx_egnn_chain_image_bytes.restype = i64
+    L.mdx_egnn_chain_image_bytes.argtypes = [i32, i32]
+    L.mdx_egnn_chain_pack.restype = i32
+    L.mdx_egnn_chain_pack.argtypes = [C.POINTER(vp), i32, i32, i32, vp, vp]
+    L.mdx_egnn_edge_chain.restype = i32
+    L.mdx_egnn_edge_chain.argtypes = [C.POINTER(EgnnChain), vp, vp, i32, vp, i64, vp, vp, vp, vp, vp]
+    L.mdx_egnn_coord_aggregate.restype = i32
+    L.mdx_egnn_coord_aggregate.argtypes = [vp, vp, i32, vp, vp, vp, i64, i32, vp, vp]
     L.mdx_rng_fill.restype = i32
     L.mdx_rng_fill.argtypes = [i32, u64, u32, u32, u32, i64, i32, vp, vp]
     L.mdx_math_probe.restype = i32

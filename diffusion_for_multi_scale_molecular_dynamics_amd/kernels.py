@@ -510,6 +510,78 @@ def segment_rows(data, offsets, degree, mean: bool) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# fused EGNN edge chain on the matrix cores (csrc/mdx_egnn_chain.hip)
+# ----------------------------------------------------------------------------------------------------------------
+EDGE_CHAIN_PRECISIONS = {"f32": 0, "f16x3": 1}
+
+
+class EdgeChainPack:
+    """Device image of one E_GCL layer's per-edge MLP chain for mdx_egnn_edge_chain: the H -> H weight matrices of the
+    message MLP (after its first layer) and of the coordinate MLP, re-laid out by mdx_egnn_chain_pack for `precision`,
+    plus the small vectors.  Built from the modules' parameters at construction; `stamp` tells when to rebuild."""
+
+    def __init__(self, first_message_layer, message_layers, coord_layers, coord_out_layer, input_size: int, precision: str):
+        H = first_message_layer.out_features
+        dev = first_message_layer.weight.device
+        layers = list(message_layers) + list(coord_layers)
+        if precision not in EDGE_CHAIN_PRECISIONS:
+            raise _hip.MdxError(f"edge-chain precision must be one of {sorted(EDGE_CHAIN_PRECISIONS)}; got {precision!r}")
+        if not self.supported(first_message_layer, message_layers, coord_layers, coord_out_layer):
+            raise _hip.MdxError("this E_GCL shape is not covered by the fused edge chain (see mdx_egnn_edge_chain)")
+        self.precision, self.hidden = precision, H
+        self._keep = [layer.weight.detach().to(F32).contiguous() for layer in layers]
+        n_bytes = lib().mdx_egnn_chain_image_bytes(H, len(layers))
+        self.image = torch.empty(n_bytes, dtype=torch.uint8, device=dev)
+        array = (C.c_void_p * len(layers))(*[w.data_ptr() for w in self._keep])
+        with torch.cuda.device(dev):
+            check(lib().mdx_egnn_chain_pack(array, len(layers), H, EDGE_CHAIN_PRECISIONS[precision],
+                                            C.c_void_p(self.image.data_ptr()), stream_handle()), "mdx_egnn_chain_pack")
+        self.biases = torch.stack([layer.bias.detach().to(F32) for layer in layers]).contiguous()
+        self.bias_in = first_message_layer.bias.detach().to(F32).contiguous()
+        self.w_radial = first_message_layer.weight.detach()[:, 2 * input_size].to(F32).contiguous()
+        self.w_out = coord_out_layer.weight.detach().reshape(-1).to(F32).contiguous()
+        self.c_struct = _hip.EgnnChain(H, len(list(message_layers)), len(list(coord_layers)),
+                                       EDGE_CHAIN_PRECISIONS[precision], self.image.data_ptr(), self.biases.data_ptr(),
+                                       self.bias_in.data_ptr(), self.w_radial.data_ptr(), self.w_out.data_ptr())
+        self._keep = []                    # the image holds its own copy of the matrices
+        self.device = dev
+
+    @staticmethod
+    def supported(first_message_layer, message_layers, coord_layers, coord_out_layer) -> bool:
+        H = first_message_layer.out_features
+        layers = list(message_layers) + list(coord_layers)
+        return (H in (32, 64, 128, 256) and len(list(message_layers)) >= 1 and len(list(coord_layers)) >= 1 and
+                len(layers) <= _hip.EGNN_CHAIN_MAX_LAYERS and
+                all(l.in_features == H and l.out_features == H and l.bias is not None for l in layers) and
+                first_message_layer.bias is not None and coord_out_layer.in_features == H and
+                coord_out_layer.out_features == 1 and coord_out_layer.bias is None)
+
+
+def egnn_edge_chain(pack: EdgeChainPack, node_proj, coord, edges, status=None, n_edges_dev=None):
+    """messages [E,H], edge_scalar [E] of the fused per-edge chain (mdx_egnn_edge_chain); edges sorted by source."""
+    E, H = edges.shape[0], pack.hidden
+    assert node_proj.shape[1] == 2 * H and coord.shape[0] == node_proj.shape[0]
+    messages = torch.empty(E, H, dtype=F32, device=edges.device)
+    scalar = torch.empty(E, dtype=F32, device=edges.device)
+    rc = lib().mdx_egnn_edge_chain(C.byref(pack.c_struct), ptr(node_proj, F32, "node_proj"), ptr(coord, F32, "coord"),
+                                   coord.shape[1], ptr(edges, I64, "edges"), E, ptr(n_edges_dev, I64, "n_edges_dev"),
+                                   ptr(messages, F32, "messages"), ptr(scalar, F32, "edge_scalar"),
+                                   ptr(status, I32, "status"), stream_handle())
+    check(rc, "mdx_egnn_edge_chain")
+    return messages, scalar
+
+
+def egnn_coord_aggregate(edge_scalar, coord, edges, offsets, degree, mean: bool) -> torch.Tensor:
+    """coord + segment sum/mean of (coord_i - coord_dst) * edge_scalar over each node's sorted edges."""
+    out = torch.empty_like(coord)
+    rc = lib().mdx_egnn_coord_aggregate(ptr(edge_scalar, F32, "edge_scalar"), ptr(coord, F32, "coord"), coord.shape[1],
+                                        ptr(edges, I64, "edges"), ptr(offsets, I64, "offsets"), ptr(degree, I64, "degree"),
+                                        coord.shape[0], int(bool(mean)), ptr(out, F32, "coord_out"), stream_handle())
+    check(rc, "mdx_egnn_coord_aggregate")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # RNG fills / probes
 # ----------------------------------------------------------------------------------------------------------------
 RNG_UNIFORM, RNG_NORMAL, RNG_GUMBEL = 0, 1, 2

@@ -9,7 +9,17 @@ get_edges_batch produce):
     which removes the [E, 2H+1] concatenation and 2/5 of the message-MLP FLOPs;
   * on device tensors the two per-node reductions run as one-wavefront-per-node HIP kernels over the sorted segments
     (kernels.segment_rows for the messages; kernels.egnn_coord_head = last coordinate layer H -> 1, product with
-    coord_diff and segment mean in one pass over the [E, H] activations).
+    coord_diff and segment mean in one pass over the [E, H] activations);
+  * on device tensors, without autograd, the whole per-edge part of a layer -- first message layer, the message MLP,
+    the coordinate MLP and its H -> 1 head -- is ONE hand-written MFMA kernel (kernels.egnn_edge_chain,
+    csrc/mdx_egnn_chain.hip) that keeps the [E, H] activations in registers between layers; `edge_chain_precision`
+    selects exact binary32 MFMA ("f32") or the split-f16 three-product form ("f16x3"); None keeps the per-layer
+    library-GEMM path (also taken for shapes the kernel does not cover: attention, tanh, normalize, unequal widths).
+
+The HIP calls are invisible to autograd, so they are used only when no gradient can be requested (torch.no_grad(), or
+nothing requires grad); with autograd on, the module runs as plain PyTorch.  Callers that pass their own edge list
+(no `degree`) get it sorted by source here first: the segment kernels need that order, the reference's
+unsorted_segment_sum accepted any.
 """
 from typing import Callable, Optional, Tuple
 
@@ -68,6 +78,9 @@ class E_GCL(nn.Module):
         self.epsilon = 1e-8
         self.input_size = input_size
         self.use_fused_ops = True        # device tensors only; the CPU path is plain PyTorch
+        self.edge_chain_precision = "f32"    # "f32" | "f16x3" | None (per-layer library GEMMs)
+        self.status_word = None          # device int32 word for MDX_STATUS_EGNN_F16_RANGE (set by the score network)
+        self._chain = (None, None)       # (stamp, kernels.EdgeChainPack)
 
         mh, nh, ch = message_hidden_dimensions_size, node_hidden_dimensions_size, coordinate_hidden_dimensions_size
         layers = [nn.Linear(2 * input_size + 1, mh), act_fn]
@@ -114,6 +127,40 @@ class E_GCL(nn.Module):
             out = out * self.att_mlp(out)
         return out
 
+    def _chain_modules(self):
+        """(first message layer, message H->H layers, coordinate H->H layers, coordinate head) if the per-edge MLPs have
+        the Linear / SiLU alternation the fused kernel implements, else None."""
+        if self.attention or self.normalize or self.tanh:
+            return None
+        message, coordinate = list(self.message_mlp), list(self.coord_mlp)
+        if len(message) % 2 or len(coordinate) % 2 == 0:
+            return None
+        pairs = list(zip(message[0::2], message[1::2])) + list(zip(coordinate[0:-1:2], coordinate[1:-1:2]))
+        if not all(isinstance(lin, nn.Linear) and isinstance(act, nn.SiLU) for lin, act in pairs):
+            return None
+        if not isinstance(coordinate[-1], nn.Linear):
+            return None
+        return message[0], message[2::2], coordinate[0:-1:2], coordinate[-1]
+
+    def _edge_chain_pack(self):
+        """The layer's kernels.EdgeChainPack, rebuilt when a parameter, the device or the precision changed; None when
+        the fused kernel does not apply."""
+        if self.edge_chain_precision is None:
+            return None
+        modules = self._chain_modules()
+        if modules is None:
+            return None
+        from .. import kernels
+        if not kernels.EdgeChainPack.supported(*modules):
+            return None
+        linears = [modules[0], *modules[1], *modules[2], modules[3]]
+        stamp = (self.edge_chain_precision,) + tuple((t.data_ptr(), t._version) for lin in linears
+                                                      for t in (lin.weight, lin.bias) if t is not None)
+        if self._chain[0] != stamp:
+            self._chain = (stamp, kernels.EdgeChainPack(*modules, input_size=self.input_size,
+                                                        precision=self.edge_chain_precision))
+        return self._chain[1]
+
     def _coord_head_is_plain(self) -> bool:
         last = self.coord_mlp[-1]
         return isinstance(last, nn.Linear) and last.out_features == 1 and last.bias is None and \
@@ -127,6 +174,14 @@ class E_GCL(nn.Module):
         row, col = edge_index[:, 0], edge_index[:, 1]
         if degree is None:
             degree = torch.bincount(row, minlength=h.shape[0])
+        # the HIP calls are invisible to autograd: only when no gradient can be requested
+        needs_grad = torch.is_grad_enabled() and (h.requires_grad or coord.requires_grad or
+                                                  any(t.requires_grad for t in self.parameters()))
+        fused = self.use_fused_ops and h.is_cuda and not needs_grad
+        if fused and offsets is not None and edge_index.shape[0] > 0:
+            pack = self._edge_chain_pack()
+            if pack is not None:
+                return self._forward_edge_chain(pack, h, edge_index, coord, degree, offsets)
         inv_deg = (1.0 / degree.clamp(min=1).to(h.dtype)).unsqueeze(1)
 
         coord_diff = coord.index_select(0, row) - coord.index_select(0, col)
@@ -134,7 +189,6 @@ class E_GCL(nn.Module):
         if self.normalize:
             coord_diff = torch.tanh(radial) / torch.sqrt(radial + self.epsilon ** 2) * coord_diff
 
-        fused = self.use_fused_ops and h.is_cuda
         messages = self._messages(h, edge_index, radial, fused)
 
         segments = fused and offsets is not None and messages.shape[1] % 4 == 0
@@ -158,6 +212,23 @@ class E_GCL(nn.Module):
         if self.residual:
             out = h + out
         return out, coord
+
+
+    def _forward_edge_chain(self, pack, h, edge_index, coord, degree, offsets):
+        """E_GCL.forward with the per-edge work in one MFMA kernel: node projections (library GEMM, per node) -> fused
+        chain -> the two sorted-segment reductions -> node MLP."""
+        from .. import kernels
+        first, n_in = self.message_mlp[0], self.input_size
+        w = first.weight
+        proj = torch.nn.functional.linear(h, torch.cat([w[:, :n_in], w[:, n_in:2 * n_in]], dim=0))
+        coord = coord.contiguous()
+        messages, edge_scalar = kernels.egnn_edge_chain(pack, proj.contiguous(), coord, edge_index, status=self.status_word)
+        coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean)
+        agg = kernels.segment_rows(messages, offsets, degree, self.message_mean)
+        out = run_mlp(self.node_mlp, torch.cat([h, agg], dim=1), True)
+        if self.residual:
+            out = h + out
+        return out, coord_out
 
 
 class EGNN(nn.Module):
@@ -199,6 +270,9 @@ class EGNN(nn.Module):
         else:
             h = emb(h)
         if degree is None:
+            # a caller's own edge list: any order is accepted (as by the reference's unsorted_segment_sum); the segment
+            # kernels need the edges grouped by source, so sort them (stable: the order within a node is kept)
+            edges = edges[torch.argsort(edges[:, 0], stable=True)]
             degree = torch.bincount(edges[:, 0], minlength=h.shape[0])
         offsets = (torch.cumsum(degree, 0) - degree) if h.is_cuda else None
         for layer in self.graph_layers:

@@ -102,8 +102,30 @@ class EGNNScoreNetwork(ScoreNetwork):
                 "A floating point value for the radial cutoff is needed for edges=radial_cutoff."
         self.drop_duplicate_edges = hp.drop_duplicate_edges
         self.edge_builder = edge_builder
-        self.graph_status = None      # device word that collects MDX_STATUS_CUTOFF_TOO_LARGE without a sync
-        self.egnn = EGNN(
+        self.graph_status = None      # device word that collects MDX_STATUS_* bits of the forward without a sync
+        self.egnn = self._make_egnn(hp)
+
+    @property
+    def edge_chain_precision(self):
+        """"f32" (exact binary32 MFMA), "f16x3" (split-f16, three products) or None (per-layer library GEMMs): the
+        arithmetic of the fused per-edge MFMA kernel of every graph layer (models/egnn.py)."""
+        return self.egnn.graph_layers[0].edge_chain_precision if len(self.egnn.graph_layers) else None
+
+    @edge_chain_precision.setter
+    def edge_chain_precision(self, value):
+        for layer in self.egnn.graph_layers:
+            layer.edge_chain_precision = value
+
+    def check_status(self):
+        """Raise for any MDX_STATUS_* bit the forward passes have collected (one host read); clears the word."""
+        if self.graph_status is not None:
+            try:
+                neighbors._raise_if_cutoff_too_large(self.graph_status)
+            finally:
+                self.graph_status.zero_()
+
+    def _make_egnn(self, hp):
+        return EGNN(
             input_size=self.number_of_features_per_node, num_classes=self.num_atom_types + 1,
             message_n_hidden_dimensions=hp.message_n_hidden_dimensions,
             message_hidden_dimensions_size=hp.message_hidden_dimensions_size,
@@ -144,6 +166,10 @@ class EGNNScoreNetwork(ScoreNetwork):
         comp = batch[NOISY_AXL_COMPOSITION]
         x = comp.X
         bsz, n, d = x.shape
+        if x.is_cuda and (self.graph_status is None or self.graph_status.device != x.device):
+            self.graph_status = torch.zeros(1, dtype=torch.int32, device=x.device)
+        for layer in self.egnn.graph_layers:       # where the fused edge chain reports MDX_STATUS_EGNN_F16_RANGE
+            layer.status_word = self.graph_status if x.is_cuda else None
         edges, degree = self._build_edges(x, comp.L)
 
         flat = x.reshape(bsz * n, d)

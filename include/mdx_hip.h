@@ -40,6 +40,8 @@ extern "C" {
 /* bits of the optional device status word */
 #define MDX_STATUS_CUTOFF_TOO_LARGE 1u   /* utils/neighbors.py:107-113 assert               */
 #define MDX_STATUS_MASK_AT_LAST_STEP 2u  /* generators/langevin_generator.py:616-620 assert */
+#define MDX_STATUS_EGNN_F16_RANGE 4u     /* mdx_egnn_edge_chain, split-f16 mode: an activation left the f16 range     */
+#define MDX_STATUS_GRAPH_CAPACITY 8u     /* mdx_radius_graph_fill_capped: more edges than the caller's capacity      */
 
 #define MDX_MAX_CLASSES 8      /* C supported by the fused atom-type kernels */
 #define MDX_PREDICTOR 0
@@ -324,6 +326,45 @@ MDX_API int mdx_egnn_coord_head(const float* hidden, const float* w_out, const f
                                 float* trans, mdx_stream_t stream);
 MDX_API int mdx_segment_rows(const float* data, const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int H,
                              int mean, float* out, mdx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fused EGNN edge chain on the matrix cores (hand-written MFMA kernel, csrc/mdx_egnn_chain.hip): for every edge of the
+ * SORTED edge list, the whole per-edge part of E_GCL.forward (models/egnn.py:136-200, 232-289) in one launch --
+ *   x0  = SiLU(node_proj[src,:H] + node_proj[dst,H:] + bias_in + |coord_src - coord_dst|^2 w_radial)   (first message layer)
+ *   x   = SiLU(x W_l^T + b_l), l = 0 .. n_message_layers-1                  -> messages_out [E,H]
+ *   y   = SiLU(y W_l^T + b_l), l = n_message_layers .. +n_coord_layers-1    (coordinate MLP, all its H -> H layers)
+ *   edge_scalar_out[e] = y . w_out                                          (its last layer, Linear(H, 1, bias=False))
+ * The [E,H] activations stay in registers between layers (accumulator tile == next layer's MFMA operand).
+ * hidden in {32, 64, 128, 256}; message and coordinate MLPs of equal width; SiLU activations; no attention / tanh /
+ * normalize (callers keep the per-layer library path for those).
+ * precision 0: v_mfma_f32_32x32x2_f32, exact binary32 (== fmaf chains in a fixed order).
+ * precision 1: split-f16, three v_mfma_f32_32x32x16_f16 per product (hi.hi + hi.lo + lo.hi), binary32 accumulation:
+ *              ~2^-22 relative per product; sets MDX_STATUS_EGNN_F16_RANGE when an activation exceeds 6e4 in magnitude.
+ * weight_image: the n_message_layers + n_coord_layers matrices [H,H] (nn.Linear layout) re-laid out by
+ * mdx_egnn_chain_pack for the chosen precision (mdx_egnn_chain_image_bytes bytes, caller-owned, 16-byte aligned).
+ * n_edges: number of edge rows to process = capacity of the outputs; n_edges_dev (nullable): device word with the actual
+ * count (<= n_edges), for callers that size the edge list without reading it back. */
+#define MDX_EGNN_CHAIN_MAX_LAYERS 16
+typedef struct mdx_egnn_chain {
+    int32_t hidden, n_message_layers, n_coord_layers, precision;
+    const void* weight_image;
+    const float* biases;       /* [n_message_layers + n_coord_layers, H] */
+    const float* bias_in;      /* [H]  bias of the first message layer                       */
+    const float* w_radial;     /* [H]  its weight column for the squared distance            */
+    const float* w_out;        /* [H]  weight of the last coordinate layer                   */
+} mdx_egnn_chain_t;
+MDX_API int64_t mdx_egnn_chain_image_bytes(int hidden, int n_layers);
+MDX_API int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, int hidden, int precision, void* image_out,
+                                mdx_stream_t stream);
+MDX_API int mdx_egnn_edge_chain(const mdx_egnn_chain_t* chain_host, const float* node_proj, const float* coord,
+                                int coord_dimension, const int64_t* edges, int64_t n_edges, const int64_t* n_edges_dev,
+                                float* messages_out, float* edge_scalar_out, uint32_t* status, mdx_stream_t stream);
+/* coord_out[i,:] = coord[i,:] + (1/degree_i if mean) sum_{e in segment i} (coord[i,:] - coord[dst_e,:]) edge_scalar[e]
+ * -- E_GCL.coord_model's trans = coord_diff * coord_mlp(m), unsorted_segment_sum / _mean and the residual add
+ * (models/egnn.py:162-200), on the sorted segments; no atomics, fixed summation order. */
+MDX_API int mdx_egnn_coord_aggregate(const float* edge_scalar, const float* coord, int coord_dimension, const int64_t* edges,
+                                     const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int mean,
+                                     float* coord_out, mdx_stream_t stream);
 
 /* Device-RNG draws as stand-alone fills (trajectory initialisation, tests of the RNG specification).
  * kind 0 = uniform (0,1), 1 = standard normal, 2 = Gumbel(0,1).  out [n_items, width]. */

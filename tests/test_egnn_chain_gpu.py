@@ -1,0 +1,226 @@
+"""The hand-written MFMA edge-chain kernel (csrc/mdx_egnn_chain.hip) against fp64 references, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import nets
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_l2(got, want):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return float((got.detach() - want.detach()).norm() / want.detach().norm().clamp(min=1e-300))
+
+
+def _chain_reference(lin0, msg, crd, out, n_in, h, coord, edges):
+    """E_GCL's per-edge part in fp64 exactly as models/egnn.py:136-200 composes it (concat -> Linear -> SiLU ...)."""
+    f64 = torch.float64
+    src, dst = edges[:, 0], edges[:, 1]
+    diff = coord.to(f64)[src] - coord.to(f64)[dst]
+    radial = (diff ** 2).sum(1, keepdim=True)
+    x = torch.cat([h.to(f64)[src], h.to(f64)[dst], radial], dim=1)
+    silu = torch.nn.functional.silu
+    x = silu(x @ lin0.weight.to(f64).t() + lin0.bias.to(f64))
+    for layer in msg:
+        x = silu(x @ layer.weight.to(f64).t() + layer.bias.to(f64))
+    y = x
+    for layer in crd:
+        y = silu(y @ layer.weight.to(f64).t() + layer.bias.to(f64))
+    return x, (y @ out.weight.to(f64).t()).reshape(-1)
+
+
+# tolerance per arithmetic mode: rel-L2 of the [E, H] messages and of the per-edge scalar against fp64
+TOLERANCE = {"f32": 2e-6, "f16x3": 1e-5}
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("H,n_msg,n_crd,n_nodes,deg", [(32, 1, 1, 40, 7), (64, 2, 3, 300, 11), (128, 3, 2, 500, 25),
+                                                        (256, 4, 5, 1200, 25), (256, 1, 1, 3, 2)])
+def test_edge_chain_against_fp64(cuda, precision, H, n_msg, n_crd, n_nodes, deg):
+    """Random network, random node features, a ragged sorted edge list whose length is not a multiple of the 128-edge
+    workgroup tile: messages [E,H] and the coordinate head's scalar against the fp64 evaluation of the reference's
+    composition (asymmetric random weights: any transposed or permuted fragment map shows up as an O(1) error)."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    g = torch.Generator().manual_seed(1000 * H + n_nodes)
+    n_in, D = 24, 6
+    torch.manual_seed(H + n_msg)
+    lin0 = torch.nn.Linear(2 * n_in + 1, H)
+    msg = [torch.nn.Linear(H, H) for _ in range(n_msg)]
+    crd = [torch.nn.Linear(H, H) for _ in range(n_crd)]
+    out = torch.nn.Linear(H, 1, bias=False)
+    for layer in msg + crd:                      # activations of order one through the whole chain (default init shrinks them)
+        with torch.no_grad():
+            layer.weight.mul_(1.7)
+    degree = torch.randint(0, 2 * deg, (n_nodes,), generator=g)
+    degree[0] = 0
+    degree[-1] = max(int(degree[-1]), 6)
+    src = torch.repeat_interleave(torch.arange(n_nodes), degree)
+    E = int(src.numel())
+    dst = torch.randint(0, n_nodes, (E,), generator=g)
+    edges = torch.stack([src, dst], 1)
+    h = torch.randn(n_nodes, n_in, generator=g)
+    coord = torch.rand(n_nodes, D, generator=g) * 2 - 1
+    want_m, want_s = _chain_reference(lin0, msg, crd, out, n_in, h, coord, edges)
+
+    mods = [m.to(cuda) for m in [lin0] + msg + crd + [out]]
+    lin0_d, msg_d, crd_d, out_d = mods[0], mods[1:1 + n_msg], mods[1 + n_msg:-1], mods[-1]
+    assert kernels.EdgeChainPack.supported(lin0_d, msg_d, crd_d, out_d)
+    pack = kernels.EdgeChainPack(lin0_d, msg_d, crd_d, out_d, input_size=n_in, precision=precision)
+    w = lin0_d.weight.detach()
+    proj = torch.nn.functional.linear(h.to(cuda), torch.cat([w[:, :n_in], w[:, n_in:2 * n_in]], 0)).contiguous()
+    status = torch.zeros(1, dtype=torch.int32, device=cuda)
+    coord_d, edges_d = coord.to(cuda).contiguous(), edges.to(cuda)
+    got_m, got_s = kernels.egnn_edge_chain(pack, proj, coord_d, edges_d, status=status)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    assert torch.isfinite(got_m).all() and torch.isfinite(got_s).all()
+    tol = TOLERANCE[precision]
+    err_m, err_s = _rel_l2(got_m, want_m), _rel_l2(got_s, want_s)
+    assert err_m < tol and err_s < tol, (precision, H, err_m, err_s)
+    # per-row check as well: no single edge (e.g. of the ragged last tile) may be off
+    row_err = ((got_m.double().cpu() - want_m).norm(dim=1) / want_m.norm(dim=1).clamp(min=1e-30)).max()
+    assert float(row_err) < 20 * tol, float(row_err)
+    # a device-resident edge count smaller than the capacity: rows beyond it are not touched
+    n_dev = torch.tensor([E - 5], dtype=torch.int64, device=cuda)
+    m2 = torch.full((E, H), -7.0, device=cuda)
+    s2 = torch.full((E,), -7.0, device=cuda)
+    from diffusion_for_multi_scale_molecular_dynamics_amd._hip import check, lib, ptr, stream_handle
+    import ctypes as C
+    if E > 5:
+        check(lib().mdx_egnn_edge_chain(C.byref(pack.c_struct), ptr(proj, torch.float32, "p"),
+                                        ptr(coord_d, torch.float32, "c"), D,
+                                        ptr(edges_d, torch.int64, "e"), E, ptr(n_dev, torch.int64, "n"),
+                                        ptr(m2, torch.float32, "m"), ptr(s2, torch.float32, "s"), None, stream_handle()),
+              "mdx_egnn_edge_chain")
+        torch.cuda.synchronize()
+        assert torch.equal(m2[:E - 5], got_m[:E - 5]) and torch.equal(s2[:E - 5], got_s[:E - 5])
+        assert (m2[E - 5:] == -7.0).all() and (s2[E - 5:] == -7.0).all()
+
+
+def test_edge_chain_f16_range_is_reported(cuda):
+    """Split-f16 mode: an activation beyond the f16 range sets MDX_STATUS_EGNN_F16_RANGE; binary32 mode does not care."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
+    H, n_in = 32, 4
+    torch.manual_seed(0)
+    lin0, msg, crd, out = torch.nn.Linear(2 * n_in + 1, H), [torch.nn.Linear(H, H)], [torch.nn.Linear(H, H)], \
+        torch.nn.Linear(H, 1, bias=False)
+    with torch.no_grad():
+        lin0.bias.fill_(1e5)                            # SiLU(1e5) = 1e5 > 65504
+    mods = [m.to(cuda) for m in (lin0, msg[0], crd[0], out)]
+    edges = torch.tensor([[0, 1], [1, 0]], device=cuda)
+    proj = torch.zeros(2, 2 * H, device=cuda)
+    coord = torch.rand(2, 6, device=cuda)
+    for precision, want in (("f16x3", _hip.STATUS_EGNN_F16_RANGE), ("f32", 0)):
+        pack = kernels.EdgeChainPack(mods[0], [mods[1]], [mods[2]], mods[3], input_size=n_in, precision=precision)
+        status = torch.zeros(1, dtype=torch.int32, device=cuda)
+        kernels.egnn_edge_chain(pack, proj, coord, edges, status=status)
+        assert int(status.item()) == want
+
+
+def test_coord_aggregate_against_torch(cuda):
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    g = torch.Generator().manual_seed(5)
+    n_nodes, D = 300, 6
+    degree = torch.randint(0, 30, (n_nodes,), generator=g)
+    degree[7] = 0
+    src = torch.repeat_interleave(torch.arange(n_nodes), degree)
+    E = int(src.numel())
+    dst = torch.randint(0, n_nodes, (E,), generator=g)
+    s = torch.randn(E, generator=g)
+    coord = torch.randn(n_nodes, D, generator=g)
+    offsets = torch.cumsum(degree, 0) - degree
+    for mean in (False, True):
+        want = torch.zeros(n_nodes, D, dtype=torch.float64).index_add_(
+            0, src, (coord.double()[src] - coord.double()[dst]) * s.double()[:, None])
+        if mean:
+            want = want / degree.clamp(min=1).double()[:, None]
+        want = coord.double() + want
+        got = kernels.egnn_coord_aggregate(s.to(cuda), coord.to(cuda), torch.stack([src, dst], 1).to(cuda),
+                                           offsets.to(cuda), degree.to(cuda), mean)
+        assert _rel_l2(got, want) < 1e-6
+
+
+@pytest.mark.parametrize("hidden,n_layers,n_hidden", [(32, 2, 2), (128, 3, 3), (256, 4, 4)])
+def test_egnn_forward_edge_chain_modes(cuda, hidden, n_layers, n_hidden):
+    """EGNNScoreNetwork.forward (radius graph, N = 64, two atom types) with the fused MFMA edge chain -- exact binary32
+    and split-f16 -- against the per-layer library-GEMM path and against the plain PyTorch module: scores and logits
+    within 1e-5 of the output scale; fp64 evaluation of the same module as the common yardstick."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
+                                                                              NOISY_AXL_COMPOSITION, TIME)
+    torch.manual_seed(7)
+    net = nets.egnn_net(2, "radial_cutoff", 7.5, hidden=hidden, n_layers=n_layers, n_hidden=n_hidden).to(cuda)
+    B, N = 6, 64
+    batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.randint(0, 3, (B, N), device=cuda), X=torch.rand(B, N, 3, device=cuda),
+                                        L=torch.tensor([11.084] * 3 + [0.0] * 3, device=cuda).repeat(B, 1)),
+             TIME: torch.rand(B, 1, device=cuda), NOISE: torch.rand(B, 1, device=cuda) * 0.2,
+             CARTESIAN_FORCES: torch.zeros(B, N, 3, device=cuda)}
+    outs = {}
+    for mode in ("f32", "f16x3", None, "plain"):
+        net.edge_chain_precision = None if mode == "plain" else mode
+        for layer in net.egnn.graph_layers:
+            layer.use_fused_ops = mode != "plain"
+        with torch.no_grad():
+            outs[mode] = net(batch, conditional=False)
+        net.check_status()
+    assert net.egnn.graph_layers[0]._chain[1] is not None           # the MFMA kernel really ran
+    for layer in net.egnn.graph_layers:
+        layer._chain = (None, None)                                  # (packs hold raw pointers: not deep-copyable)
+    # fp64 yardstick: the same module in double precision on the same edges
+    import copy
+    net64 = copy.deepcopy(net).double()
+    for layer in net64.egnn.graph_layers:
+        layer.use_fused_ops = False
+    batch64 = {k: (AXL(A=v.A, X=v.X.double(), L=v.L.double()) if k == NOISY_AXL_COMPOSITION else v.double())
+               for k, v in batch.items()}
+    edges, degree = net._build_edges(batch[NOISY_AXL_COMPOSITION].X, batch[NOISY_AXL_COMPOSITION].L)
+    net64.edge_builder = lambda x, cell, rc: (edges, degree)
+    with torch.no_grad():
+        want = net64(batch64, conditional=False)
+    errs = {}
+    for mode, got in outs.items():
+        errs[mode] = (_rel_l2(got.X, want.X), _rel_l2(got.A[..., :-1], want.A[..., :-1]))
+    print("EGNN forward rel-L2 vs fp64 (scores, logits):", {str(k): tuple(f"{e:.2e}" for e in v) for k, v in errs.items()})
+    for mode in ("f32", "f16x3", None, "plain"):
+        assert errs[mode][0] < 3e-5 and errs[mode][1] < 1e-5, (mode, errs[mode])
+    # the MFMA modes are as accurate as the reference arithmetic (plain PyTorch fp32), within a small factor
+    for mode in ("f32", "f16x3"):
+        assert errs[mode][0] < 4 * errs["plain"][0] + 1e-7 and errs[mode][1] < 4 * errs["plain"][1] + 1e-7, (mode, errs)
+
+
+def test_egnn_fused_path_is_off_under_autograd(cuda):
+    """With gradients enabled the module runs as plain PyTorch (the HIP calls are invisible to autograd): outputs carry a
+    grad_fn and match the no-grad fused result."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
+                                                                              NOISY_AXL_COMPOSITION, TIME)
+    torch.manual_seed(3)
+    net = nets.egnn_net(1, "radial_cutoff", 7.5, hidden=32, n_layers=2, n_hidden=1).to(cuda)
+    B, N = 2, 64
+    batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.randint(0, 2, (B, N), device=cuda), X=torch.rand(B, N, 3, device=cuda),
+                                        L=torch.tensor([10.86] * 3 + [0.0] * 3, device=cuda).repeat(B, 1)),
+             TIME: torch.rand(B, 1, device=cuda), NOISE: torch.rand(B, 1, device=cuda) * 0.2,
+             CARTESIAN_FORCES: torch.zeros(B, N, 3, device=cuda)}
+    with torch.no_grad():
+        fused = net(batch, conditional=False)
+    with_grad = net(batch, conditional=False)
+    assert with_grad.X.grad_fn is not None and fused.X.grad_fn is None
+    assert _rel_l2(with_grad.X.detach(), fused.X) < 1e-4          # same function, two fp32 evaluation orders
+    with_grad.X.sum().backward()
+    assert net.egnn.graph_layers[0].message_mlp[2].weight.grad is not None
+
+
+def test_egnn_accepts_unsorted_edges(cuda):
+    """A caller's own edge list in any order (the reference's unsorted_segment_sum accepts it): EGNN.forward sorts it by
+    source before the segment kernels; result equals the sorted call."""
+    torch.manual_seed(5)
+    net = nets.egnn_net(1, "fully_connected", None, hidden=32, n_layers=2, n_hidden=1).to(cuda)
+    n_nodes = 24
+    from diffusion_for_multi_scale_molecular_dynamics_amd.utils import neighbors
+    edges = neighbors.get_edges_batch(8, 3, device=cuda)
+    h = torch.randn(n_nodes, 3, device=cuda)
+    x = torch.randn(n_nodes, 6, device=cuda)
+    perm = torch.randperm(edges.shape[0], device=cuda)
+    with torch.no_grad():
+        a = net.egnn(h=h, edges=edges, x=x.clone())
+        b = net.egnn(h=h, edges=edges[perm], x=x.clone())
+    assert _rel_l2(b.X, a.X) < 1e-5 and _rel_l2(b.A, a.A) < 1e-5
