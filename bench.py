@@ -280,6 +280,35 @@ def time_edge_gemm(n_edges, device, hidden=256, launches=10):
                        "mdx_linear_act; 36 of these per network forward)", avg_launch_us=round(ms * 1e3, 2))
 
 
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
+
+
+def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
+    """The dominant kernel of the EGNN workloads: one launch of the hand-written fused edge chain (csrc/mdx_egnn_chain.hip)
+    of the network's first graph layer over a synthetic sorted edge list of the workload's size, HIP events on the launch
+    stream.  Algorithmic FLOPs = 2 E H^2 per H -> H layer (the per-edge MLPs); in the split-f16 mode the matrix
+    cores execute three f16 products per algorithmic one, and `achieved` counts those against the f16 peak."""
+    layer = net.egnn.graph_layers[0]
+    pack = layer._edge_chain_pack()
+    H, n_layers = pack.hidden, pack.c_struct.n_message_layers + pack.c_struct.n_coord_layers
+    deg = max(1, n_edges // n_nodes)
+    src = torch.arange(n_nodes, device=device).repeat_interleave(deg)
+    dst = (src // 64) * 64 + torch.randint(0, 64, (src.numel(),), device=device)
+    edges = torch.stack([src, dst], 1).contiguous()
+    proj = torch.randn(n_nodes, 2 * H, device=device)
+    coord = torch.rand(n_nodes, 6, device=device)
+    ms = time_launches(lambda: kernels.egnn_edge_chain(pack, proj, coord, edges), device, launches)
+    flops = 2.0 * edges.shape[0] * H * H * n_layers
+    split = pack.precision == "f16x3"
+    executed = flops * (3 if split else 1) / (ms * 1e-3) / 1e12
+    peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+    return dict(bound="mfma", achieved=round(executed, 2), peak=peak, unit="TFLOP/s", frac=round(executed / peak, 4),
+                traffic=None, kernel=f"egnn_edge_chain_kernel<{H},{1 if split else 0}> ({'split-f16: 3 x v_mfma_f32_32x32x16_f16' if split else 'v_mfma_f32_32x32x2_f32'}"
+                f" per product; {n_layers} fused H->H layers, {edges.shape[0]} edges per launch; 4 launches per network forward)",
+                avg_launch_us=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
+                algorithmic_tflops=round(flops / (ms * 1e-3) / 1e12, 2))
+
+
 def cpu_baseline(w, name, budget_s=15.0, resampling=0):
     """The CPU oracle on this host's cores over a bounded sample of the same workload."""
     import nets as test_nets
@@ -376,6 +405,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (with ranks sharing a GPU) exists to rehearse the multi-rank control "
                          "flow on a one-GPU box")
+    ap.add_argument("--egnn-precision", choices=["f32", "f16x3", "library"], default="f32",
+                    help="EGNN workloads: arithmetic of the fused per-edge MFMA kernel -- 'f32' exact binary32 MFMA, 'f16x3' "
+                         "split-f16 three-product form (binary32-level accuracy, measured in the tests), 'library' = per-layer "
+                         "hipBLASLt GEMMs (round-1 path)")
     ap.add_argument("--master-port", type=int, default=29541, help="rendezvous port when bench.py starts its own ranks")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="no GPU work: the ranks only run the job's control flow on host tensors (gloo) -- rendezvous, the "
@@ -425,6 +458,8 @@ def main():
     resampling = (args.resampling if args.resampling is not None else w.get("resampling", 0)) if "repaint" in w else 0
     gen, noise, sampling, net = build_generator(w, device, rank, batch, use_graph, resampling=resampling)
     gen.fused_score_network = forward == "fused"
+    if not mlp:
+        net.edge_chain_precision = None if args.egnn_precision == "library" else args.egnn_precision
 
     def wait_for_gpu():
         """The GPU is awaited by polling an event before the blocking synchronize: a blocking synchronize alone wakes
@@ -504,7 +539,7 @@ def main():
                                 trajectory_ms=round(generic_ms, 4),
                                 value=round((batch * world) / ((generic_ms + gather_ms) * 1e-3), 2), unit="structures/s")
 
-        roofline = forward_gemm = None
+        roofline = forward_gemm = roofline_hbm = None
         if rank == 0:
             if forward == "fused":
                 m = time_fused_kernel(gen, loop, batch, w, device)
@@ -512,7 +547,11 @@ def main():
                 m = time_update_kernel(gen, batch, w, device)
             else:
                 m = time_radius_graph(batch, w, device)
-                forward_gemm = time_edge_gemm(int(round(m["edges_per_atom"] * batch * w["n_atoms"])), device)
+                n_e = int(round(m["edges_per_atom"] * batch * w["n_atoms"]))
+                if args.egnn_precision == "library":
+                    forward_gemm = time_edge_gemm(n_e, device)
+                else:
+                    forward_gemm = time_edge_chain(net, n_e, batch * w["n_atoms"], device)
             achieved = m["bytes"] / (m["ms"] * 1e-3) / 1e9
             traffic = None          # HBM bytes per launch measured with PMC counters in a separate rocprofv3 pass
             try:
@@ -557,8 +596,11 @@ def main():
     }
     if generic_path is not None:
         result["generic_path"] = generic_path
-    if forward_gemm is not None:      # EGNN workloads: the step is library-GEMM time; the hand-written kernels are < 1 %
-        result["forward_gemm"] = forward_gemm
+    if forward_gemm is not None:
+        # EGNN workloads: the step is the per-edge MLP chain (matrix cores); the streaming kernels are < 1 % of it.  The
+        # dominant kernel's roofline is `roofline`; the largest HBM-bound kernel (radius graph, N1) is `roofline_hbm`.
+        result["roofline_hbm"], result["roofline"] = roofline, forward_gemm
+        result["config"]["egnn_edge_chain"] = args.egnn_precision
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(w, args.workload, resampling=resampling)
     print(json.dumps(result), flush=True)

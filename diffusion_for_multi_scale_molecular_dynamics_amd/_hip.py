@@ -76,7 +76,7 @@ class Mlp(C.Structure):
 class EgnnChain(C.Structure):
     """mdx_egnn_chain_t"""
     _fields_ = [(n, C.c_int32) for n in ("hidden", "n_message_layers", "n_coord_layers", "precision")] + \
-        [(n, C.c_void_p) for n in ("weight_image", "biases", "bias_in", "w_radial", "w_out")]
+        [(n, C.c_void_p) for n in ("weight_image", "biases", "bias_in", "w_radial")]
 
 
 def build(force=False):
@@ -169,7 +169,7 @@ def _declare(L):
     L.mdx_egnn_chain_image_bytes.restype = i64
     L.mdx_egnn_chain_image_bytes.argtypes = [i32, i32]
     L.mdx_egnn_chain_pack.restype = i32
-    L.mdx_egnn_chain_pack.argtypes = [C.POINTER(vp), i32, i32, i32, vp, vp]
+    L.mdx_egnn_chain_pack.argtypes = [C.POINTER(vp), i32, vp, i32, i32, vp, vp]
     L.mdx_egnn_edge_chain.restype = i32
     L.mdx_egnn_edge_chain.argtypes = [C.POINTER(EgnnChain), vp, vp, i32, vp, i64, vp, vp, vp, vp, vp]
     L.mdx_egnn_coord_aggregate.restype = i32

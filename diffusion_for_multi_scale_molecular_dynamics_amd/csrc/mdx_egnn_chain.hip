@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/mdx_hip.h"
 
 namespace {
@@ -43,15 +45,13 @@ typedef __attribute__((address_space(1))) const char gbl_c;
 constexpr int kWave = 64;
 constexpr int kWaves = 4;                 // wavefronts per workgroup = SIMDs per CU
 constexpr int kTileEdges = 32 * kWaves;   // edges per workgroup tile
-constexpr int kRing = 3;                  // LDS ring slots for weight chunks (two chunks in flight ahead of the MFMAs)
-constexpr float kF16Max = 60000.0f;
+constexpr int kRing = 4;                  // LDS ring slots for weight chunks: being read | readable next | two in flight
 
 struct ChainArgs {
     const char* image;          // [layers][H/32 chunks][chunk bytes]
     const float* biases;        // [layers][H]
     const float* bias_in;       // [H]
     const float* w_radial;      // [H]
-    const float* w_out;         // [H]
     const float* node_proj;     // [n_nodes][2H]
     const float* coord;         // [n_nodes][D]
     const int64_t* edges;       // [E][2]
@@ -63,10 +63,16 @@ struct ChainArgs {
     uint32_t* status;
 };
 
-__device__ __forceinline__ float silu_f(float y)
+constexpr float kLog2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f;
+
+// Inside the chain every activation is carried as u = log2(e) SiLU(y), computed from the pre-activation z = log2(e) y:
+//   u = z / (1 + 2^-z)      -- hardware exp2 (negation is a source modifier) and reciprocal, four instructions per value.
+// W u = log2(e) W SiLU(y), so a layer fed with u and started from log2(e) b produces the next z directly: only the biases
+// (scaled when they are staged into LDS), the first layer (scaled here) and the two outputs (messages x ln 2 when they are
+// stored; w_out x ln 2 in the packed image) know about the factor.
+__device__ __forceinline__ float silu_scaled(float z)
 {
-    // y * 1 / (1 + exp(-y)): hardware exp2 and reciprocal (~1e-7 relative); -inf / +inf / NaN behave as the formula does
-    return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.44269504088896340736f));
+    return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z));
 }
 
 // Activations of a wavefront's 32 edges in MFMA B-operand registers.
@@ -82,18 +88,32 @@ struct Act<H, 1> {
 };
 
 template <int H>
-__device__ __forceinline__ void put(Act<H, 0>& a, int t, int r, float y, float& range)
+__device__ __forceinline__ void put(Act<H, 0>& a, int t, int r, float y)
 {
     a.v[16 * t + r] = y;
 }
 template <int H>
-__device__ __forceinline__ void put(Act<H, 1>& a, int t, int r, float y, float& range)
+__device__ __forceinline__ void put(Act<H, 1>& a, int t, int r, float y)
 {
     const _Float16 hi = (_Float16)y;
     a.hi[2 * t + (r >> 3)][r & 7] = hi;
     a.lo[2 * t + (r >> 3)][r & 7] = (_Float16)(y - (float)hi);
-    range = __builtin_fmaxf(range, __builtin_fabsf(y));
 }
+
+// Timing diagnostics (never in the shipped build): -DMDX_CHAIN_STAMPS makes wavefront 0 of workgroup 0 write s_memtime at
+// marked points into the buffer passed as `status` (uint64 [4096]); tools/chain_bench.py --stamps prints the intervals.
+#ifdef MDX_CHAIN_STAMPS
+#define MDX_STAMP(id)                                                                                              \
+    do {                                                                                                           \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 4000) {                                               \
+            ((unsigned long long*)stamp_buf)[stamp_n++] = ((unsigned long long)(id) << 48) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffull); \
+        }                                                                                                          \
+    } while (0)
+__device__ void* stamp_buf;
+__device__ int stamp_n;
+#else
+#define MDX_STAMP(id)
+#endif
 
 template <int H, int PREC>
 struct Chain {
@@ -111,36 +131,111 @@ struct Chain {
     lds_c* ring;
     int wave, lane;
 
+    int rot;                // this workgroup's rotation of the 1-KB piece order (all workgroups stream the same image in the
+                            // same order at nearly the same time: without it every CU of an XCD asks its L2 for the same
+                            // lines -- the same channels -- at once)
+
     __device__ __forceinline__ void issue_chunk()
     {
-        const char* src = image + (size_t)next_issue * CHUNK + wave * (CHUNK / kWaves) + lane * 16;
-        lds_c* dst = ring + slot_issue * CHUNK + wave * (CHUNK / kWaves);
+        const char* src = image + (size_t)next_issue * CHUNK + lane * 16;
+        lds_c* dst = ring + slot_issue * CHUNK;
+        constexpr int PIECES = CHUNK / 1024;
 #pragma unroll
-        for (int i = 0; i < LPW; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_c*)(src + i * 1024), (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        for (int i = 0; i < LPW; ++i) {
+            const int piece = (wave * LPW + i + rot) & (PIECES - 1);
+            __builtin_amdgcn_global_load_lds((gbl_c*)(src + piece * 1024), (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+        }
         next_issue = next_issue + 1 == chunks_total ? 0 : next_issue + 1;
         slot_issue = slot_issue + 1 == kRing ? 0 : slot_issue + 1;
     }
 
-    // Make the next chunk readable, request the one two ahead; returns the LDS address of the readable chunk.
-    __device__ __forceinline__ lds_c* acquire_chunk()
+    // Called in the MIDDLE of a tile's MFMA stream: makes the NEXT chunk readable (so that its first fragments can be read
+    // beside the second half of the current tile's MFMAs) and requests the chunk three ahead into the slot of the chunk
+    // before the current one -- every wavefront is past that one.  Returns the LDS address of the next chunk.
+    bool stores_behind;     // the message stores of this tile were issued after the last chunk request: they are younger
+                            // than the chunk waited for next, so that wait may leave them pending too
+
+    __device__ __forceinline__ lds_c* acquire_next()
     {
-        // this wavefront's share of the chunk has landed once at most LPW younger requests (the following chunk) are pending
-        if constexpr (LPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if constexpr (LPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        // every wavefront's share has landed, and every wavefront has finished reading the slot requested below
+        // this wavefront's share of the next chunk has landed once at most LPW younger requests (the chunk after it) are
+        // pending; the barrier extends that to every wavefront's share
+        MDX_STAMP(1);
+        if (stores_behind) {
+            // H / 8 store instructions were issued behind the youngest chunk request
+            if constexpr (LPW == 8) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+            else if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else if constexpr (LPW == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            stores_behind = false;
+        } else {
+            if constexpr (LPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (LPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        }
+        MDX_STAMP(2);
+#if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 8))
+        __builtin_amdgcn_s_barrier();
+#endif
+        asm volatile("" ::: "memory");
+        MDX_STAMP(3);
+#if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 4))
+        issue_chunk();
+#endif
+        slot_read = slot_read + 1 == kRing ? 0 : slot_read + 1;
+        return ring + slot_read * CHUNK;
+    }
+
+    // Once per workgroup, before the first tile: three chunks requested, the first one readable.
+    __device__ __forceinline__ lds_c* prime()
+    {
+        issue_chunk();
+        issue_chunk();
+        issue_chunk();
+        if constexpr (LPW == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (LPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue_chunk();
-        lds_c* w = ring + slot_read * CHUNK;
-        slot_read = slot_read + 1 == kRing ? 0 : slot_read + 1;
-        return w;
+        return ring + slot_read * CHUNK;
     }
 };
 
-enum LayerKind { kHidden = 0, kLastMessage = 1, kHead = 2 };
+// The outstanding epilogue: it runs one tile late, BESIDE the next tile's MFMAs (the matrix pipe and the vector ALU issue
+// from one wavefront's stream; with one wavefront per SIMD nothing else would fill the MFMAs' issue shadow).
+// Elements [r0, r1) of the pending tile tp: u = z / (1 + 2^-z), z = the accumulator (the scaled bias is already in it: it was
+// its initial value) -> the next layer's operand registers.  A value beyond the f16 range becomes an infinity in the split
+// and a NaN one layer later, in every feature of its edge: it reaches the kernel's outputs, where it is looked for.  Branch-free, so that it is one scheduling region with the MFMAs around
+// it.  tp, r0, r1 are constants after unrolling.
+template <int H, int PREC>
+__device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const f32x16& pend, Act<H, PREC>& dst)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (r < r0 || r >= r1) continue;
+        if constexpr (PREC == 0) {
+            put<H>(dst, tp, r, silu_scaled(pend[r]));
+        } else if (!(r & 1)) {
+            // a pair of elements: hi = f16(y) (packed convert), lo = f16(y - hi) with the subtraction straight off the
+            // packed halves (v_fma_mix_f32: f16 operand x -1 + f32 operand, exact)
+            const float y0 = silu_scaled(pend[r]), y1 = silu_scaled(pend[r + 1]);
+            uint32_t hi, lo;
+            float l0, l1;
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(y0), "v"(y1));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(y0));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(y1));
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(l0), "v"(l1));
+            const int s = 2 * tp + (r >> 3), j = (r & 7) >> 1;
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 vh = __builtin_bit_cast(u32x4, dst.hi[s]), vl = __builtin_bit_cast(u32x4, dst.lo[s]);
+            vh[j] = hi;
+            vl[j] = lo;
+            dst.hi[s] = __builtin_bit_cast(half8, vh);
+            dst.lo[s] = __builtin_bit_cast(half8, vl);
+        }
+    }
+}
 
 template <int H, int PREC>
 __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(ChainArgs p)
@@ -148,36 +243,71 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     using C = Chain<H, PREC>;
     constexpr int NT = C::NT;
+    constexpr int STEPS = PREC == 0 ? H / 8 : H / 16;        // k-steps of a tile: 4 f32 MFMAs | 3 f16 MFMAs each
+    constexpr int PFD = STEPS >= 4 ? 2 : 1;                   // weight fragments are read from LDS this many steps ahead
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
     const int h = lane >> 5, col = lane & 31;
     const int layers = p.n_message + p.n_coord;
 
     lds_c* ring = (lds_c*)lds_raw;
-    lds_f* par = (lds_f*)(lds_raw + kRing * C::CHUNK);      // [layers][H] biases | bias_in | w_radial | w_out
+    lds_f* par = (lds_f*)(lds_raw + kRing * C::CHUNK);      // [layers][H] biases | bias_in | w_radial
     lds_f* par_in = par + layers * H;
     lds_f* par_wr = par_in + H;
-    lds_f* par_wo = par_wr + H;
 
     const int64_t n_edges = p.n_edges_dev ? (*p.n_edges_dev < p.n_edges ? *p.n_edges_dev : p.n_edges) : p.n_edges;
     const int64_t n_tiles = (n_edges + kTileEdges - 1) / kTileEdges;
     if ((int64_t)blockIdx.x >= n_tiles) return;             // uniform per workgroup
 
-    for (int i = threadIdx.x; i < layers * H; i += kWaves * kWave) par[i] = p.biases[i];
+    for (int i = threadIdx.x; i < layers * H; i += kWaves * kWave) par[i] = p.biases[i] * kLog2e;
     for (int i = threadIdx.x; i < H; i += kWaves * kWave) {
         par_in[i] = p.bias_in[i];
         par_wr[i] = p.w_radial[i];
-        par_wo[i] = p.w_out[i];
     }
     __syncthreads();
 
     C ch;
-    ch.image = p.image; ch.chunks_total = layers * NT; ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
+    ch.image = p.image; ch.chunks_total = layers * NT + 1; ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
     ch.ring = ring; ch.wave = wave; ch.lane = lane;
-    ch.issue_chunk();
-    ch.issue_chunk();
+    ch.stores_behind = false;
+    ch.rot = (int)((blockIdx.x * 5u) & (unsigned)(C::CHUNK / 1024 - 1));
 
-    float range = 0.0f;
+    // Weight fragments of a k-step, and the state that flows from one tile to the next: the LDS address of the tile's
+    // chunk, its first PFD fragments and its initial accumulator (= the bias), all read beside the previous tile's MFMAs.
+    struct Frag {
+        f32x4 f;
+        half8 hi, lo;
+    };
+    auto read_frag = [&](const lds_c* w, int s) -> Frag {
+        Frag r;
+        if constexpr (PREC == 0) {
+            r.f = *(const __attribute__((address_space(3))) f32x4*)(w + s * 1024 + lane * 16);
+        } else {
+            r.hi = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + lane * 16);
+            r.lo = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + 1024 + lane * 16);
+        }
+        return r;
+    };
+    auto read_bias = [&](const lds_f* bias_row) -> f32x16 {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (bias_row) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *(const __attribute__((address_space(3))) f32x4*)(bias_row + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[4 * g + i] = b4[i];
+            }
+        }
+        return acc;
+    };
+    const lds_c* w_cur = ch.prime();
+    Frag pre[PFD];
+#pragma unroll
+    for (int s = 0; s < PFD; ++s) pre[s] = read_frag(w_cur, s);
+    f32x16 acc_next = read_bias(par);
+
+    bool out_of_range = false;       // split-f16: a non-finite output (see epilogue_elements)
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        MDX_STAMP(9);
         // ---- this lane's edge ------------------------------------------------------------------------------------
         const int64_t e_raw = tile * kTileEdges + wave * 32 + col;
         const bool live = e_raw < n_edges;
@@ -195,85 +325,142 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             const float* pd = p.node_proj + dst * 2 * H + H + 4 * h;
 #pragma unroll
             for (int q = 0; q < H / 8; ++q) {               // features 8 q + 4 h + (0..3)
+#if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 2)
+                const f32x4 a = {radial, 1.0f, 2.0f, radial}, b = {0.5f, radial, 0.25f, 1.0f};
+#else
                 const f32x4 a = *(const f32x4*)(ps + 8 * q), b = *(const f32x4*)(pd + 8 * q);
+#endif
                 const f32x4 b0 = *(const __attribute__((address_space(3))) f32x4*)(par_in + 8 * q + 4 * h);
                 const f32x4 wr = *(const __attribute__((address_space(3))) f32x4*)(par_wr + 8 * q + 4 * h);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float y = silu_f(((a[i] + b[i]) + b0[i]) + radial * wr[i]);
-                    put<H>(xa, q >> 2, 4 * (q & 3) + i, y, range);
+                    const float y = silu_scaled((((a[i] + b[i]) + b0[i]) + radial * wr[i]) * kLog2e);
+                    put<H>(xa, q >> 2, 4 * (q & 3) + i, y);
                 }
+                // half of the two gathers in flight at a time (the other operand set and the accumulators are free here):
+                // hoisting all of them costs 256 registers
+                if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        MDX_STAMP(10);
         // ---- the chain ----------------------------------------------------------------------------------------------
-        float head = 0.0f;
-        auto layer = [&](const Act<H, PREC>& in, Act<H, PREC>& out, int l, int kind) {
+        f32x16 pend;                                          // accumulators whose epilogue is outstanding
+
+        // One tile: the MFMAs of (layer, t) from operand registers `in`; beside them (a) the outstanding epilogue, which
+        // writes tile `tp` of `epi_dst`, (b) from the middle on, the reads of the NEXT tile's first fragments and bias
+        // (next_bias == nullptr: that tile starts from zero -- the head).
+        auto run_tile = [&](const Act<H, PREC>& in, bool have, int tp, Act<H, PREC>& epi_dst, const lds_f* next_bias) -> f32x16 {
+            MDX_STAMP(4);
+            f32x16 acc = acc_next;
+            Frag fr[STEPS + PFD];
+#pragma unroll
+            for (int s = 0; s < PFD; ++s) fr[s] = pre[s];
+            const lds_c* w_next = nullptr;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                if (s == STEPS / 2) w_next = ch.acquire_next();
+                if (s + PFD < STEPS) fr[s + PFD] = read_frag(w_cur, s + PFD);
+                else fr[s + PFD] = read_frag(w_next, s + PFD - STEPS);
+                if (s == STEPS - 1) acc_next = read_bias(next_bias);
+                if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst);
+                if constexpr (PREC == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s].f[i], in.v[4 * s + i], acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].hi, in.hi[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].hi, in.lo[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].lo, in.hi[s], acc, 0, 0, 0);
+                }
+#ifdef MDX_CHAIN_PIN_STEPS
+                __builtin_amdgcn_sched_barrier(0);      // keep each k-step's share of vector work beside ITS MFMAs
+#endif
+            }
+#pragma unroll
+            for (int s = 0; s < PFD; ++s) pre[s] = fr[STEPS + s];
+            w_cur = w_next;
+            return acc;
+        };
+        // One layer: tiles t = 0 .. NT-1.  The epilogue beside tile t is that of the tile before it: tile t-1 of this layer
+        // (-> out), or, at t = 0, the last tile of the previous layer (-> in: its features are the last k-steps of this
+        // layer, produced before the MFMAs that read them).  FIRST: nothing is outstanding at t = 0.
+        auto layer = [&](auto first_tag, Act<H, PREC>& in, Act<H, PREC>& out, int l) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             const lds_f* bias = par + l * H;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const lds_c* w = ch.acquire_chunk();
-                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                if constexpr (PREC == 0) {
-#pragma unroll
-                    for (int q = 0; q < H / 8; ++q) {
-                        const f32x4 w4 = *(const __attribute__((address_space(3))) f32x4*)(w + q * 1024 + lane * 16);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i], in.v[4 * q + i], acc, 0, 0, 0);
-                    }
-                } else {
-                    f32x16 cor = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int s = 0; s < H / 16; ++s) {
-                        const half8 whi = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + lane * 16);
-                        const half8 wlo = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + 1024 + lane * 16);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, in.hi[s], acc, 0, 0, 0);
-                        cor = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, in.lo[s], cor, 0, 0, 0);
-                        cor = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, in.hi[s], cor, 0, 0, 0);
-                    }
-                    acc += cor;
-                }
-                // epilogue of the tile: rows 32 t + 8 g + 4 h + (0..3), g = 0..3
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 b4 = *(const __attribute__((address_space(3))) f32x4*)(bias + 32 * t + 8 * g + 4 * h);
-                    f32x4 y;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] = silu_f(acc[4 * g + i] + b4[i]);
-                    if (kind == kHead) {
-                        const f32x4 wo = *(const __attribute__((address_space(3))) f32x4*)(par_wo + 32 * t + 8 * g + 4 * h);
-                        head += (y[0] * wo[0] + y[1] * wo[1]) + (y[2] * wo[2] + y[3] * wo[3]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) put<H>(out, t, 4 * g + i, y[i], range);
-                        if (kind == kLastMessage && live)
-                            *(f32x4*)(p.messages + e * H + 32 * t + 8 * g + 4 * h) = y;
-                    }
-                }
+                // the tile after this one: the next tile of this layer, the first of the next layer, or the head (no bias)
+                const lds_f* next_bias = t + 1 < NT ? bias + 32 * (t + 1) : (l + 1 < layers ? bias + H : nullptr);
+                if (t == 0) pend = run_tile(in, !FIRST, NT - 1, in, next_bias);
+                else pend = run_tile(in, true, t - 1, out, next_bias);
             }
         };
-        // layers alternate between the two register sets; `kind` is wave-uniform
-        int l = 0;
-        while (l < layers) {
-            layer(xa, xb, l, l == p.n_message - 1 ? kLastMessage : (l == layers - 1 ? kHead : kHidden));
-            ++l;
-            if (l >= layers) break;
-            layer(xb, xa, l, l == p.n_message - 1 ? kLastMessage : (l == layers - 1 ? kHead : kHidden));
-            ++l;
+        // messages = the operand registers of the first coordinate layer, complete once its first tile has run
+        auto store_messages = [&](const Act<H, PREC>& m) {
+#if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 1)
+            if (e_raw >= 0) return;
+#endif
+            // every wavefront issues exactly H / 8 store instructions (lanes beyond the edge count masked off, the address
+            // clamped): the next chunk wait counts on them (Chain::stores_behind)
+            float* row = p.messages + e * H + 4 * h;
+            if (live) {
+#pragma unroll
+            for (int q = 0; q < H / 8; ++q) {
+                f32x4 y;
+                const int t = q >> 2, r0 = 4 * (q & 3);
+                if constexpr (PREC == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = m.v[16 * t + r0 + i] * kLn2;
+                } else {
+                    // hi + lo in one instruction per value: v_fma_mix_f32 with both addends taken from the packed halves
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 vh = __builtin_bit_cast(u32x4, m.hi[2 * t + (r0 >> 3)]), vl = __builtin_bit_cast(u32x4, m.lo[2 * t + (r0 >> 3)]);
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const uint32_t ph = vh[((r0 & 7) >> 1) + pr], pl = vl[((r0 & 7) >> 1) + pr];
+                        float y0, y1;
+                        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(ph), "v"(pl));
+                        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(y1) : "v"(ph), "v"(pl));
+                        y[2 * pr] = y0 * kLn2;
+                        y[2 * pr + 1] = y1 * kLn2;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) out_of_range = out_of_range || !(__builtin_fabsf(y[i]) <= 3.0e38f);
+                }
+                *(f32x4*)(row + 8 * q) = y;
+            }
+            }
+            ch.stores_behind = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(live) != 0);
+        };
+        // the head: one more tile whose image row 0 is w_out (no bias, no activation): s_e = row 0 of the accumulator
+        auto head_tile = [&](Act<H, PREC>& in) {
+            Act<H, PREC> unused;
+            const f32x16 acc = run_tile(in, true, NT - 1, in, par);      // after the head: layer 0, tile 0 of the next edges
+            (void)unused;
+            if constexpr (PREC == 1) out_of_range = out_of_range || (live && !(__builtin_fabsf(acc[0]) <= 3.0e38f));
+            if (live && h == 0) p.edge_scalar[e] = acc[0];
+        };
+        layer(std::true_type{}, xa, xb, 0);
+        for (int l = 1;;) {
+            layer(std::false_type{}, xb, xa, l);
+            if (l == p.n_message) store_messages(xb);
+            if (++l >= layers) { head_tile(xa); break; }
+            layer(std::false_type{}, xa, xb, l);
+            if (l == p.n_message) store_messages(xa);
+            if (++l >= layers) { head_tile(xb); break; }
         }
-        head += __shfl_xor(head, 32, kWave);
-        if (live && h == 0) p.edge_scalar[e] = head;
     }
     // requests still in flight target this workgroup's LDS: let them land before the workgroup ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (PREC == 1) {
-        if (p.status && !(range <= kF16Max)) atomicOr(p.status, MDX_STATUS_EGNN_F16_RANGE);
+        if (p.status && out_of_range) atomicOr(p.status, MDX_STATUS_EGNN_F16_RANGE);
     }
 }
 
 // ---- weight image ------------------------------------------------------------------------------------------------
 struct PackArgs {
     const float* w[MDX_EGNN_CHAIN_MAX_LAYERS];      // [H][H] nn.Linear weights (out, in), device
+    const float* w_out;                             // [H] the coordinate head: row 0 of one more 32-row chunk (rest zero)
     int layers, H, precision;
     void* image;
 };
@@ -282,23 +469,28 @@ __global__ __launch_bounds__(256) void egnn_chain_pack_kernel(PackArgs p)
 {
     const int H = p.H, NT = H / 32;
     const int64_t per_layer = (int64_t)H * H;
-    const int64_t total = per_layer * p.layers;
+    const int64_t total = per_layer * p.layers + 32 * H;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int l = (int)(idx / per_layer);
+        const int l = (int)(idx / per_layer);               // == p.layers: the head chunk
         int64_t r = idx - l * per_layer;
         const int t = (int)(r / (32 * H));                  // chunk = accumulator tile
         r -= (int64_t)t * 32 * H;
         (void)NT;
+        const bool head = l == p.layers;
+        auto weight = [&](int n, int k) -> float {
+            if (head) return n == 0 ? p.w_out[k] * kLn2 : 0.0f;       // the chain carries log2(e) x activation
+            return p.w[l][(int64_t)n * H + k];
+        };
         if (p.precision == 0) {
             // chunk: [q = H/8][lane 64][4 floats]; lane (n = 32 t + (lane & 31), h = lane >> 5) holds W[n][8 q + 4 h + i]
             const int q = (int)(r / 256), lane = (int)(r % 256) / 4, i = (int)(r % 4);
             const int n = 32 * t + (lane & 31), k = 8 * q + 4 * (lane >> 5) + i;
-            ((float*)p.image)[idx] = p.w[l][(int64_t)n * H + k];
+            ((float*)p.image)[idx] = weight(n, k);
         } else {
             // chunk: [s = H/16][hi: lane 64 x 8 halfs | lo: lane 64 x 8 halfs]; element j: k = 16 s + 8 (j >> 2) + 4 h + (j & 3)
             const int s = (int)(r / 512), lane = (int)(r % 512) / 8, j = (int)(r % 8);
             const int n = 32 * t + (lane & 31), k = 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-            const float v = p.w[l][(int64_t)n * H + k];
+            const float v = weight(n, k);
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)(v - (float)hi);
             _Float16* chunk = (_Float16*)((char*)p.image + ((int64_t)l * (H / 32) + t) * ((int64_t)H * 32 * 4));
@@ -332,7 +524,7 @@ template <int H, int PREC>
 int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
 {
     using C = Chain<H, PREC>;
-    const size_t lds = (size_t)kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 3 * H);
+    const size_t lds = (size_t)kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H);
     static bool granted[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MDX_ERR_HIP;
@@ -358,13 +550,14 @@ extern "C" {
 int64_t mdx_egnn_chain_image_bytes(int hidden, int n_layers)
 {
     if (hidden < 32 || (hidden % 32) || n_layers < 1) return -1;
-    return (int64_t)n_layers * hidden * hidden * 4;
+    return ((int64_t)n_layers * hidden * hidden + 32 * hidden) * 4;      // the layers + the head's 32-row chunk
 }
 
-int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, int hidden, int precision, void* image_out,
-                        mdx_stream_t stream)
+int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, const float* w_out, int hidden, int precision,
+                        void* image_out, mdx_stream_t stream)
 {
-    if (!weights_host || !image_out || n_layers < 1 || (precision != 0 && precision != 1)) return MDX_ERR_INVALID_ARG;
+    if (!weights_host || !w_out || !image_out || n_layers < 1 || (precision != 0 && precision != 1))
+        return MDX_ERR_INVALID_ARG;
     if (n_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     if (hidden != 32 && hidden != 64 && hidden != 128 && hidden != 256) return MDX_ERR_UNSUPPORTED;
     PackArgs a{};
@@ -372,8 +565,9 @@ int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, int hidd
         if (!weights_host[l]) return MDX_ERR_INVALID_ARG;
         a.w[l] = weights_host[l];
     }
+    a.w_out = w_out;
     a.layers = n_layers; a.H = hidden; a.precision = precision; a.image = image_out;
-    const int64_t total = (int64_t)n_layers * hidden * hidden;
+    const int64_t total = (int64_t)n_layers * hidden * hidden + 32 * hidden;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(egnn_chain_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
@@ -390,14 +584,22 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
     if (c->n_message_layers + c->n_coord_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     if (c->hidden != 32 && c->hidden != 64 && c->hidden != 128 && c->hidden != 256) return MDX_ERR_UNSUPPORTED;
     if (n_edges == 0) return MDX_OK;
-    if (!c->weight_image || !c->biases || !c->bias_in || !c->w_radial || !c->w_out || !node_proj || !coord || !edges ||
+    if (!c->weight_image || !c->biases || !c->bias_in || !c->w_radial || !node_proj || !coord || !edges ||
         !messages_out || !edge_scalar_out)
         return MDX_ERR_INVALID_ARG;
     ChainArgs a{};
     a.image = (const char*)c->weight_image; a.biases = c->biases; a.bias_in = c->bias_in; a.w_radial = c->w_radial;
-    a.w_out = c->w_out; a.node_proj = node_proj; a.coord = coord; a.edges = edges; a.n_edges_dev = n_edges_dev;
+    a.node_proj = node_proj; a.coord = coord; a.edges = edges; a.n_edges_dev = n_edges_dev;
     a.n_edges = n_edges; a.n_message = c->n_message_layers; a.n_coord = c->n_coord_layers; a.D = coord_dimension;
     a.messages = messages_out; a.edge_scalar = edge_scalar_out; a.status = status;
+#ifdef MDX_CHAIN_STAMPS
+    {
+        int zero = 0;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(stamp_buf), &status, sizeof(void*), 0, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream));
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(stamp_n), &zero, sizeof(int), 0, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream));
+        a.status = nullptr;
+    }
+#endif
     const int layers = a.n_message + a.n_coord;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define MDX_CHAIN_CASE(HH)                                                                         \

@@ -533,16 +533,17 @@ class EdgeChainPack:
         n_bytes = lib().mdx_egnn_chain_image_bytes(H, len(layers))
         self.image = torch.empty(n_bytes, dtype=torch.uint8, device=dev)
         array = (C.c_void_p * len(layers))(*[w.data_ptr() for w in self._keep])
+        self.w_out = coord_out_layer.weight.detach().reshape(-1).to(F32).contiguous()
         with torch.cuda.device(dev):
-            check(lib().mdx_egnn_chain_pack(array, len(layers), H, EDGE_CHAIN_PRECISIONS[precision],
-                                            C.c_void_p(self.image.data_ptr()), stream_handle()), "mdx_egnn_chain_pack")
+            check(lib().mdx_egnn_chain_pack(array, len(layers), C.c_void_p(self.w_out.data_ptr()), H,
+                                            EDGE_CHAIN_PRECISIONS[precision], C.c_void_p(self.image.data_ptr()),
+                                            stream_handle()), "mdx_egnn_chain_pack")
         self.biases = torch.stack([layer.bias.detach().to(F32) for layer in layers]).contiguous()
         self.bias_in = first_message_layer.bias.detach().to(F32).contiguous()
         self.w_radial = first_message_layer.weight.detach()[:, 2 * input_size].to(F32).contiguous()
-        self.w_out = coord_out_layer.weight.detach().reshape(-1).to(F32).contiguous()
         self.c_struct = _hip.EgnnChain(H, len(list(message_layers)), len(list(coord_layers)),
                                        EDGE_CHAIN_PRECISIONS[precision], self.image.data_ptr(), self.biases.data_ptr(),
-                                       self.bias_in.data_ptr(), self.w_radial.data_ptr(), self.w_out.data_ptr())
+                                       self.bias_in.data_ptr(), self.w_radial.data_ptr())
         self._keep = []                    # the image holds its own copy of the matrices
         self.device = dev
 

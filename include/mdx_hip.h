@@ -340,8 +340,10 @@ MDX_API int mdx_segment_rows(const float* data, const int64_t* offsets, const in
  * precision 0: v_mfma_f32_32x32x2_f32, exact binary32 (== fmaf chains in a fixed order).
  * precision 1: split-f16, three v_mfma_f32_32x32x16_f16 per product (hi.hi + hi.lo + lo.hi), binary32 accumulation:
  *              ~2^-22 relative per product; sets MDX_STATUS_EGNN_F16_RANGE when an activation exceeds 6e4 in magnitude.
- * weight_image: the n_message_layers + n_coord_layers matrices [H,H] (nn.Linear layout) re-laid out by
- * mdx_egnn_chain_pack for the chosen precision (mdx_egnn_chain_image_bytes bytes, caller-owned, 16-byte aligned).
+ * weight_image: the n_message_layers + n_coord_layers matrices [H,H] (nn.Linear layout; weights_host = host array of
+ * device pointers) and the head's weight w_out [H], re-laid out by mdx_egnn_chain_pack for the chosen precision
+ * (mdx_egnn_chain_image_bytes bytes, caller-owned, 16-byte aligned); the head rides the same pipeline as one more
+ * 32-row chunk whose row 0 is w_out.
  * n_edges: number of edge rows to process = capacity of the outputs; n_edges_dev (nullable): device word with the actual
  * count (<= n_edges), for callers that size the edge list without reading it back. */
 #define MDX_EGNN_CHAIN_MAX_LAYERS 16
@@ -351,11 +353,10 @@ typedef struct mdx_egnn_chain {
     const float* biases;       /* [n_message_layers + n_coord_layers, H] */
     const float* bias_in;      /* [H]  bias of the first message layer                       */
     const float* w_radial;     /* [H]  its weight column for the squared distance            */
-    const float* w_out;        /* [H]  weight of the last coordinate layer                   */
 } mdx_egnn_chain_t;
 MDX_API int64_t mdx_egnn_chain_image_bytes(int hidden, int n_layers);
-MDX_API int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, int hidden, int precision, void* image_out,
-                                mdx_stream_t stream);
+MDX_API int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, const float* w_out, int hidden,
+                                int precision, void* image_out, mdx_stream_t stream);
 MDX_API int mdx_egnn_edge_chain(const mdx_egnn_chain_t* chain_host, const float* node_proj, const float* coord,
                                 int coord_dimension, const int64_t* edges, int64_t n_edges, const int64_t* n_edges_dev,
                                 float* messages_out, float* edge_scalar_out, uint32_t* status, mdx_stream_t stream);

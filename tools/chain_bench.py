@@ -18,10 +18,18 @@ ap.add_argument("--degree", type=int, default=25)
 ap.add_argument("--hidden", type=int, default=256)
 ap.add_argument("--launches", type=int, default=5)
 ap.add_argument("--modes", default="f32,f16x3,library")
+ap.add_argument("--n-msg", type=int, default=4)
+ap.add_argument("--n-crd", type=int, default=5)
+ap.add_argument("--eager", action="store_true", help="time eager launches with HIP events (no hipGraph: safe under rocprofv3 --pmc)")
+ap.add_argument("--stamps", action="store_true", help="with a -DMDX_CHAIN_STAMPS build: print the stamped intervals")
+ap.add_argument("--lib", default=None, help="alternative libmdx_hip.so (ablation builds)")
 args = ap.parse_args()
+if args.lib:
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip
+    _hip.LIB_PATH = os.path.abspath(args.lib)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-H, n_in, n_msg, n_crd = args.hidden, args.hidden, 4, 5
+H, n_in, n_msg, n_crd = args.hidden, args.hidden, args.n_msg, args.n_crd
 n_nodes, E = args.nodes, args.nodes * args.degree
 lin0 = torch.nn.Linear(2 * n_in + 1, H).to(dev)
 msg = [torch.nn.Linear(H, H).to(dev) for _ in range(n_msg)]
@@ -49,8 +57,42 @@ with torch.no_grad():
         else:
             pack = kernels.EdgeChainPack(lin0, msg, crd, out, input_size=n_in, precision=mode)
 
+            stamps = torch.zeros(8192, dtype=torch.int32, device=dev) if args.stamps else None
+
             def launch(pack=pack):
-                return kernels.egnn_edge_chain(pack, proj, coord, edges)
-        ms = bench.time_launches(launch, dev, args.launches)
+                return kernels.egnn_edge_chain(pack, proj, coord, edges, status=stamps)
+            if args.stamps:
+                launch(); launch()
+                torch.cuda.synchronize()
+                raw = stamps.view(torch.int64).cpu().numpy()
+                ids, t = raw >> 48, raw & ((1 << 48) - 1)
+                keep = ids > 0
+                ids, t = ids[keep], t[keep]
+                import collections
+                print("first 60 stamps (id, delta to previous in cycles of s_memtime):")
+                print([(int(i), int(t[k] - t[k - 1]) if k else 0) for k, i in enumerate(ids[:60])])
+                seq = [(int(ids[k - 1]), int(ids[k]), int(t[k] - t[k - 1])) for k in range(1, len(ids))]
+                print("(3->4) second-half-of-tile series:", [d_ for a, b, d_ in seq if (a, b) == (3, 4)][:160])
+                print("(4->1) first-half series:", [d_ for a, b, d_ in seq if (a, b) == (4, 1)][:160])
+                # steady state: per stamp-id transition statistics
+                d = collections.defaultdict(list)
+                for k in range(1, len(ids)):
+                    d[(int(ids[k - 1]), int(ids[k]))].append(int(t[k] - t[k - 1]))
+                for key, v in sorted(d.items()):
+                    v = sorted(v)
+                    print(key, "n", len(v), "median", v[len(v) // 2], "mean", sum(v) / len(v), "max", v[-1])
+                continue
+        if args.eager:
+            launch()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.launches):
+                launch()
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / args.launches
+        else:
+            ms = bench.time_launches(launch, dev, args.launches)
         res[mode] = {"ms": round(ms, 4), "algorithmic_tflops": round(flops / ms / 1e9, 2)}
 print(json.dumps(res))
