@@ -1527,7 +1527,8 @@ __global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __res
                                                               float rc, int64_t B, int N, int unique, int chunks,
                                                               int64_t* __restrict__ counts, const int64_t* __restrict__ offsets,
                                                               int64_t* __restrict__ edges, int32_t* __restrict__ image_out,
-                                                              float* __restrict__ shifts_out, uint32_t* status)
+                                                              float* __restrict__ shifts_out, uint32_t* status,
+                                                              int64_t capacity)
 {
     extern __shared__ float lds[];
     float* pos = lds;            // [N][3]
@@ -1612,10 +1613,10 @@ __global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __res
                     longlong2 pair;
                     pair.x = row;
                     pair.y = row - i + j;
-                    reinterpret_cast<longlong2*>(edges)[e] = pair;      // one 16-B store per edge
+                    if (e < capacity) reinterpret_cast<longlong2*>(edges)[e] = pair;      // one 16-B store per edge
                 } else {
                     uint32_t m = mask;
-                    while (m) {
+                    while (m && e < capacity) {
                         const int l = __ffs(m) - 1;
                         m &= m - 1;
                         longlong2 pair;
@@ -1635,6 +1636,8 @@ __global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __res
             running += total;
         }
         if (!FILL && lane == 0) counts[row] = running;
+        // a caller-sized edge list that is too small: nothing is written beyond it, and the caller is told
+        if (FILL && lane == 0 && status && base + running > capacity) atomicOr(status, MDX_STATUS_GRAPH_CAPACITY);
     }
 }
 
@@ -1965,7 +1968,24 @@ int mdx_radius_graph_count(const float* cart, const float* cell, float rc, int64
     const size_t lds = sizeof(float) * (3 * (size_t)N + 81);
     hipLaunchKernelGGL(radius_graph_kernel<false>, dim3((unsigned)(batch * chunks)), dim3(kBlock), lds, as_stream(stream),
                        cart, cell, rc, batch, N, unique, chunks, counts, (const int64_t*)nullptr, (int64_t*)nullptr,
-                       (int32_t*)nullptr, (float*)nullptr, status);
+                       (int32_t*)nullptr, (float*)nullptr, status, (int64_t)0);
+    return launch_status();
+}
+
+int mdx_radius_graph_fill_capped(const float* cart, const float* cell, float rc, int64_t batch, int N, int unique,
+                                 const int64_t* offsets, int64_t capacity, int64_t* edges_out, int32_t* image_out,
+                                 float* shifts_out, uint32_t* status, mdx_stream_t stream)
+{
+    const int ok = radius_graph_args_ok(cart, cell, rc, batch, N);
+    if (ok != MDX_OK) return ok;
+    if (capacity < 0) return MDX_ERR_INVALID_ARG;
+    if (batch == 0) return MDX_OK;
+    if (!offsets || (capacity > 0 && !edges_out) || (!unique && capacity > 0 && !image_out)) return MDX_ERR_INVALID_ARG;
+    const int chunks = (int)cdiv(N, kRowsPerBlock);
+    const size_t lds = sizeof(float) * (3 * (size_t)N + 81);
+    hipLaunchKernelGGL(radius_graph_kernel<true>, dim3((unsigned)(batch * chunks)), dim3(kBlock), lds, as_stream(stream),
+                       cart, cell, rc, batch, N, unique, chunks, (int64_t*)nullptr, offsets, edges_out, image_out,
+                       shifts_out, status, capacity);
     return launch_status();
 }
 
@@ -1973,16 +1993,8 @@ int mdx_radius_graph_fill(const float* cart, const float* cell, float rc, int64_
                           const int64_t* offsets, int64_t* edges_out, int32_t* image_out, float* shifts_out,
                           mdx_stream_t stream)
 {
-    const int ok = radius_graph_args_ok(cart, cell, rc, batch, N);
-    if (ok != MDX_OK) return ok;
-    if (batch == 0) return MDX_OK;
-    if (!offsets || !edges_out || (!unique && !image_out)) return MDX_ERR_INVALID_ARG;
-    const int chunks = (int)cdiv(N, kRowsPerBlock);
-    const size_t lds = sizeof(float) * (3 * (size_t)N + 81);
-    hipLaunchKernelGGL(radius_graph_kernel<true>, dim3((unsigned)(batch * chunks)), dim3(kBlock), lds, as_stream(stream),
-                       cart, cell, rc, batch, N, unique, chunks, (int64_t*)nullptr, offsets, edges_out, image_out,
-                       shifts_out, (uint32_t*)nullptr);
-    return launch_status();
+    return mdx_radius_graph_fill_capped(cart, cell, rc, batch, N, unique, offsets, INT64_MAX, edges_out, image_out, shifts_out,
+                                        nullptr, stream);
 }
 
 static int mlp_ok(const mdx_mlp_t* m)

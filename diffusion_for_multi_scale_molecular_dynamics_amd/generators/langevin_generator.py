@@ -15,7 +15,6 @@ Same class name, constructor, step methods and behaviour as the reference's Lang
 There is no CPU fallback: calling this generator with device="cpu" raises.
 """
 import dataclasses
-import gc
 from typing import Optional
 
 import torch
@@ -419,17 +418,17 @@ class IterationLoop:
             comp.L.copy_(saved.L)
             gen._status.zero_()
             self.graph = torch.cuda.CUDAGraph()
-            # no Python garbage collection while the stream is capturing: a collected object that owns device
-            # resources (an older generator's graph, a library handle) would call into HIP in the middle of the
-            # capture and abort the process
-            gc_was_enabled = gc.isenabled()
-            gc.disable()
-            try:
-                with torch.cuda.graph(self.graph):
-                    gen._iteration_on_device_index(comp, self.forces, self.d_index)
-            finally:
-                if gc_was_enabled:
-                    gc.enable()
+            # Objects whose finaliser calls HIP must not be collected while the stream is capturing: an older loop's
+            # torch.cuda.CUDAGraph (hipGraphExecDestroy) and kernels.BlasContext (hipblasLtDestroy).  The first kind is
+            # released deterministically here, before the capture starts (the previous loop of this generator is dropped
+            # and torch.cuda.graph() itself runs gc.collect() on entry); the second lives for the whole process in
+            # BlasContext._by_device and refuses to destroy its handle during a capture.
+            previous = gen._buffers.pop("graph_loop", None)
+            if previous is not None:
+                previous.graph = None
+            del previous
+            with torch.cuda.graph(self.graph):
+                gen._iteration_on_device_index(comp, self.forces, self.d_index)
         kernels.index_set(self.d_index, starting_step_index - 1)
 
     def advance(self, iterations: int):

@@ -224,6 +224,30 @@ def radius_graph(cartesian_positions, basis_vectors, radial_cutoff: float, uniqu
     return dict(counts=counts, edges=edges, image=image, shifts=shifts)
 
 
+def radius_graph_static(cartesian_positions, basis_vectors, radial_cutoff: float, capacity: int,
+                        status: Optional[torch.Tensor] = None):
+    """Unique-pair radius graph into a caller-sized edge list, with NO host synchronisation (capturable into a hipGraph):
+    returns dict(counts [B*N], offsets [B*N], edges [capacity, 2], n_edges int64 [1] on the device).  Rows beyond
+    n_edges are uninitialised; more than `capacity` edges sets STATUS_GRAPH_CAPACITY in `status`."""
+    B, N, d = cartesian_positions.shape
+    assert d == 3 and basis_vectors.shape == (B, 3, 3)
+    dev = cartesian_positions.device
+    counts = torch.empty(B * N, dtype=I64, device=dev)
+    L = lib()
+    check(L.mdx_radius_graph_count(ptr(cartesian_positions, F32, "cartesian_positions"),
+                                   ptr(basis_vectors, F32, "basis_vectors"), float(radial_cutoff), B, N, 1,
+                                   ptr(counts, I64, "counts"), ptr(status, I32, "status"), stream_handle()),
+          "mdx_radius_graph_count")
+    inclusive = torch.cumsum(counts, 0)
+    offsets = inclusive - counts
+    edges = torch.empty(int(capacity), 2, dtype=I64, device=dev)
+    check(L.mdx_radius_graph_fill_capped(ptr(cartesian_positions, F32, "cartesian_positions"),
+                                         ptr(basis_vectors, F32, "basis_vectors"), float(radial_cutoff), B, N, 1,
+                                         ptr(offsets, I64, "offsets"), int(capacity), ptr(edges, I64, "edges"), None, None,
+                                         ptr(status, I32, "status"), stream_handle()), "mdx_radius_graph_fill_capped")
+    return dict(counts=counts, offsets=offsets, edges=edges, n_edges=inclusive[-1:])
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # fused MLP score network
 # ----------------------------------------------------------------------------------------------------------------
@@ -443,11 +467,28 @@ class BlasContext:
         self.workspace = torch.empty(self.WORKSPACE_BYTES, dtype=torch.uint8, device=device)
         self.silu_epilogue_ok = True      # cleared the first time the library reports no SWISH_BIAS kernel
 
+    def close(self):
+        """Release the hipBLASLt handle now (deterministically; mdx_blas_destroy calls into HIP, which is not allowed
+        while a stream of this thread is capturing)."""
+        if self.handle is not None:
+            handle, self.handle = self.handle, None
+            lib().mdx_blas_destroy(handle)
+
     def __del__(self):
+        # This is the one object of the package whose finaliser calls HIP.  Instances live in _by_device for the life of the
+        # process, so the collector never sees one during a capture; should that ever change, leak the handle rather than
+        # abort the capture.
         try:
-            lib().mdx_blas_destroy(self.handle)
+            if not torch.cuda.is_current_stream_capturing():
+                self.close()
         except Exception:
             pass
+
+    @classmethod
+    def close_all(cls):
+        for ctx in cls._by_device.values():
+            ctx.close()
+        cls._by_device.clear()
 
     @classmethod
     def get(cls, device):
@@ -559,7 +600,8 @@ class EdgeChainPack:
 
 
 def egnn_edge_chain(pack: EdgeChainPack, node_proj, coord, edges, status=None, n_edges_dev=None):
-    """messages [E,H], edge_scalar [E] of the fused per-edge chain (mdx_egnn_edge_chain); edges sorted by source."""
+    """messages [E,H], edge_scalar [E] of the fused per-edge chain (mdx_egnn_edge_chain); edges sorted by source.
+    n_edges_dev (int64 [1], device): the actual number of edge rows when `edges` is a capacity-sized list."""
     E, H = edges.shape[0], pack.hidden
     assert node_proj.shape[1] == 2 * H and coord.shape[0] == node_proj.shape[0]
     messages = torch.empty(E, H, dtype=F32, device=edges.device)

@@ -167,10 +167,11 @@ class E_GCL(nn.Module):
             last.in_features % 4 == 0 and len(self.coord_mlp) >= 2 and isinstance(self.coord_mlp[-2], nn.SiLU)
 
     def forward(self, h: torch.Tensor, edge_index: torch.Tensor, coord: torch.Tensor,
-                degree: Optional[torch.Tensor] = None, offsets: Optional[torch.Tensor] = None
-                ) -> Tuple[torch.Tensor, torch.Tensor]:
+                degree: Optional[torch.Tensor] = None, offsets: Optional[torch.Tensor] = None,
+                n_edges: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """h [n_nodes, F]; edge_index [E, 2] sorted by column 0; coord [n_nodes, D]; degree [n_nodes] edge counts;
-        offsets [n_nodes] = exclusive scan of degree (enables the segment kernels on device tensors)."""
+        offsets [n_nodes] = exclusive scan of degree (enables the segment kernels on device tensors); n_edges: int64 [1]
+        on the device when edge_index is a capacity-sized list whose first n_edges rows are the edges (fused chain only)."""
         row, col = edge_index[:, 0], edge_index[:, 1]
         if degree is None:
             degree = torch.bincount(row, minlength=h.shape[0])
@@ -181,7 +182,8 @@ class E_GCL(nn.Module):
         if fused and offsets is not None and edge_index.shape[0] > 0:
             pack = self._edge_chain_pack()
             if pack is not None:
-                return self._forward_edge_chain(pack, h, edge_index, coord, degree, offsets)
+                return self._forward_edge_chain(pack, h, edge_index, coord, degree, offsets, n_edges)
+        assert n_edges is None, "a capacity-sized edge list needs the fused edge chain in every layer"
         inv_deg = (1.0 / degree.clamp(min=1).to(h.dtype)).unsqueeze(1)
 
         coord_diff = coord.index_select(0, row) - coord.index_select(0, col)
@@ -214,7 +216,7 @@ class E_GCL(nn.Module):
         return out, coord
 
 
-    def _forward_edge_chain(self, pack, h, edge_index, coord, degree, offsets):
+    def _forward_edge_chain(self, pack, h, edge_index, coord, degree, offsets, n_edges=None):
         """E_GCL.forward with the per-edge work in one MFMA kernel: node projections (library GEMM, per node) -> fused
         chain -> the two sorted-segment reductions -> node MLP."""
         from .. import kernels
@@ -222,7 +224,8 @@ class E_GCL(nn.Module):
         w = first.weight
         proj = torch.nn.functional.linear(h, torch.cat([w[:, :n_in], w[:, n_in:2 * n_in]], dim=0))
         coord = coord.contiguous()
-        messages, edge_scalar = kernels.egnn_edge_chain(pack, proj.contiguous(), coord, edge_index, status=self.status_word)
+        messages, edge_scalar = kernels.egnn_edge_chain(pack, proj.contiguous(), coord, edge_index, status=self.status_word,
+                                                        n_edges_dev=n_edges)
         coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean)
         agg = kernels.segment_rows(messages, offsets, degree, self.message_mean)
         out = run_mlp(self.node_mlp, torch.cat([h, agg], dim=1), True)
@@ -257,8 +260,9 @@ class EGNN(nn.Module):
                 act_fn=act_fn, residual=residual, attention=attention, normalize=normalize, coords_agg=coords_agg,
                 message_agg=message_agg, tanh=tanh))
 
-    def forward(self, h: torch.Tensor, edges: torch.Tensor, x: torch.Tensor,
-                degree: Optional[torch.Tensor] = None) -> AXL:
+    def forward(self, h: torch.Tensor, edges: torch.Tensor, x: torch.Tensor, degree=None) -> AXL:
+        """degree: None (a caller's own edge list, any order), the edge count per node [n_nodes] of a list sorted by source,
+        or the triple (degree, offsets, n_edges) of a capacity-sized list (utils/neighbors.get_edges_static)."""
         emb = self.embedding_in
         if h.is_cuda and emb.in_features <= 8:
             # [sigma | one-hot type] -> hidden: with 2-4 input features the library GEMM spends 0.45 ms on a K = 3
@@ -274,7 +278,11 @@ class EGNN(nn.Module):
             # kernels need the edges grouped by source, so sort them (stable: the order within a node is kept)
             edges = edges[torch.argsort(edges[:, 0], stable=True)]
             degree = torch.bincount(edges[:, 0], minlength=h.shape[0])
-        offsets = (torch.cumsum(degree, 0) - degree) if h.is_cuda else None
+        n_edges = None
+        if isinstance(degree, tuple):
+            degree, offsets, n_edges = degree
+        else:
+            offsets = (torch.cumsum(degree, 0) - degree) if h.is_cuda else None
         for layer in self.graph_layers:
-            h, x = layer(h, edges, x, degree, offsets)
+            h, x = layer(h, edges, x, degree, offsets, n_edges)
         return AXL(A=self.node_classification_layer(h), X=x, L=torch.zeros_like(x))

@@ -103,6 +103,11 @@ class EGNNScoreNetwork(ScoreNetwork):
         self.drop_duplicate_edges = hp.drop_duplicate_edges
         self.edge_builder = edge_builder
         self.graph_status = None      # device word that collects MDX_STATUS_* bits of the forward without a sync
+        # Radius graph without a host read between count and fill (so that a whole sampler iteration can be captured into a
+        # hipGraph): the edge list is sized for the worst case B N (N - 1) -- it cannot overflow -- as long as the [E, H]
+        # message buffer of that size stays below this many bytes; above it, the two-call protocol with its one host read
+        # is used.  Applies when every graph layer runs the fused edge chain (nothing else then needs E on the host).
+        self.static_edge_list_max_bytes = 24 << 30
         self.egnn = self._make_egnn(hp)
 
     @property
@@ -159,6 +164,15 @@ class EGNNScoreNetwork(ScoreNetwork):
         assert self.drop_duplicate_edges, "the HIP graph path implements drop_duplicate_edges=True"
         if self.graph_status is None or self.graph_status.device != relative_coordinates.device:
             self.graph_status = torch.zeros(1, dtype=torch.int32, device=relative_coordinates.device)
+        capacity = bsz * n * (n - 1)
+        width = max((layer.message_mlp[0].out_features for layer in self.egnn.graph_layers), default=0)
+        if relative_coordinates.is_cuda and not torch.is_grad_enabled() and 0 < capacity * width * 4 <= \
+                self.static_edge_list_max_bytes and all(layer._edge_chain_pack() is not None
+                                                        for layer in self.egnn.graph_layers):
+            edges, degree, offsets, n_edges = neighbors.get_edges_static(relative_coordinates, unit_cell,
+                                                                         self.radial_cutoff, capacity,
+                                                                         status=self.graph_status)
+            return edges, (degree, offsets, n_edges)
         return neighbors.get_edges_with_radial_cutoff(relative_coordinates, unit_cell, self.radial_cutoff,
                                                       status=self.graph_status, return_degree=True)
 

@@ -103,6 +103,16 @@ def get_edges_with_radial_cutoff(relative_coordinates: torch.Tensor, unit_cell: 
     return adj.transpose(0, 1)
 
 
+def get_edges_static(relative_coordinates: torch.Tensor, unit_cell: torch.Tensor, radial_cutoff: float, capacity: int,
+                     status: Optional[torch.Tensor] = None):
+    """get_edges_with_radial_cutoff without the host read of the edge count: a capacity-sized edge list
+    (edges [capacity, 2], degree [B*N], offsets [B*N], n_edges int64 [1] on the device).  capacity = B N (N - 1) cannot
+    overflow; a smaller one reports through `status` (STATUS_GRAPH_CAPACITY)."""
+    cart = torch.matmul(relative_coordinates, unit_cell).contiguous()
+    out = kernels.radius_graph_static(cart, unit_cell.contiguous(), radial_cutoff, capacity, status=status)
+    return out["edges"], out["counts"], out["offsets"], out["n_edges"]
+
+
 def get_edges_batch(n_nodes: int, batch_size: int, device=None) -> torch.Tensor:
     """Fully connected edges without self loops, [B n (n-1), 2], sorted by source (models/egnn_utils.py:73-104)."""
     idx = torch.arange(n_nodes, device=device)

@@ -208,6 +208,15 @@ MDX_API int mdx_radius_graph_count(const float* cartesian_positions, const float
 MDX_API int mdx_radius_graph_fill(const float* cartesian_positions, const float* basis_vectors, float radial_cutoff,
                           int64_t batch, int number_of_atoms, int unique, const int64_t* offsets,
                           int64_t* edges_out, int32_t* image_out, float* shifts_out, mdx_stream_t stream);
+/* The same with a caller-sized edge list ("capacity + overflow flag"): step 2 happens on the device --
+ * offsets = exclusive scan of counts, E = its last element + last count, both left in device memory -- and the outputs
+ * hold `capacity` rows, so no host read sits between count and fill (the step can be captured into a hipGraph).  Edges
+ * beyond `capacity` are not written and MDX_STATUS_GRAPH_CAPACITY is OR-ed into `status` (nullable).  capacity =
+ * batch * N * (N - 1) can never overflow in unique mode. */
+MDX_API int mdx_radius_graph_fill_capped(const float* cartesian_positions, const float* basis_vectors, float radial_cutoff,
+                                         int64_t batch, int number_of_atoms, int unique, const int64_t* offsets,
+                                         int64_t capacity, int64_t* edges_out, int32_t* image_out, float* shifts_out,
+                                         uint32_t* status, mdx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused score network: the reference's MLPScoreNetwork (models/score_networks/mlp_score_network.py:54-370,

@@ -224,3 +224,62 @@ def test_egnn_accepts_unsorted_edges(cuda):
         a = net.egnn(h=h, edges=edges, x=x.clone())
         b = net.egnn(h=h, edges=edges[perm], x=x.clone())
     assert _rel_l2(b.X, a.X) < 1e-5 and _rel_l2(b.A, a.A) < 1e-5
+
+
+def test_radius_graph_static_equals_two_call(cuda):
+    """The capacity-sized radius graph (no host read between count and fill) gives the same edge list, degrees and count as
+    the two-call protocol; a capacity that is too small writes nothing beyond it and reports STATUS_GRAPH_CAPACITY."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
+    torch.manual_seed(11)
+    B, N, rc = 7, 64, 7.5
+    x = torch.rand(B, N, 3, device=cuda)
+    cell = torch.diag(torch.tensor([16.5, 16.5, 16.5])).repeat(B, 1, 1).to(cuda)
+    cart = (x @ cell).contiguous()
+    ref = kernels.radius_graph(cart, cell, rc, unique=True)
+    E = ref["edges"].shape[0]
+    status = torch.zeros(1, dtype=torch.int32, device=cuda)
+    out = kernels.radius_graph_static(cart, cell, rc, B * N * (N - 1), status=status)
+    assert int(out["n_edges"].item()) == E and int(status.item()) == 0
+    assert torch.equal(out["edges"][:E], ref["edges"]) and torch.equal(out["counts"], ref["counts"].view(-1))
+    assert torch.equal(out["offsets"], torch.cumsum(ref["counts"].view(-1), 0) - ref["counts"].view(-1))
+    small = E - 37
+    guard = torch.full((small + 64, 2), -5, dtype=torch.int64, device=cuda)
+    check, lib, ptr, stream_handle = _hip.check, _hip.lib, _hip.ptr, _hip.stream_handle
+    check(lib().mdx_radius_graph_fill_capped(ptr(cart, torch.float32, "c"), ptr(cell, torch.float32, "b"), rc, B, N, 1,
+                                             ptr(out["offsets"], torch.int64, "o"), small, ptr(guard, torch.int64, "e"), None,
+                                             None, ptr(status, torch.int32, "s"), stream_handle()), "fill_capped")
+    assert int(status.item()) == _hip.STATUS_GRAPH_CAPACITY
+    assert torch.equal(guard[:small], ref["edges"][:small]) and (guard[small:] == -5).all()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_egnn_sampler_graph_replay_equals_eager(cuda, precision):
+    """The EGNN sampler iteration (radius graph with a capacity-sized edge list + fused edge chain: no host read) captured
+    into a hipGraph and replayed equals the eager run bit for bit; and equals the run with the two-call radius graph."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.predictor_corrector_axl_generator import \
+        PredictorCorrectorSamplingParameters
+    from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters
+    import cases
+    import warnings
+    outs = {}
+    for mode in ("eager", "graph", "two_call"):
+        torch.manual_seed(21)
+        net = nets.egnn_net(1, "radial_cutoff", 7.5, hidden=32, n_layers=2, n_hidden=2).to(cuda)
+        net.edge_chain_precision = precision
+        if mode == "two_call":
+            net.static_edge_list_max_bytes = 0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            npar = NoiseParameters(**cases.noise_ns(5, **cases.LIN))
+            spar = PredictorCorrectorSamplingParameters(**cases.sampling_ns(64, 1, M=2, greedy=False, one=False,
+                                                                            cell=[10.86] * 3),
+                                                        rng_mode="device", seed=31, use_hip_graph=mode == "graph")
+        gen = LangevinGenerator(npar, spar, net)
+        with torch.no_grad():
+            out = gen.sample(12, cuda)
+        outs[mode] = (out.A.cpu().numpy(), out.X.cpu().numpy())
+    for mode in ("graph", "two_call"):
+        assert np.array_equal(outs["eager"][0], outs[mode][0]), mode
+        assert np.array_equal(outs["eager"][1].view(np.int32), outs[mode][1].view(np.int32)), mode
+    assert (outs["eager"][0] != 1).all()
