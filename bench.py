@@ -400,10 +400,11 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (with ranks sharing a GPU) exists to rehearse the multi-rank control "
                          "flow on a one-GPU box")
-    ap.add_argument("--egnn-precision", choices=["f32", "f16x3", "library"], default="f32",
-                    help="EGNN workloads: arithmetic of the fused per-edge MFMA kernel -- 'f32' exact binary32 MFMA, 'f16x3' "
-                         "split-f16 three-product form (binary32-level accuracy, measured in the tests), 'library' = per-layer "
-                         "hipBLASLt GEMMs (round-1 path)")
+    ap.add_argument("--egnn-precision", choices=["f32", "f16x3", "library"], default="f16x3",
+                    help="EGNN workloads: arithmetic of the fused per-edge MFMA kernel -- 'f16x3' (the product's default) "
+                         "split-f16 three-product form with binary32 accumulation, binary32-level accuracy (error against fp64 "
+                         "equal to the f32 paths': tests/test_egnn_chain_gpu.py); 'f32' exact binary32 MFMA; 'library' = "
+                         "per-layer hipBLASLt GEMMs (round-1 path).  The other MFMA mode is timed too and reported beside it.")
     ap.add_argument("--master-port", type=int, default=29541, help="rendezvous port when bench.py starts its own ranks")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="no GPU work: the ranks only run the job's control flow on host tensors (gloo) -- rendezvous, the "
@@ -520,6 +521,17 @@ def main():
         gen.check_status()
         job_ms = (trajectory_ms if trajectory_ms is not None else T * ms_per_step) + gather_ms
         value = (batch * world) / (job_ms * 1e-3)
+        other_mode = None
+        if not mlp and args.egnn_precision in ("f32", "f16x3"):
+            # the same job through the other arithmetic mode of the edge chain (2 iterations, same timing protocol)
+            other = "f32" if args.egnn_precision == "f16x3" else "f16x3"
+            net.edge_chain_precision = other
+            loop_o = new_loop()
+            advance(loop_o, 1, T)
+            ms_o = timed(lambda: advance(loop_o, 2, T)) * 1e3 / 2
+            net.edge_chain_precision = args.egnn_precision
+            other_mode = dict(egnn_edge_chain=other, ms_per_step=round(ms_o, 5),
+                              value=round((batch * world) / ((T * ms_o + gather_ms) * 1e-3), 4), unit="structures/s")
         generic_path = None
         if forward == "fused":
             # the same job through the generic instantiation of the persistent kernel (any MLP shape takes this path;
@@ -577,7 +589,9 @@ def main():
         "value_from": ("one whole %d-iteration trajectory timed end to end (trajectory_ms %.4f) + gather" % (T, trajectory_ms))
         if trajectory_ms is not None else "total_time_steps x ms_per_step + gather",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (random-init score network, uniform-random initial structures)",
+        "dtype": "f32" if mlp or args.egnn_precision != "f16x3" else
+        "f32 (per-edge matrix products as split-f16 hi/lo x3 MFMA terms with f32 accumulation: 22-bit products; state, "
+        "updates, reductions and every other layer in f32)", "data": "synthetic (random-init score network, uniform-random initial structures)",
         "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": batch, "global_batch": batch * world,
                    "number_of_atoms": w["n_atoms"], "total_time_steps": T, "corrector_steps": w["M"],
                    "repaint_resampling_steps": resampling,
@@ -592,6 +606,8 @@ def main():
     }
     if generic_path is not None:
         result["generic_path"] = generic_path
+    if other_mode is not None:
+        result["other_edge_chain_mode"] = other_mode
     if forward_gemm is not None:
         # EGNN workloads: the step is the per-edge MLP chain (matrix cores); the streaming kernels are < 1 % of it.  The
         # dominant kernel's roofline is `roofline`; the largest HBM-bound kernel (radius graph, N1) is `roofline_hbm`.

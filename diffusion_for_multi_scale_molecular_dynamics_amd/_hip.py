@@ -41,6 +41,11 @@ class MdxError(RuntimeError):
     """A C-ABI call returned a negative status."""
 
 
+class EdgeChainRangeError(MdxError):
+    """MDX_STATUS_EGNN_F16_RANGE: the split-f16 edge chain met an activation beyond the f16 range; the call's results are
+    invalid and must be recomputed with edge_chain_precision='f32'."""
+
+
 class Schedule(C.Structure):
     """mdx_schedule_t"""
     _fields_ = [("total_time_steps", C.c_int32), ("num_classes", C.c_int32), ("sigma_min", C.c_double),

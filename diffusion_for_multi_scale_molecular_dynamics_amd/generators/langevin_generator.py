@@ -373,14 +373,32 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         net_status = getattr(self.axl_network, "graph_status", None)
         if net_status is not None:
             from ..utils.neighbors import _raise_if_cutoff_too_large
-            _raise_if_cutoff_too_large(net_status)
-            net_status.zero_()
+            try:
+                _raise_if_cutoff_too_large(net_status)
+            finally:
+                net_status.zero_()
 
     def sample(self, number_of_samples: int, device: torch.device) -> AXL:
+        from .._hip import EdgeChainRangeError
         self._prepare(device)
         self._begin_call(torch.device(device))
-        composition = super().sample(number_of_samples, device)
-        self.check_status()
+        try:
+            composition = super().sample(number_of_samples, device)
+            self.check_status()
+        except EdgeChainRangeError:
+            # The score network's split-f16 edge chain met a value beyond the f16 range: recompute this call with the exact
+            # binary32 MFMA kernel (device RNG: the same call index gives the same draws; reference-order RNG cannot be
+            # rewound, so there the error stands).
+            if self.rng_mode != "device" or not hasattr(self.axl_network, "edge_chain_precision"):
+                raise
+            import warnings
+            warnings.warn("EGNN edge chain: value beyond the f16 range; recomputing the call with edge_chain_precision='f32'")
+            self.axl_network.edge_chain_precision = "f32"
+            self._buffers.pop("graph_loop", None)
+            self._call_counter -= 1
+            self._begin_call(torch.device(device))
+            composition = super().sample(number_of_samples, device)
+            self.check_status()
         if self.rng_mode == "device":
             self.noise_source = None
         return composition

@@ -167,7 +167,7 @@ class EGNNScoreNetwork(ScoreNetwork):
         capacity = bsz * n * (n - 1)
         width = max((layer.message_mlp[0].out_features for layer in self.egnn.graph_layers), default=0)
         if relative_coordinates.is_cuda and not torch.is_grad_enabled() and 0 < capacity * width * 4 <= \
-                self.static_edge_list_max_bytes and all(layer._edge_chain_pack() is not None
+                self.static_edge_list_max_bytes and all(layer.use_fused_ops and layer._edge_chain_pack() is not None
                                                         for layer in self.egnn.graph_layers):
             edges, degree, offsets, n_edges = neighbors.get_edges_static(relative_coordinates, unit_cell,
                                                                          self.radial_cutoff, capacity,

@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 from .. import kernels
-from .._hip import STATUS_CUTOFF_TOO_LARGE, STATUS_EGNN_F16_RANGE, STATUS_GRAPH_CAPACITY, MdxError
+from .._hip import (STATUS_CUTOFF_TOO_LARGE, STATUS_EGNN_F16_RANGE, STATUS_GRAPH_CAPACITY, EdgeChainRangeError,
+                     MdxError)
 
 AdjacencyInfo = namedtuple(
     "AdjacencyInfo",
@@ -31,8 +32,8 @@ def _raise_if_cutoff_too_large(status: torch.Tensor):
         raise AssertionError("The radial cutoff is so large that neighbors could be located "
                              "beyond the first shell of periodic unit cell images.")
     if word & STATUS_EGNN_F16_RANGE:
-        raise MdxError("EGNN edge chain, split-f16 mode: an activation left the f16 range (|x| > 6e4); the results of "
-                       "this call are invalid -- run the network with edge_chain_precision='f32'")
+        raise EdgeChainRangeError("EGNN edge chain, split-f16 mode: an activation left the f16 range (|x| > 6.5e4); the "
+                                  "results of this call are invalid -- run the network with edge_chain_precision='f32'")
     if word & STATUS_GRAPH_CAPACITY:
         raise MdxError("radius graph: the edge list outgrew its capacity and the retry did not run (internal error)")
 

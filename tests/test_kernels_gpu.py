@@ -455,7 +455,7 @@ def test_bench_contract(cuda, workload):
                 "vs_baseline", "dtype", "data", "config", "roofline", "job_ms", "value_from"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup and d["value"] > 0 and d["vs_baseline"] is None
-    assert d["config"]["workload"].startswith(workload or "C3") and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["config"]["workload"].startswith(workload or "C3") and d["scaling"] == "weak" and d["dtype"].startswith("f32")
     assert d["config"]["env"] == {"MDX_STRAY_VARIABLE": "1"}          # stray MDX_* variables are visible, and unused
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
@@ -467,3 +467,8 @@ def test_bench_contract(cuda, workload):
         assert d["generic_path"]["value"] > 0 and d["generic_path"]["value"] <= d["value"] * 1.05
     else:
         assert abs(d["job_ms"] - 1000 * d["ms_per_step"]) < 1e-6 * d["job_ms"] + 1e-3
+        # EGNN workload: the dominant kernel is the hand-written MFMA edge chain; both arithmetic modes are on the line
+        assert r["bound"] == "mfma" and "egnn_edge_chain_kernel" in r["kernel"] and d["roofline_hbm"]["bound"] == "hbm"
+        assert d["config"]["egnn_edge_chain"] == "f16x3" and d["other_edge_chain_mode"]["egnn_edge_chain"] == "f32"
+        assert 0 < d["other_edge_chain_mode"]["value"] < d["value"]
+        assert d["config"]["hip_graph"] is True
