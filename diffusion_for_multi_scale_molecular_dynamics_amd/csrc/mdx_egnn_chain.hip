@@ -359,10 +359,18 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 if (s == STEPS / 2) w_next = ch.acquire_next();
+#if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 32)
+                fr[s + PFD] = fr[s];
+#else
                 if (s + PFD < STEPS) fr[s + PFD] = read_frag(w_cur, s + PFD);
                 else fr[s + PFD] = read_frag(w_next, s + PFD - STEPS);
+#endif
                 if (s == STEPS - 1) acc_next = read_bias(next_bias);
+#if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 16))
                 if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst);
+#else
+                if (have && s == 0) asm volatile("" ::"v"(pend));      // keep the MFMAs alive without their epilogue
+#endif
                 if constexpr (PREC == 0) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
