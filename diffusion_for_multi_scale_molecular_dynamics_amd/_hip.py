@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
     "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_radius_graph_fill_capped", "mdx_mlp_forward",
-    "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
+    "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_variant", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
     "mdx_egnn_chain_image_bytes", "mdx_egnn_chain_pack", "mdx_egnn_edge_chain", "mdx_egnn_coord_aggregate",
     "mdx_rng_fill", "mdx_math_probe",
 )
@@ -155,6 +155,8 @@ def _declare(L):
     L.mdx_mlp_pc_sample.restype = i32
     L.mdx_mlp_pc_sample.argtypes = [C.POINTER(Schedule), C.POINTER(Mlp), C.POINTER(PcFlags), i32, i32, i32, i32, Rng, i64,
                                     vp, vp, vp, vp, i64, u32, vp, vp]
+    L.mdx_mlp_pc_sample_variant.restype = i32
+    L.mdx_mlp_pc_sample_variant.argtypes = [C.POINTER(Mlp), u32]
     L.mdx_mlp_pc_sample_workspace_floats.restype = i64
     L.mdx_mlp_pc_sample_workspace_floats.argtypes = [C.POINTER(Mlp), i32, i32, i32, i64]
     L.mdx_mlp_image_floats.restype = i64

@@ -1017,31 +1017,48 @@ __host__ __device__ inline int mlp_scratch_floats(const mdx_mlp_t& m)
 // The same holds at the other end: the last hidden layer has no activation (:337-344), so it and the three output heads
 // are one 64 -> 46 linear map (mdx_mlp_t.folded_output).  The template network is then three layers -- 15 + 16 + 16
 // weight quads = 188 registers, no AGPR traffic -- instead of five.
+// The family of register-resident instantiations: N = 8, d = 3, hidden 64, atom-type / lattice embeddings of size 1 (the
+// reference's template), C in {2, 3} classes and NH in {2, 3, 4} hidden layers.  SPEC = 100 + 10 C + NH.
+constexpr bool spec_folded(int SPEC) { return SPEC >= 100; }
+constexpr int spec_classes(int SPEC) { return SPEC >= 100 ? (SPEC - 100) / 10 : 2; }
+constexpr int spec_hidden_layers(int SPEC) { return SPEC >= 100 ? (SPEC - 100) % 10 : 3; }
+
+template <int C, int NH>
 struct MlpRegsFolded {
-    lds_f4 wf[15], wh1[16], wfo[16];
-    float bf, bh1, bfo;
+    static constexpr int MID = NH - 2;                  // hidden layers between the folded input and the folded output
+    static constexpr int NOUT = 8 * C + 24 + 6;         // logits | score_x | score_l
+    lds_f4 wf[15], wmid[MID > 0 ? MID : 1][16], wfo[16];
+    float bf, bmid[MID > 0 ? MID : 1], bfo;
 };
 
-__device__ __forceinline__ void load_mlp_regs_folded(MlpRegsFolded& R, const mdx_mlp_t& m, const MlpWeightsLds& w, int lane)
+template <int C, int NH>
+__device__ __forceinline__ void load_mlp_regs_folded(MlpRegsFolded<C, NH>& R, const mdx_mlp_t& m, const MlpWeightsLds& w,
+                                                     int lane)
 {
+    constexpr int NOUT = MlpRegsFolded<C, NH>::NOUT;
     const lds_f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     const lds_f4* folded = reinterpret_cast<const lds_f4*>(m.folded_input);       // [15][64] quads, then the bias [64]
 #pragma unroll
     for (int q = 0; q < 15; ++q) R.wf[q] = folded[q * 64 + lane];
     R.bf = m.folded_input[15 * 64 * 4 + lane];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) R.wh1[q] = ((lds_cf4*)w.wh(1))[q * 64 + lane];
-    const lds_f4* out = reinterpret_cast<const lds_f4*>(m.folded_output);        // [16][46] quads, then the bias [46]
+    for (int k = 0; k < NH - 2; ++k) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) R.wfo[q] = lane < 46 ? out[q * 46 + lane] : zero;
-    R.bh1 = w.bh(1)[lane];
-    R.bfo = lane < 46 ? m.folded_output[16 * 46 * 4 + lane] : 0.0f;
+        for (int q = 0; q < 16; ++q) R.wmid[k][q] = ((lds_cf4*)w.wh(1 + k))[q * 64 + lane];
+        R.bmid[k] = w.bh(1 + k)[lane];
+    }
+    const lds_f4* out = reinterpret_cast<const lds_f4*>(m.folded_output);        // [16][NOUT] quads, then the bias [NOUT]
+#pragma unroll
+    for (int q = 0; q < 16; ++q) R.wfo[q] = lane < NOUT ? out[q * NOUT + lane] : zero;
+    R.bfo = lane < NOUT ? m.folded_output[16 * NOUT * 4 + lane] : 0.0f;
 }
 
-__device__ __forceinline__ void mlp_forward_folded(const MlpWeightsLds& w, const MlpRegsFolded& R, int lane, lds_cf* x,
+template <int C, int NH>
+__device__ __forceinline__ void mlp_forward_folded(const MlpWeightsLds& w, const MlpRegsFolded<C, NH>& R, int lane, lds_cf* x,
                                                    lds_ci64* a, lds_cf* l, float time, float sigma, lds_f* buf_a, lds_f* buf_b,
                                                    lds_f* logits)
 {
+    constexpr int NOUT = MlpRegsFolded<C, NH>::NOUT;
     // the 59 (+1 zero) inputs of the folded layer
     if (lane < 24) {
         // hardware sin / cos take their argument in revolutions: cos(2 pi x), sin(2 pi x) directly
@@ -1065,11 +1082,18 @@ __device__ __forceinline__ void mlp_forward_folded(const MlpWeightsLds& w, const
     wave_sync();
     buf_a[lane] = silu_(dot_regs<15>(R.wf, buf_b, R.bf));
     wave_sync();
-    buf_b[lane] = silu_(dot_regs<16>(R.wh1, buf_a, R.bh1));
-    wave_sync();
-    if (lane < 46) {                                            // logits (16) | score_x (24) | score_l (6), contiguous
-        const float o = dot_regs<16>(R.wfo, buf_b, R.bfo);
-        logits[lane] = (lane < 16 && (lane & 1)) ? -__builtin_huge_valf() : o;
+    // the middle layers ping-pong between the two buffers; `cur` ends up holding the input of the folded output layer
+    lds_f* cur = buf_a;
+    lds_f* other = buf_b;
+#pragma unroll
+    for (int k = 0; k < NH - 2; ++k) {
+        other[lane] = silu_(dot_regs<16>(R.wmid[k], cur, R.bmid[k]));
+        wave_sync();
+        lds_f* t = cur; cur = other; other = t;
+    }
+    if (lane < NOUT) {                                          // logits (8 C) | score_x (24) | score_l (6), contiguous
+        const float o = dot_regs<16>(R.wfo, cur, R.bfo);
+        logits[lane] = (lane < 8 * C && (lane % C) == C - 1) ? -__builtin_huge_valf() : o;
     }
     // no hand-off here: the caller stores the step's noise record next to these outputs and synchronises once
 }
@@ -1239,9 +1263,10 @@ template <int SPEC>
 __device__ __forceinline__ void specialise(mdx_mlp_t& m, PcArgs& pc)
 {
     if constexpr (SPEC >= 1) {
-        m.number_of_atoms = 8; m.spatial_dimension = 3; m.num_classes = 2; m.hidden_size = 64; m.n_hidden = 3;
+        m.number_of_atoms = 8; m.spatial_dimension = 3; m.num_classes = spec_classes(SPEC); m.hidden_size = 64;
+        m.n_hidden = spec_hidden_layers(SPEC);
         m.e_coordinates = 32; m.e_noise = 16; m.e_time = 16; m.e_atom_type = 1; m.e_lattice = 1;
-        pc.N = 8; pc.d = 3; pc.C = 2; pc.nl = 6;
+        pc.N = 8; pc.d = 3; pc.C = spec_classes(SPEC); pc.nl = 6;
     }
 }
 
@@ -1250,6 +1275,16 @@ inline bool matches_template_mlp(const mdx_mlp_t& m)
     return m.number_of_atoms == 8 && m.spatial_dimension == 3 && m.num_classes == 2 && m.hidden_size == 64 &&
            m.n_hidden == 3 && m.e_coordinates == 32 && m.e_noise == 16 && m.e_time == 16 && m.e_atom_type == 1 &&
            m.e_lattice == 1;
+}
+
+// the register-resident folded family (SPEC >= 100): one or two atom types, two to four hidden layers
+inline int folded_family_spec(const mdx_mlp_t& m)
+{
+    const bool shape = m.number_of_atoms == 8 && m.spatial_dimension == 3 && m.hidden_size == 64 && m.e_coordinates == 32 &&
+                       m.e_noise == 16 && m.e_time == 16 && m.e_atom_type == 1 && m.e_lattice == 1;
+    if (!shape || m.num_classes < 2 || m.num_classes > 3 || m.n_hidden < 2 || m.n_hidden > 4) return 0;
+    if (!m.folded_input || !m.folded_output) return 0;
+    return 100 + 10 * m.num_classes + m.n_hidden;
 }
 
 template <int G, bool LDS_WEIGHTS, int SPEC>
@@ -1266,9 +1301,9 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
     auto run = [&](const auto& w, lds_f* scratch) {
         const MlpWaveLds r = carve_wave_lds(m, scratch + wave * mlp_wave_floats(m));
         [[maybe_unused]] MlpRegs regs;
-        [[maybe_unused]] MlpRegsFolded folded;
+        [[maybe_unused]] MlpRegsFolded<spec_classes(SPEC), spec_hidden_layers(SPEC)> folded;
         if constexpr (SPEC == 1 && LDS_WEIGHTS) load_mlp_regs(regs, w, lane);
-        if constexpr (SPEC == 2 && LDS_WEIGHTS) {
+        if constexpr (spec_folded(SPEC) && LDS_WEIGHTS) {
             load_mlp_regs_folded(folded, m, w, lane);
             // The folded weights come from global memory.  Complete those loads HERE: left pending into the loop, the
             // compiler must assume them outstanding at the loop head and guards the first FMAs of every iteration with
@@ -1316,7 +1351,7 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
                     if (!(p.diag_skip & 1)) {
                         if constexpr (SPEC == 1 && LDS_WEIGHTS)
                             mlp_forward_regs(w, regs, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b, r.logits);
-                        else if constexpr (SPEC == 2 && LDS_WEIGHTS)
+                        else if constexpr (spec_folded(SPEC) && LDS_WEIGHTS)
                             mlp_forward_folded(w, folded, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b,
                                                r.logits);
                         else
@@ -1711,9 +1746,13 @@ static void launch_mlp_sampler(int G, unsigned grid, size_t lds, hipStream_t st,
     }
 }
 
+#define MDX_FOLDED_FAMILY(X) X(122) X(123) X(124) X(132) X(133) X(134)
+
 static const void* mlp_sampler_lds_function(int G, int spec)
 {
-    if (spec == 2) return (const void*)mlp_pc_sample_kernel<8, true, 2>;
+#define MDX_CASE(S) if (spec == S) return (const void*)mlp_pc_sample_kernel<8, true, S>;
+    MDX_FOLDED_FAMILY(MDX_CASE)
+#undef MDX_CASE
     if (spec == 1) return (const void*)mlp_pc_sample_kernel<8, true, 1>;
     switch (G) {
         case 1: return (const void*)mlp_pc_sample_kernel<1, true, 0>;
@@ -2072,6 +2111,19 @@ int64_t mdx_mlp_pc_sample_workspace_floats(const mdx_mlp_t* mlp_host, int number
     return (rec0 + number_of_corrector_steps * rec1) * batch * n_iterations;
 }
 
+static int mlp_sampler_variant(const mdx_mlp_t& m, uint32_t options)
+{
+    int spec = matches_template_mlp(m) && !(options & MDX_MLP_SAMPLE_GENERIC_KERNEL) ? 1 : 0;
+    if (!(options & (MDX_MLP_SAMPLE_GENERIC_KERNEL | MDX_MLP_SAMPLE_UNFOLDED)) && folded_family_spec(m)) spec = folded_family_spec(m);
+    return spec;
+}
+
+int mdx_mlp_pc_sample_variant(const mdx_mlp_t* mlp_host, uint32_t options)
+{
+    if (mlp_ok(mlp_host) != MDX_OK) return -1;
+    return mlp_sampler_variant(*mlp_host, options);
+}
+
 int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_host, const mdx_pc_flags_t* f,
                       int number_of_corrector_steps, int atom_type_transition_in_corrector, int start_index,
                       int n_iterations, mdx_rng_t rng, int64_t batch, int64_t* atom_types, float* x, float* l,
@@ -2163,16 +2215,17 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
     }
     if (in_lds) {
         const size_t lds = per_wave * kMlpWaves + image;
-        // 0: generic instantiation; 1: template dimensions as literals; 2: the same with the folded input / output layers
-        int spec = matches_template_mlp(*mlp_host) && !(options & MDX_MLP_SAMPLE_GENERIC_KERNEL) ? 1 : 0;
-        if (spec == 1 && mlp_host->folded_input && mlp_host->folded_output && !(options & MDX_MLP_SAMPLE_UNFOLDED)) spec = 2;
+        // 0: generic instantiation; 1: template dimensions as literals, layer by layer; >= 100: the register-resident family
+        // with the folded input / output layers (100 + 10 C + NH)
+        const int spec = mlp_sampler_variant(*mlp_host, options);
         if (lds > kMlpLdsBudget) {       // up to 128 KiB of the CU's 160 KiB: opt in above the 64 KiB default
             // the attribute is a property of the code object: set it when the requirement grows, not on every launch
             // (per device: a process that samples on a second GPU must opt in there as well)
             static std::atomic<size_t> granted[kMaxDevices][16];
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return MDX_ERR_HIP;
-            const int slot = spec ? 6 + spec : (G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : G == 32 ? 5 : 6);
+            const int slot = spec >= 100 ? 8 + (spec - 120) / 10 * 3 + (spec % 10 - 2)      // 8 .. 13
+                             : spec ? 7 : (G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : G == 32 ? 5 : 6);
             if (granted[dev][slot].load() < lds) {
                 if (hipFuncSetAttribute(mlp_sampler_lds_function(G, spec), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) != hipSuccess)
@@ -2180,9 +2233,11 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
                 granted[dev][slot].store(lds);
             }
         }
-        if (spec == 2)
-            hipLaunchKernelGGL((mlp_pc_sample_kernel<8, true, 2>), dim3(grid), dim3(kMlpWaves * kWave), lds, st, a);
-        else if (spec == 1)
+#define MDX_CASE(S) \
+        if (spec == S) hipLaunchKernelGGL((mlp_pc_sample_kernel<8, true, S>), dim3(grid), dim3(kMlpWaves * kWave), lds, st, a); else
+        MDX_FOLDED_FAMILY(MDX_CASE)
+#undef MDX_CASE
+        if (spec == 1)
             hipLaunchKernelGGL((mlp_pc_sample_kernel<8, true, 1>), dim3(grid), dim3(kMlpWaves * kWave), lds, st, a);
         else
             launch_mlp_sampler<true>(G, grid, lds, st, a);

@@ -295,6 +295,11 @@ MDX_API int mdx_mlp_forward(const mdx_mlp_t* mlp_host, const int64_t* atom_types
 MDX_API int64_t mdx_mlp_pc_sample_workspace_floats(const mdx_mlp_t* mlp_host, int number_of_corrector_steps,
                                                    int atom_type_transition_in_corrector, int n_iterations,
                                                    int64_t batch);
+/* Which instantiation mdx_mlp_pc_sample runs for this network and these options: 0 = generic (any shape), 1 = the
+ * reference template's dimensions as literals (layer by layer), 100 + 10 C + NH = the register-resident family with folded
+ * input / output layers: N = 8, d = 3, hidden 64, embeddings 32/16/16/1/1, C in {2,3} classes, NH in {2,3,4} hidden layers
+ * (needs folded_input and folded_output).  -1: invalid descriptor. */
+MDX_API int mdx_mlp_pc_sample_variant(const mdx_mlp_t* mlp_host, uint32_t options);
 MDX_API int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_host,
                               const mdx_pc_flags_t* flags_host, int number_of_corrector_steps,
                               int atom_type_transition_in_corrector, int start_index, int n_iterations, mdx_rng_t rng,

@@ -1128,3 +1128,41 @@ def test_start_from_given_configuration_on_the_hip_path(cuda, name, tmp_path):
 def RS_AXL_cpu(comp):
     from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import AXL
     return AXL(A=comp.A.cpu(), X=comp.X.cpu(), L=comp.L.cpu())
+
+
+@pytest.mark.parametrize("num_atom_types,n_hidden", [(1, 2), (1, 3), (1, 4), (2, 2), (2, 3), (2, 4)])
+def test_fused_sampler_register_resident_family(cuda, num_atom_types, n_hidden):
+    """The register-resident instantiations of the persistent sampler (N = 8, hidden 64; one or two atom types; 2-4 hidden
+    layers; folded input / output layers) against the generic instantiation of the same kernel: the same function, folded
+    rounding.  One iteration from the same state: atom types exact, coordinates within 1e-6; a whole trajectory on a neutral
+    schedule: atom types exact, coordinates within 1e-5.  And each network really gets its own instantiation."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
+    P = _pkg()
+    torch.manual_seed(1234 + n_hidden)
+    net = nets.mlp_net(8, num_atom_types, hidden=64, n_hidden=n_hidden).to(cuda)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = P["Noise"](**cases.noise_ns(40, **cases.LIN))
+        spar = P["Sampling"](**cases.sampling_ns(8, num_atom_types), rng_mode="device", seed=3, fused_score_network=True)
+    gen = P["Langevin"](npar, spar, net)
+    with torch.no_grad():
+        gen._prepare(cuda)
+        gen._begin_call(cuda)
+        start = gen.initialize(200, cuda)
+        sched, pack = gen._prepare(cuda), gen.fused_pack(cuda)
+        assert kernels.lib().mdx_mlp_pc_sample_variant(pack.c_struct, 0) == 100 + 10 * (num_atom_types + 1) + n_hidden
+        generic = _hip.MLP_SAMPLE_GENERIC_KERNEL | _hip.MLP_SAMPLE_UNFOLDED
+        assert kernels.lib().mdx_mlp_pc_sample_variant(pack.c_struct, generic) == 0
+        results = {}
+        for name, options in (("family", 0), ("generic", generic)):
+            for n_iterations in (1, 40):
+                comp = RS.AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
+                kernels.mlp_pc_sample(sched, pack, gen._flags(True), 1, False, 40, n_iterations, gen._rng(0), comp.A,
+                                      comp.X, comp.L, gen._status, workspace=gen._noise_workspace, options=options)
+                results[name, n_iterations] = _np(comp)
+    for n_iterations, tol in ((1, 1e-6), (40, 1e-5)):
+        a, b = results["family", n_iterations], results["generic", n_iterations]
+        assert np.array_equal(a.A, b.A), n_iterations
+        assert torus_rel_l2(a.X, b.X) < tol, (n_iterations, torus_rel_l2(a.X, b.X))
+    assert (results["family", 40].A != num_atom_types).all()
