@@ -297,8 +297,15 @@ def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
     split = pack.precision == "f16x3"
     executed = flops * (3 if split else 1) / (ms * 1e-3) / 1e12
     peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+    traffic = None              # HBM-side bytes per launch from a separate PMC pass (profiles/traffic_r02.json), C3 shape only
+    try:
+        entry = json.load(open(os.path.join(ROOT, "profiles", "traffic_r02.json")))[f"C3/edge_chain/{pack.precision}"]
+        if abs(edges.shape[0] - 819200) < 0.06 * 819200 and H == 256 and n_layers == 9:
+            traffic = entry["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     return dict(bound="mfma", achieved=round(executed, 2), peak=peak, unit="TFLOP/s", frac=round(executed / peak, 4),
-                traffic=None, kernel=f"egnn_edge_chain_kernel<{H},{1 if split else 0}> ({'split-f16: 3 x v_mfma_f32_32x32x16_f16' if split else 'v_mfma_f32_32x32x2_f32'}"
+                traffic=traffic, kernel=f"egnn_edge_chain_kernel<{H},{1 if split else 0}> ({'split-f16: 3 x v_mfma_f32_32x32x16_f16' if split else 'v_mfma_f32_32x32x2_f32'}"
                 f" per product; {n_layers} fused H->H layers, {edges.shape[0]} edges per launch; 4 launches per network forward)",
                 avg_launch_us=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
                 algorithmic_tflops=round(flops / (ms * 1e-3) / 1e12, 2))

@@ -1194,61 +1194,84 @@ struct NoiseFillArgs {
     float* out;
 };
 
+// Records are assembled in LDS -- one lane per atom draws, as the persistent kernel would -- and leave the workgroup as
+// contiguous runs (16 bytes per lane when the record geometry allows it): a record is read back as one stream, and one
+// lane scattering 4-byte scalars into it wrote 36.4 MB for 29.5 MB of payload (1.23x, round-1 PMC).
+constexpr int kStageFloats = 5120;      // >= (256 / N) (N (d + C + 1) + 8) for every N <= 64, d <= 3, C <= 8
 __global__ __launch_bounds__(kBlock) void pc_noise_fill_kernel(NoiseFillArgs p)
 {
-    const int sub = blockIdx.y;                                   // 0 predictor, 1 + m corrector m: uniform per block
+    __shared__ __attribute__((aligned(16))) float stage[kStageFloats];
     const int N = p.N, d = p.d, C = p.C;
-    const int64_t per_it = p.B * N;
-    const int64_t total = per_it * p.n_iterations;
-    const int64_t rec_total = p.rec0 + (int64_t)p.M * p.rec1;
+    const int64_t n_records = p.B * (int64_t)p.n_iterations;      // (iteration, structure) pairs
+    const int rec_total = p.rec0 + p.M * p.rec1;                  // predictor part | M corrector parts
     const uint32_t k0 = (uint32_t)p.rng.seed, k1 = (uint32_t)(p.rng.seed >> 32);
     const uint32_t call8 = p.rng.call << 8;
-    const bool types = sub == 0 || p.types_in_corrector;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t it = t / per_it;
-        const int64_t item = t - it * per_it;                     // b * N + n
-        const int64_t b = item / N;
-        const int n = (int)(item - b * N);
-        const int i = p.start_index - 1 - (int)it;
-        const uint32_t draw = (uint32_t)(sub == 0 ? i + 1 : i) * p.rng.draw_stride + (uint32_t)sub;
-        float* rec = p.out + (it * p.B + b) * rec_total + (sub == 0 ? 0 : p.rec0 + (sub - 1) * p.rec1);
-        const u32x4 r = philox4x32_10((uint32_t)item, call8, draw, MDX_TAG_COORD, k0, k1);
-        float z0, z1, z2 = 0.0f, z3;
-        box_muller(r.v[0], r.v[1], z0, z1);
-        if (d > 2) box_muller(r.v[2], r.v[3], z2, z3);
-        rec[n * d] = z0;
-        if (d > 1) rec[n * d + 1] = z1;
-        if (d > 2) rec[n * d + 2] = z2;
-        if (types) {
-            for (int s4 = 0; s4 * 4 < C; ++s4) {
-                const u32x4 g = philox4x32_10((uint32_t)item, call8 | (uint32_t)s4, draw, MDX_TAG_GUMBEL, k0, k1);
-                for (int l = 0; l < 4 && s4 * 4 + l < C; ++l) rec[N * d + n * C + s4 * 4 + l] = gumbel_from_u(u01(g.v[l]));
-            }
-            if (p.greedy)
-                rec[N * d + N * C + n] = u01(philox4x32_10((uint32_t)item, call8, draw, MDX_TAG_BINARY, k0, k1).v[0]);
-            if (n == 0) {
-                // One atom type: with logits (finite, -inf) the posterior p(a_{t-1} | a_t) of this step is a function of
-                // a_t alone -- evaluated here once per step for a_t = 0 and a_t = MASK with the update's own functions
-                // (same bits), so that the update only selects.  Other class counts: table marked invalid.
-                float* t = rec + N * (d + C + 1);
-                t[7] = 0.0f;
-                if (C == 2) {
-                    const int idx = sub == 0 ? i : (i > 0 ? i - 1 : 0);         // the step's row of the Q tables
-                    const float lgc[2] = {0.0f, -__builtin_huge_valf()};
-                    const FixedSoftmaxC2 fixed = fixed_softmax_c2(p.small_eps);
-                    for (int sel = 0; sel < 2; ++sel) {
-                        float pr[MDX_MAX_CLASSES];
-                        posterior(lgc, sel, p.sched.q + idx * 4, p.sched.qbar + idx * 4, p.sched.qbar_tm1 + idx * 4, 2,
-                                  p.small_eps, pr, fixed);
-                        t[sel] = pr[1];
-                        t[2 + 2 * sel] = logf_(pr[0] + p.small_eps);
-                        t[3 + 2 * sel] = logf_(pr[1] + p.small_eps);
+    // whole records per workgroup pass: as many as the lanes cover (one lane per atom) and the stage holds
+    int R = kBlock / N;
+    if (R > kStageFloats / rec_total) R = kStageFloats / rec_total;
+    const int r_local = threadIdx.x / N, n = threadIdx.x - r_local * N;
+    const bool vec4 = !(rec_total & 3) && !(reinterpret_cast<uintptr_t>(p.out) & 15);
+    for (int64_t r0 = (int64_t)blockIdx.x * R; r0 < n_records; r0 += (int64_t)gridDim.x * R) {
+        const int64_t record = r0 + r_local;                      // = it * B + b
+        if (r_local < R && record < n_records) {
+            const int64_t it = record / p.B;
+            const int64_t b = record - it * p.B;
+            const int64_t item = b * N + n;
+            const int i = p.start_index - 1 - (int)it;
+            for (int sub = 0; sub <= p.M; ++sub) {                // 0 predictor, 1 + m corrector m
+                const bool types = sub == 0 || p.types_in_corrector;
+                const uint32_t draw = (uint32_t)(sub == 0 ? i + 1 : i) * p.rng.draw_stride + (uint32_t)sub;
+                float* rec = stage + r_local * rec_total + (sub == 0 ? 0 : p.rec0 + (sub - 1) * p.rec1);
+                const u32x4 r = philox4x32_10((uint32_t)item, call8, draw, MDX_TAG_COORD, k0, k1);
+                float z0, z1, z2 = 0.0f, z3;
+                box_muller(r.v[0], r.v[1], z0, z1);
+                if (d > 2) box_muller(r.v[2], r.v[3], z2, z3);
+                rec[n * d] = z0;
+                if (d > 1) rec[n * d + 1] = z1;
+                if (d > 2) rec[n * d + 2] = z2;
+                if (!types) continue;
+                for (int s4 = 0; s4 * 4 < C; ++s4) {
+                    const u32x4 g = philox4x32_10((uint32_t)item, call8 | (uint32_t)s4, draw, MDX_TAG_GUMBEL, k0, k1);
+                    for (int l = 0; l < 4 && s4 * 4 + l < C; ++l) rec[N * d + n * C + s4 * 4 + l] = gumbel_from_u(u01(g.v[l]));
+                }
+                // (the slot exists in every type record; without greedy sampling nobody reads it)
+                rec[N * d + N * C + n] = p.greedy ? u01(philox4x32_10((uint32_t)item, call8, draw, MDX_TAG_BINARY, k0, k1).v[0])
+                                                  : 0.0f;
+                if (n == 0) {
+                    // One atom type: with logits (finite, -inf) the posterior p(a_{t-1} | a_t) of this step is a function of
+                    // a_t alone -- evaluated here once per step for a_t = 0 and a_t = MASK with the update's own functions
+                    // (same bits), so that the update only selects.  Other class counts: table marked invalid.
+                    float* t = rec + N * (d + C + 1);
+                    for (int k = 0; k < kP2Table; ++k) t[k] = 0.0f;
+                    if (C == 2) {
+                        const int idx = sub == 0 ? i : (i > 0 ? i - 1 : 0);         // the step's row of the Q tables
+                        const float lgc[2] = {0.0f, -__builtin_huge_valf()};
+                        const FixedSoftmaxC2 fixed = fixed_softmax_c2(p.small_eps);
+                        for (int sel = 0; sel < 2; ++sel) {
+                            float pr[MDX_MAX_CLASSES];
+                            posterior(lgc, sel, p.sched.q + idx * 4, p.sched.qbar + idx * 4, p.sched.qbar_tm1 + idx * 4, 2,
+                                      p.small_eps, pr, fixed);
+                            t[sel] = pr[1];
+                            t[2 + 2 * sel] = logf_(pr[0] + p.small_eps);
+                            t[3 + 2 * sel] = logf_(pr[1] + p.small_eps);
+                        }
+                        t[6] = logf_(0.0f + p.small_eps);
+                        t[7] = 1.0f;
                     }
-                    t[6] = logf_(0.0f + p.small_eps);
-                    t[7] = 1.0f;
                 }
             }
         }
+        __syncthreads();
+        // the staged records are ONE contiguous run of the workspace
+        const int64_t here = n_records - r0 < R ? n_records - r0 : R;
+        float* dst = p.out + r0 * rec_total;
+        if (vec4) {
+            for (int q = threadIdx.x; q < here * (rec_total >> 2); q += kBlock)
+                reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(stage)[q];
+        } else {
+            for (int q = threadIdx.x; q < here * rec_total; q += kBlock) dst[q] = stage[q];
+        }
+        __syncthreads();
     }
 }
 
@@ -2192,6 +2215,8 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
     a.a = atom_types; a.x = x; a.l = l;
     a.rec0 = pc.N * (pc.d + pc.C + 1) + kP2Table;
     a.rec1 = a.types_in_corrector ? a.rec0 : pc.N * pc.d;
+    // a record longer than the pre-pass kernel's LDS stage (many correctors x many classes): draw in-kernel instead
+    if (noise_workspace && !caller_noise && a.rec0 + (int64_t)a.M * a.rec1 > kStageFloats) noise_workspace = nullptr;
     a.noise = noise_workspace;
     // diag_skip bits of the kernel: 1 no forward, 2 no update (diagnostics builds only), 8 no hoisted softmax, 16 no table
     a.diag_skip = ((options & MDX_MLP_SAMPLE_DIAG_NO_FORWARD) ? 1 : 0) | ((options & MDX_MLP_SAMPLE_DIAG_NO_UPDATE) ? 2 : 0) |
@@ -2209,7 +2234,9 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
         nf.types_in_corrector = a.types_in_corrector; nf.greedy = pc.greedy;
         nf.B = batch; nf.N = pc.N; nf.d = pc.d; nf.C = pc.C; nf.rec0 = a.rec0; nf.rec1 = a.rec1; nf.M = a.M;
         nf.out = noise_workspace;
-        hipLaunchKernelGGL(pc_noise_fill_kernel, dim3(flat_grid(batch * pc.N * n_iterations), a.M + 1), dim3(kBlock),
+        int per_pass = kBlock / pc.N;
+        if (per_pass > kStageFloats / (a.rec0 + a.M * a.rec1)) per_pass = kStageFloats / (a.rec0 + a.M * a.rec1);
+        hipLaunchKernelGGL(pc_noise_fill_kernel, dim3(flat_grid(cdiv(batch * n_iterations, per_pass) * kBlock)), dim3(kBlock),
                            0, st, nf);
         if (hipGetLastError() != hipSuccess) return MDX_ERR_HIP;
     }

@@ -4,13 +4,13 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 rm -rf $O/prof_c2_fused
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2_fused -- python3 $R/bench.py --no-cpu-baseline > $O/prof_c2_fused.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2_fused -- python3 $R/bench.py --workload C2 --no-cpu-baseline > $O/prof_c2_fused.log 2>&1
 find $O/prof_c2_fused -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $O/c2_fused_kernel_stats.csv
 echo "kernel trace done" >> $O/heartbeat.txt
 for CTR in FETCH_SIZE WRITE_SIZE; do
   OUT=$O/pmc_c2_fused_${CTR}
   rm -rf $OUT
-  rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --no-cpu-baseline > $O/pmc_c2_fused_${CTR}.log 2>&1
+  rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --workload C2 --no-cpu-baseline > $O/pmc_c2_fused_${CTR}.log 2>&1
   echo "$CTR done" >> $O/heartbeat.txt
   F=$(find $OUT -name '*counter_collection.csv' | head -1)
   python3 - "$F" $CTR <<'PY' | tee -a $GRAFT_REPO_ROOT/gpurun_out/pmc_c2_fused_summary.txt
