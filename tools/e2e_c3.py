@@ -1,5 +1,6 @@
 """One full C3 job end to end: generator.sample(512) with the EGNN (4 x 256, rc 7.5), 1000 iterations x (1 predictor +
-2 correctors), wall clock; checks the result's properties.  ~2 minutes."""
+2 correctors), wall clock (graph capture and warm-up included); checks the result's properties.  ~40 s.
+    python tools/e2e_c3.py [C3|C4] [--no-graph] [--precision=f32]"""
 import json
 import os
 import sys
@@ -14,7 +15,10 @@ import bench  # noqa: E402
 device = torch.device("cuda:0")
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 w = bench.WORKLOADS[name]
-gen, noise, sampling, net = bench.build_generator(w, device, 0, w["batch"], False)
+use_graph = "--no-graph" not in sys.argv
+gen, noise, sampling, net = bench.build_generator(w, device, 0, w["batch"], use_graph)
+precision = next((a.split("=")[1] for a in sys.argv if a.startswith("--precision=")), "f16x3")
+net.edge_chain_precision = precision
 with torch.no_grad():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -23,4 +27,5 @@ with torch.no_grad():
     seconds = time.perf_counter() - t0
 assert (out.A != w["num_atom_types"]).all() and torch.isfinite(out.X).all() and (out.X >= 0).all() and (out.X < 1).all()
 print(json.dumps({"job": f"{name} generator.sample({w['batch']}), {w['noise']['total_time_steps']} iterations, end to end",
+                  "hip_graph": use_graph, "edge_chain": net.edge_chain_precision,
                   "seconds": round(seconds, 2), "structures_per_s": round(w["batch"] / seconds, 4)}))
