@@ -61,6 +61,10 @@ struct ChainArgs {
     float* messages;            // [E][H]
     float* edge_scalar;         // [E]
     uint32_t* status;
+    // MODE 1 (a chain of H -> H layers over the ROWS of a matrix, last layer linear, optional residual): n_edges rows
+    const float* rows_in;       // [M][H]
+    const float* residual;      // [M][H], nullable
+    float* rows_out;            // [M][H]
 };
 
 constexpr float kLog2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f;
@@ -208,18 +212,20 @@ struct Chain {
 // its initial value) -> the next layer's operand registers.  A value beyond the f16 range becomes an infinity in the split
 // and a NaN one layer later, in every feature of its edge: it reaches the kernel's outputs, where it is looked for.  Branch-free, so that it is one scheduling region with the MFMAs around
 // it.  tp, r0, r1 are constants after unrolling.
+// `linear` (wave-uniform): the tile belongs to a layer without activation (the last layer of a row chain): u = z, a select.
 template <int H, int PREC>
-__device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const f32x16& pend, Act<H, PREC>& dst)
+__device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const f32x16& pend, Act<H, PREC>& dst,
+                                                  bool linear = false)
 {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         if (r < r0 || r >= r1) continue;
         if constexpr (PREC == 0) {
-            put<H>(dst, tp, r, silu_scaled(pend[r]));
+            put<H>(dst, tp, r, linear ? pend[r] : silu_scaled(pend[r]));
         } else if (!(r & 1)) {
             // a pair of elements: hi = f16(y) (packed convert), lo = f16(y - hi) with the subtraction straight off the
             // packed halves (v_fma_mix_f32: f16 operand x -1 + f32 operand, exact)
-            const float y0 = silu_scaled(pend[r]), y1 = silu_scaled(pend[r + 1]);
+            const float y0 = linear ? pend[r] : silu_scaled(pend[r]), y1 = linear ? pend[r + 1] : silu_scaled(pend[r + 1]);
             uint32_t hi, lo;
             float l0, l1;
             asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(y0), "v"(y1));
@@ -237,7 +243,9 @@ __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const 
     }
 }
 
-template <int H, int PREC>
+// MODE 0: the EGNN edge chain (gathered first layer, messages + head out).  MODE 1: the same pipeline over the rows of a
+// matrix -- out = residual + W_L (SiLU(W_{L-1} ... SiLU(W_1 x + b_1) ...)) + b_L -- used for the per-node MLP of an EGNN layer.
+template <int H, int PREC, int MODE>
 __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(ChainArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -259,14 +267,16 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     if ((int64_t)blockIdx.x >= n_tiles) return;             // uniform per workgroup
 
     for (int i = threadIdx.x; i < layers * H; i += kWaves * kWave) par[i] = p.biases[i] * kLog2e;
-    for (int i = threadIdx.x; i < H; i += kWaves * kWave) {
-        par_in[i] = p.bias_in[i];
-        par_wr[i] = p.w_radial[i];
+    if constexpr (MODE == 0) {
+        for (int i = threadIdx.x; i < H; i += kWaves * kWave) {
+            par_in[i] = p.bias_in[i];
+            par_wr[i] = p.w_radial[i];
+        }
     }
     __syncthreads();
 
     C ch;
-    ch.image = p.image; ch.chunks_total = layers * NT + 1; ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
+    ch.image = p.image; ch.chunks_total = layers * NT + (MODE == 0 ? 1 : 0); ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
     ch.ring = ring; ch.wave = wave; ch.lane = lane;
     ch.stores_behind = false;
     ch.rot = (int)((blockIdx.x * 5u) & (unsigned)(C::CHUNK / 1024 - 1));
@@ -308,19 +318,19 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     bool out_of_range = false;       // split-f16: a non-finite output (see epilogue_elements)
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         MDX_STAMP(9);
-        // ---- this lane's edge ------------------------------------------------------------------------------------
+        // ---- this lane's edge (or row) -----------------------------------------------------------------------------
         const int64_t e_raw = tile * kTileEdges + wave * 32 + col;
         const bool live = e_raw < n_edges;
         const int64_t e = live ? e_raw : n_edges - 1;
-        const int64_t src = p.edges[2 * e], dst = p.edges[2 * e + 1];
-        float radial = 0.0f;
-        for (int k = 0; k < p.D; ++k) {
-            const float dlt = p.coord[src * p.D + k] - p.coord[dst * p.D + k];
-            radial += dlt * dlt;
-        }
-        // ---- first message layer, straight into B-operand registers ------------------------------------------------
         Act<H, PREC> xa, xb;
-        {
+        if constexpr (MODE == 0) {
+            const int64_t src = p.edges[2 * e], dst = p.edges[2 * e + 1];
+            float radial = 0.0f;
+            for (int k = 0; k < p.D; ++k) {
+                const float dlt = p.coord[src * p.D + k] - p.coord[dst * p.D + k];
+                radial += dlt * dlt;
+            }
+            // first message layer, straight into B-operand registers
             const float* ps = p.node_proj + src * 2 * H + 4 * h;
             const float* pd = p.node_proj + dst * 2 * H + H + 4 * h;
 #pragma unroll
@@ -341,6 +351,16 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 // hoisting all of them costs 256 registers
                 if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
+            // the row itself (the caller's activations, carried as log2(e) x inside the chain)
+            const float* px = p.rows_in + e * H + 4 * h;
+#pragma unroll
+            for (int q = 0; q < H / 8; ++q) {
+                const f32x4 a = *(const f32x4*)(px + 8 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) put<H>(xa, q >> 2, 4 * (q & 3) + i, a[i] * kLog2e);
+                if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+            }
         }
         MDX_STAMP(10);
         // ---- the chain ----------------------------------------------------------------------------------------------
@@ -349,7 +369,8 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         // One tile: the MFMAs of (layer, t) from operand registers `in`; beside them (a) the outstanding epilogue, which
         // writes tile `tp` of `epi_dst`, (b) from the middle on, the reads of the NEXT tile's first fragments and bias
         // (next_bias == nullptr: that tile starts from zero -- the head).
-        auto run_tile = [&](const Act<H, PREC>& in, bool have, int tp, Act<H, PREC>& epi_dst, const lds_f* next_bias) -> f32x16 {
+        auto run_tile = [&](const Act<H, PREC>& in, bool have, int tp, Act<H, PREC>& epi_dst, const lds_f* next_bias,
+                            bool linear = false) -> f32x16 {
             MDX_STAMP(4);
             f32x16 acc = acc_next;
             Frag fr[STEPS + PFD];
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #endif
                 if (s == STEPS - 1) acc_next = read_bias(next_bias);
 #if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 16))
-                if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst);
+                if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, MODE == 1 && linear);
 #else
                 if (have && s == 0) asm volatile("" ::"v"(pend));      // keep the MFMAs alive without their epilogue
 #endif
@@ -397,10 +418,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             const lds_f* bias = par + l * H;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                // the tile after this one: the next tile of this layer, the first of the next layer, or the head (no bias)
-                const lds_f* next_bias = t + 1 < NT ? bias + 32 * (t + 1) : (l + 1 < layers ? bias + H : nullptr);
+                // the tile after this one: the next tile of this layer, the first of the next layer, or -- after the last
+                // layer -- the head (no bias; MODE 0) / layer 0 of the next rows (MODE 1)
+                const lds_f* next_bias = t + 1 < NT ? bias + 32 * (t + 1) : (l + 1 < layers ? bias + H : (MODE == 0 ? nullptr : par));
+                // the epilogue beside tile 0 belongs to the previous layer (never the linear one); the others to this layer
                 if (t == 0) pend = run_tile(in, !FIRST, NT - 1, in, next_bias);
-                else pend = run_tile(in, true, t - 1, out, next_bias);
+                else pend = run_tile(in, true, t - 1, out, next_bias, l == layers - 1);
             }
         };
         // messages = the operand registers of the first coordinate layer, complete once its first tile has run
@@ -448,14 +471,70 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             if constexpr (PREC == 1) out_of_range = out_of_range || (live && !(__builtin_fabsf(acc[0]) <= 3.0e38f));
             if (live && h == 0) p.edge_scalar[e] = acc[0];
         };
+        // MODE 1: the last tile of the last (linear) layer has no tile after it to run beside; then out = residual + y
+        auto finish_rows = [&](Act<H, PREC>& y) {
+            epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, y, true);
+            const float* res = p.residual ? p.residual + e * H + 4 * h : nullptr;
+            float* row = p.rows_out + e * H + 4 * h;
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < H / 8; ++q) {
+                    f32x4 v;
+                    const int t = q >> 2, r0 = 4 * (q & 3);
+                    if constexpr (PREC == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = y.v[16 * t + r0 + i] * kLn2;
+                    } else {
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 vh = __builtin_bit_cast(u32x4, y.hi[2 * t + (r0 >> 3)]), vl = __builtin_bit_cast(u32x4, y.lo[2 * t + (r0 >> 3)]);
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const uint32_t ph = vh[((r0 & 7) >> 1) + pr], pl = vl[((r0 & 7) >> 1) + pr];
+                            float y0, y1;
+                            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(ph), "v"(pl));
+                            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(y1) : "v"(ph), "v"(pl));
+                            v[2 * pr] = y0 * kLn2;
+                            v[2 * pr + 1] = y1 * kLn2;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) out_of_range = out_of_range || !(__builtin_fabsf(v[i]) <= 3.0e38f);
+                    }
+                    if (res) {
+                        const f32x4 r4 = *(const f32x4*)(res + 8 * q);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = r4[i] + v[i];
+                    }
+                    *(f32x4*)(row + 8 * q) = v;
+                    if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // (bounds the hoisting of the residual loads)
+                }
+            }
+            ch.stores_behind = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(live) != 0);
+        };
         layer(std::true_type{}, xa, xb, 0);
-        for (int l = 1;;) {
-            layer(std::false_type{}, xb, xa, l);
-            if (l == p.n_message) store_messages(xb);
-            if (++l >= layers) { head_tile(xa); break; }
-            layer(std::false_type{}, xa, xb, l);
-            if (l == p.n_message) store_messages(xa);
-            if (++l >= layers) { head_tile(xb); break; }
+        bool done = false;
+        if constexpr (MODE == 1) {                      // (the edge chain always has a message and a coordinate layer)
+            if (layers == 1) {
+                finish_rows(xb);
+                done = true;
+            }
+        }
+        if (!done) {
+            for (int l = 1;;) {
+                layer(std::false_type{}, xb, xa, l);
+                if (MODE == 0 && l == p.n_message) store_messages(xb);
+                if (++l >= layers) {
+                    if constexpr (MODE == 0) head_tile(xa);
+                    else finish_rows(xa);
+                    break;
+                }
+                layer(std::false_type{}, xa, xb, l);
+                if (MODE == 0 && l == p.n_message) store_messages(xa);
+                if (++l >= layers) {
+                    if constexpr (MODE == 0) head_tile(xb);
+                    else finish_rows(xb);
+                    break;
+                }
+            }
         }
     }
     // requests still in flight target this workgroup's LDS: let them land before the workgroup ends
@@ -486,7 +565,7 @@ __global__ __launch_bounds__(256) void egnn_chain_pack_kernel(PackArgs p)
         (void)NT;
         const bool head = l == p.layers;
         auto weight = [&](int n, int k) -> float {
-            if (head) return n == 0 ? p.w_out[k] * kLn2 : 0.0f;       // the chain carries log2(e) x activation
+            if (head) return (n == 0 && p.w_out) ? p.w_out[k] * kLn2 : 0.0f;       // the chain carries log2(e) x activation
             return p.w[l][(int64_t)n * H + k];
         };
         if (p.precision == 0) {
@@ -528,16 +607,16 @@ __global__ __launch_bounds__(256) void egnn_coord_aggregate_kernel(const float* 
     }
 }
 
-template <int H, int PREC>
+template <int H, int PREC, int MODE>
 int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
 {
     using C = Chain<H, PREC>;
     const size_t lds = (size_t)kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H);
-    static bool granted[64] = {};
+    static bool granted[64] = {};       // (one flag per instantiation: function-local static of a template)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MDX_ERR_HIP;
     if (lds > 64 * 1024 && !granted[dev]) {
-        if (hipFuncSetAttribute((const void*)egnn_edge_chain_kernel<H, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)egnn_edge_chain_kernel<H, PREC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return MDX_ERR_HIP;
         granted[dev] = true;
@@ -547,7 +626,7 @@ int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);       // persistent: one workgroup per CU
-    hipLaunchKernelGGL((egnn_edge_chain_kernel<H, PREC>), dim3(grid), dim3(kWaves * kWave), lds, st, a);
+    hipLaunchKernelGGL((egnn_edge_chain_kernel<H, PREC, MODE>), dim3(grid), dim3(kWaves * kWave), lds, st, a);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 
@@ -564,8 +643,7 @@ int64_t mdx_egnn_chain_image_bytes(int hidden, int n_layers)
 int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, const float* w_out, int hidden, int precision,
                         void* image_out, mdx_stream_t stream)
 {
-    if (!weights_host || !w_out || !image_out || n_layers < 1 || (precision != 0 && precision != 1))
-        return MDX_ERR_INVALID_ARG;
+    if (!weights_host || !image_out || n_layers < 1 || (precision != 0 && precision != 1)) return MDX_ERR_INVALID_ARG;
     if (n_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     if (hidden != 32 && hidden != 64 && hidden != 128 && hidden != 256) return MDX_ERR_UNSUPPORTED;
     PackArgs a{};
@@ -611,7 +689,7 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
     const int layers = a.n_message + a.n_coord;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define MDX_CHAIN_CASE(HH)                                                                         \
-    case HH: return c->precision == 0 ? launch_chain<HH, 0>(a, layers, st) : launch_chain<HH, 1>(a, layers, st);
+    case HH: return c->precision == 0 ? launch_chain<HH, 0, 0>(a, layers, st) : launch_chain<HH, 1, 0>(a, layers, st);
     switch (c->hidden) {
         MDX_CHAIN_CASE(32)
         MDX_CHAIN_CASE(64)
@@ -619,6 +697,33 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
         MDX_CHAIN_CASE(256)
     }
 #undef MDX_CHAIN_CASE
+    return MDX_ERR_UNSUPPORTED;
+}
+
+int mdx_mlp_chain_rows(const mdx_egnn_chain_t* c, const float* x, const float* residual, int64_t n_rows,
+                       const int64_t* n_rows_dev, float* out, uint32_t* status, mdx_stream_t stream)
+{
+    if (!c || n_rows < 0) return MDX_ERR_INVALID_ARG;
+    if (c->n_message_layers < 1 || c->n_coord_layers != 0 || (c->precision != 0 && c->precision != 1)) return MDX_ERR_INVALID_ARG;
+    if (c->n_message_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
+    if (c->hidden != 32 && c->hidden != 64 && c->hidden != 128 && c->hidden != 256) return MDX_ERR_UNSUPPORTED;
+    if (n_rows == 0) return MDX_OK;
+    if (!c->weight_image || !c->biases || !x || !out) return MDX_ERR_INVALID_ARG;
+    ChainArgs a{};
+    a.image = (const char*)c->weight_image; a.biases = c->biases;
+    a.n_edges_dev = n_rows_dev; a.n_edges = n_rows; a.n_message = c->n_message_layers; a.n_coord = 0; a.D = 0;
+    a.rows_in = x; a.residual = residual; a.rows_out = out; a.status = status;
+    const int layers = a.n_message;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define MDX_ROWS_CASE(HH)                                                                          \
+    case HH: return c->precision == 0 ? launch_chain<HH, 0, 1>(a, layers, st) : launch_chain<HH, 1, 1>(a, layers, st);
+    switch (c->hidden) {
+        MDX_ROWS_CASE(32)
+        MDX_ROWS_CASE(64)
+        MDX_ROWS_CASE(128)
+        MDX_ROWS_CASE(256)
+    }
+#undef MDX_ROWS_CASE
     return MDX_ERR_UNSUPPORTED;
 }
 

@@ -585,7 +585,7 @@ class EdgeChainPack:
         self.c_struct = _hip.EgnnChain(H, len(list(message_layers)), len(list(coord_layers)),
                                        EDGE_CHAIN_PRECISIONS[precision], self.image.data_ptr(), self.biases.data_ptr(),
                                        self.bias_in.data_ptr(), self.w_radial.data_ptr())
-        self._keep = []                    # the image holds its own copy of the matrices
+        self._keep = []                    # the image holds its own copy (temporaries are freed in stream order)
         self.device = dev
 
     @staticmethod
@@ -597,6 +597,50 @@ class EdgeChainPack:
                 all(l.in_features == H and l.out_features == H and l.bias is not None for l in layers) and
                 first_message_layer.bias is not None and coord_out_layer.in_features == H and
                 coord_out_layer.out_features == 1 and coord_out_layer.bias is None)
+
+
+class RowChainPack:
+    """Device image of a chain of H -> H nn.Linear layers applied to the rows of a matrix (mdx_mlp_chain_rows): every layer
+    but the last is followed by SiLU.  Used for the per-node MLP of an EGNN layer after its first (2H -> H) layer."""
+
+    def __init__(self, layers, precision: str):
+        layers = list(layers)
+        H = layers[0].in_features
+        if precision not in EDGE_CHAIN_PRECISIONS:
+            raise _hip.MdxError(f"chain precision must be one of {sorted(EDGE_CHAIN_PRECISIONS)}; got {precision!r}")
+        if not self.supported(layers):
+            raise _hip.MdxError("this layer stack is not covered by mdx_mlp_chain_rows")
+        dev = layers[0].weight.device
+        self.precision, self.hidden = precision, H
+        keep = [layer.weight.detach().to(F32).contiguous() for layer in layers]
+        self.image = torch.empty(lib().mdx_egnn_chain_image_bytes(H, len(layers)), dtype=torch.uint8, device=dev)
+        array = (C.c_void_p * len(layers))(*[w.data_ptr() for w in keep])
+        with torch.cuda.device(dev):
+            check(lib().mdx_egnn_chain_pack(array, len(layers), None, H, EDGE_CHAIN_PRECISIONS[precision],
+                                            C.c_void_p(self.image.data_ptr()), stream_handle()), "mdx_egnn_chain_pack")
+        self.biases = torch.stack([layer.bias.detach().to(F32) for layer in layers]).contiguous()
+        self.c_struct = _hip.EgnnChain(H, len(layers), 0, EDGE_CHAIN_PRECISIONS[precision], self.image.data_ptr(),
+                                       self.biases.data_ptr(), None, None)
+
+    @staticmethod
+    def supported(layers) -> bool:
+        layers = list(layers)
+        if not layers:
+            return False
+        H = layers[0].in_features
+        return (H in (32, 64, 128, 256) and len(layers) <= _hip.EGNN_CHAIN_MAX_LAYERS and
+                all(l.in_features == H and l.out_features == H and l.bias is not None for l in layers))
+
+
+def mlp_chain_rows(pack: RowChainPack, x, residual=None, status=None) -> torch.Tensor:
+    """residual + chain(x) over the rows of x [M, H] (mdx_mlp_chain_rows)."""
+    M, H = x.shape
+    assert H == pack.hidden and (residual is None or residual.shape == x.shape)
+    out = torch.empty_like(x)
+    rc = lib().mdx_mlp_chain_rows(C.byref(pack.c_struct), ptr(x, F32, "x"), ptr(residual, F32, "residual"), M, None,
+                                  ptr(out, F32, "out"), ptr(status, I32, "status"), stream_handle())
+    check(rc, "mdx_mlp_chain_rows")
+    return out
 
 
 def egnn_edge_chain(pack: EdgeChainPack, node_proj, coord, edges, status=None, n_edges_dev=None):

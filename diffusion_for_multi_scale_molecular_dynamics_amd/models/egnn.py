@@ -84,6 +84,7 @@ class E_GCL(nn.Module):
         self.edge_chain_precision = "f16x3"
         self.status_word = None          # device int32 word for MDX_STATUS_EGNN_F16_RANGE (set by the score network)
         self._chain = (None, None)       # (stamp, kernels.EdgeChainPack)
+        self._node_chain = (None, None)  # (stamp, kernels.RowChainPack): the node MLP after its first layer
 
         mh, nh, ch = message_hidden_dimensions_size, node_hidden_dimensions_size, coordinate_hidden_dimensions_size
         layers = [nn.Linear(2 * input_size + 1, mh), act_fn]
@@ -107,6 +108,13 @@ class E_GCL(nn.Module):
 
         if attention:
             self.att_mlp = nn.Sequential(nn.Linear(mh, 1), nn.Sigmoid())
+
+    def __getstate__(self):
+        """Copies and pickles of the module (copy.deepcopy, torch.save of a whole model) carry no device images: the packs
+        hold raw pointers and are rebuilt on first use."""
+        state = dict(self.__dict__)
+        state["_chain"], state["_node_chain"], state["status_word"] = (None, None), (None, None), None
+        return state
 
     def _messages(self, h: torch.Tensor, edge_index: torch.Tensor, radial: torch.Tensor, fused: bool) -> torch.Tensor:
         first = self.message_mlp[0]
@@ -163,6 +171,26 @@ class E_GCL(nn.Module):
             self._chain = (stamp, kernels.EdgeChainPack(*modules, input_size=self.input_size,
                                                         precision=self.edge_chain_precision))
         return self._chain[1]
+
+    def _node_chain_pack(self):
+        """kernels.RowChainPack of the node MLP's H -> H layers (all but its first, 2H -> H, layer), or None when the stack
+        is not Linear / SiLU alternation of equal widths ending in a Linear."""
+        if self.edge_chain_precision is None:
+            return None
+        node = list(self.node_mlp)
+        if len(node) < 3 or len(node) % 2 == 0:
+            return None
+        linears, acts = node[0::2], node[1::2]
+        if not all(isinstance(lin, nn.Linear) for lin in linears) or not all(isinstance(a, nn.SiLU) for a in acts):
+            return None
+        rest = linears[1:]
+        from .. import kernels
+        if linears[0].out_features != rest[0].in_features or not kernels.RowChainPack.supported(rest):
+            return None
+        stamp = (self.edge_chain_precision,) + tuple((t.data_ptr(), t._version) for lin in rest for t in (lin.weight, lin.bias))
+        if self._node_chain[0] != stamp:
+            self._node_chain = (stamp, kernels.RowChainPack(rest, self.edge_chain_precision))
+        return self._node_chain[1]
 
     def _coord_head_is_plain(self) -> bool:
         last = self.coord_mlp[-1]
@@ -231,7 +259,16 @@ class E_GCL(nn.Module):
                                                         n_edges_dev=n_edges)
         coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean)
         agg = kernels.segment_rows(messages, offsets, degree, self.message_mean)
-        out = run_mlp(self.node_mlp, torch.cat([h, agg], dim=1), True)
+        node_in = torch.cat([h, agg], dim=1)
+        node_pack = self._node_chain_pack()
+        if node_pack is not None and (not self.residual or h.shape[1] == node_pack.hidden):
+            # first node layer (2H -> H, + SiLU): library GEMM per node; the other layers and the residual: one MFMA launch
+            first = self.node_mlp[0]
+            hidden = kernels.linear_act(node_in, first.weight, first.bias, True)
+            out = kernels.mlp_chain_rows(node_pack, hidden, residual=h.contiguous() if self.residual else None,
+                                         status=self.status_word)
+            return out, coord_out
+        out = run_mlp(self.node_mlp, node_in, True)
         if self.residual:
             out = h + out
         return out, coord_out

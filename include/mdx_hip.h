@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 4
+#define MDX_ABI_VERSION 5
 
 /* status codes */
 #define MDX_OK 0
@@ -374,6 +374,12 @@ MDX_API int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, 
 MDX_API int mdx_egnn_edge_chain(const mdx_egnn_chain_t* chain_host, const float* node_proj, const float* coord,
                                 int coord_dimension, const int64_t* edges, int64_t n_edges, const int64_t* n_edges_dev,
                                 float* messages_out, float* edge_scalar_out, uint32_t* status, mdx_stream_t stream);
+/* The same pipeline over the ROWS of a matrix (the per-node MLP of an EGNN layer, models/egnn.py:202-230, after its first
+ * layer): out[r,:] = residual[r,:] + W_L (SiLU(W_{L-1} ... SiLU(W_1 x[r,:] + b_1) ...)) + b_L -- L = chain->n_message_layers
+ * layers of H x H (chain->n_coord_layers must be 0; bias_in / w_radial unused; image packed with w_out = NULL), every layer
+ * but the last followed by SiLU; residual nullable; x, residual, out [n_rows, H] row-major; n_rows_dev nullable as above. */
+MDX_API int mdx_mlp_chain_rows(const mdx_egnn_chain_t* chain_host, const float* x, const float* residual, int64_t n_rows,
+                               const int64_t* n_rows_dev, float* out, uint32_t* status, mdx_stream_t stream);
 /* coord_out[i,:] = coord[i,:] + (1/degree_i if mean) sum_{e in segment i} (coord[i,:] - coord[dst_e,:]) edge_scalar[e]
  * -- E_GCL.coord_model's trans = coord_diff * coord_mlp(m), unsorted_segment_sum / _mean and the residual add
  * (models/egnn.py:162-200), on the sorted segments; no atomics, fixed summation order. */

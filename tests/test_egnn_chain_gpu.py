@@ -164,8 +164,7 @@ def test_egnn_forward_edge_chain_modes(cuda, hidden, n_layers, n_hidden):
             outs[mode] = net(batch, conditional=False)
         net.check_status()
     assert net.egnn.graph_layers[0]._chain[1] is not None           # the MFMA kernel really ran
-    for layer in net.egnn.graph_layers:
-        layer._chain = (None, None)                                  # (packs hold raw pointers: not deep-copyable)
+    assert net.egnn.graph_layers[0]._node_chain[1] is not None      # ... and the row chain of the node MLP
     # fp64 yardstick: the same module in double precision on the same edges
     import copy
     net64 = copy.deepcopy(net).double()
@@ -320,3 +319,35 @@ def test_sampler_recomputes_in_f32_when_the_f16_range_is_left(cuda):
         outs[mode] = out
     assert torch.equal(outs["f16x3"].A, outs["f32"].A) and torch.equal(outs["f16x3"].X, outs["f32"].X)
     assert torch.isfinite(outs["f32"].X).all()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("H,n_layers,M,with_residual", [(32, 1, 77, True), (64, 2, 500, False), (128, 3, 129, True),
+                                                        (256, 5, 1500, True)])
+def test_mlp_chain_rows_against_fp64(cuda, precision, H, n_layers, M, with_residual):
+    """mdx_mlp_chain_rows (the edge-chain pipeline over the rows of a matrix; last layer linear; optional residual) against
+    the fp64 evaluation of the same layer stack; M not a multiple of the 128-row tile."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    torch.manual_seed(H + n_layers)
+    layers = [torch.nn.Linear(H, H) for _ in range(n_layers)]
+    for layer in layers:
+        with torch.no_grad():
+            layer.weight.mul_(1.7)
+    x = torch.randn(M, H)
+    res = torch.randn(M, H) if with_residual else None
+    y = x.double()
+    for k, layer in enumerate(layers):
+        y = y @ layer.weight.double().t() + layer.bias.double()
+        if k < n_layers - 1:
+            y = torch.nn.functional.silu(y)
+    want = y + (res.double() if with_residual else 0)
+    dev_layers = [layer.to(cuda) for layer in layers]
+    pack = kernels.RowChainPack(dev_layers, precision)
+    status = torch.zeros(1, dtype=torch.int32, device=cuda)
+    got = kernels.mlp_chain_rows(pack, x.to(cuda), None if res is None else res.to(cuda), status=status)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and torch.isfinite(got).all()
+    tol = TOLERANCE[precision]
+    assert _rel_l2(got, want) < tol, (precision, H, _rel_l2(got, want))
+    row_err = ((got.double().cpu() - want.detach()).norm(dim=1) / want.detach().norm(dim=1).clamp(min=1e-30)).max()
+    assert float(row_err) < 20 * tol, float(row_err)
