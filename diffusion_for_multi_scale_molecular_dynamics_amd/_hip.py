@@ -21,14 +21,14 @@ MAX_CLASSES = 8
 TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
     TAG_INIT_LATTICE, TAG_RESAMPLE_Z, TAG_RESAMPLE_U = range(11)
 
-ABI_VERSION = 5          # MDX_ABI_VERSION of include/mdx_hip.h
+ABI_VERSION = 6          # MDX_ABI_VERSION of include/mdx_hip.h
 ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
     "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_radius_graph_fill_capped", "mdx_mlp_forward",
     "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_variant", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
-    "mdx_egnn_chain_image_bytes", "mdx_egnn_chain_pack", "mdx_egnn_edge_chain", "mdx_mlp_chain_rows", "mdx_egnn_coord_aggregate",
+    "mdx_egnn_chain_image_bytes", "mdx_egnn_chain_pack", "mdx_egnn_edge_chain", "mdx_segment_combine", "mdx_mlp_chain_rows", "mdx_egnn_coord_aggregate",
     "mdx_rng_fill", "mdx_math_probe",
 )
 MLP_MAX_HIDDEN = 8
@@ -80,7 +80,8 @@ class Mlp(C.Structure):
 
 class EgnnChain(C.Structure):
     """mdx_egnn_chain_t"""
-    _fields_ = [(n, C.c_int32) for n in ("hidden", "n_message_layers", "n_coord_layers", "precision")] + \
+    _fields_ = [(n, C.c_int32) for n in ("hidden", "n_message_layers", "n_coord_layers", "precision", "message_mode",
+                                         "reserved")] + \
         [(n, C.c_void_p) for n in ("weight_image", "biases", "bias_in", "w_radial")]
 
 
@@ -181,6 +182,8 @@ def _declare(L):
     L.mdx_egnn_chain_pack.argtypes = [C.POINTER(vp), i32, vp, i32, i32, vp, vp]
     L.mdx_egnn_edge_chain.restype = i32
     L.mdx_egnn_edge_chain.argtypes = [C.POINTER(EgnnChain), vp, vp, i32, vp, i64, vp, vp, vp, vp, vp]
+    L.mdx_segment_combine.restype = i32
+    L.mdx_segment_combine.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp]
     L.mdx_mlp_chain_rows.restype = i32
     L.mdx_mlp_chain_rows.argtypes = [C.POINTER(EgnnChain), vp, vp, i64, vp, vp, vp, vp]
     L.mdx_egnn_coord_aggregate.restype = i32

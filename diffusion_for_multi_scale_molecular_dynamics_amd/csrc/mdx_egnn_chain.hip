@@ -58,6 +58,7 @@ struct ChainArgs {
     const int64_t* n_edges_dev; // nullable: device-resident edge count (<= n_edges)
     int64_t n_edges;
     int n_message, n_coord, D;
+    int piece_sums;             // MODE 0: messages_out receives per-node PIECE SUMS instead of the messages (see aggregate_pieces)
     float* messages;            // [E][H]
     float* edge_scalar;         // [E]
     uint32_t* status;
@@ -158,13 +159,37 @@ struct Chain {
     // before the current one -- every wavefront is past that one.  Returns the LDS address of the next chunk.
     bool stores_behind;     // the message stores of this tile were issued after the last chunk request: they are younger
                             // than the chunk waited for next, so that wait may leave them pending too
+    int stores_count;       // the same for a data-dependent number of stores (piece sums): at least this many were issued
 
     __device__ __forceinline__ lds_c* acquire_next()
     {
         // this wavefront's share of the next chunk has landed once at most LPW younger requests (the chunk after it) are
         // pending; the barrier extends that to every wavefront's share
         MDX_STAMP(1);
-        if (stores_behind) {
+        if (stores_count > 0) {
+            // leave up to LPW requests + the youngest stores pending (any lower bound of the store count is safe)
+            const int k = stores_count >= 48 ? 48 : (stores_count >= 32 ? 32 : (stores_count >= 16 ? 16 : (stores_count >= 8 ? 8 : 0)));
+            stores_count = 0;
+            if constexpr (LPW == 8) {
+                if (k == 48) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+                else if (k == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+                else if (k == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                else if (k == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else if constexpr (LPW == 4) {
+                if (k == 48) asm volatile("s_waitcnt vmcnt(52)" ::: "memory");
+                else if (k == 32) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+                else if (k == 16) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                else if (k == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else if constexpr (LPW == 2) {
+                if (k >= 8) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                if (k >= 8) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            }
+        } else if (stores_behind) {
             // H / 8 store instructions were issued behind the youngest chunk request
             if constexpr (LPW == 8) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
             else if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
@@ -261,6 +286,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     lds_f* par = (lds_f*)(lds_raw + kRing * C::CHUNK);      // [layers][H] biases | bias_in | w_radial
     lds_f* par_in = par + layers * H;
     lds_f* par_wr = par_in + H;
+    // per-wavefront staging for the in-kernel message aggregation: one 32-feature slice of the wavefront's 32 edges
+    // ([edge][36]: the row pad keeps the 16-byte writes off each other's banks) + the edges' source nodes
+    constexpr int kSegRow = 36;
+    lds_f* seg_all = par_wr + H;
+    lds_f* seg = seg_all + wave * (32 * kSegRow + 32);
+    __attribute__((address_space(3))) int* seg_src = (__attribute__((address_space(3))) int*)(seg + 32 * kSegRow);
 
     const int64_t n_edges = p.n_edges_dev ? (*p.n_edges_dev < p.n_edges ? *p.n_edges_dev : p.n_edges) : p.n_edges;
     const int64_t n_tiles = (n_edges + kTileEdges - 1) / kTileEdges;
@@ -279,6 +310,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     ch.image = p.image; ch.chunks_total = layers * NT + (MODE == 0 ? 1 : 0); ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
     ch.ring = ring; ch.wave = wave; ch.lane = lane;
     ch.stores_behind = false;
+    ch.stores_count = 0;
     ch.rot = (int)((blockIdx.x * 5u) & (unsigned)(C::CHUNK / 1024 - 1));
 
     // Weight fragments of a k-step, and the state that flows from one tile to the next: the LDS address of the tile's
@@ -325,6 +357,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         Act<H, PREC> xa, xb;
         if constexpr (MODE == 0) {
             const int64_t src = p.edges[2 * e], dst = p.edges[2 * e + 1];
+            if (p.piece_sums && h == 0) seg_src[col] = (int)src;      // (node indices fit 31 bits: checked on the host)
             float radial = 0.0f;
             for (int k = 0; k < p.D; ++k) {
                 const float dlt = p.coord[src * p.D + k] - p.coord[dst * p.D + k];
@@ -463,6 +496,73 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             }
             ch.stores_behind = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(live) != 0);
         };
+        // Message aggregation inside the kernel (piece_sums): the edges are sorted by source node, so a node's edges are a
+        // run of consecutive lanes.  Per 32-feature slice the wavefront stages its 32 x 32 block in LDS, then lane (f, half)
+        // walks the 16 edges of its half and adds feature f up, emitting the running sum whenever the source node changes
+        // and at the end of the half: a PIECE = the sum over a node's edges inside one 16-edge group, written to the row of
+        // the piece's last edge (128 contiguous bytes per half-wavefront store).  mdx_segment_combine adds a node's pieces
+        // (its last row and every row = 15 mod 16 inside its segment) in row order: fixed order, no atomics.  The messages
+        // themselves never reach memory.  Returns the number of store instructions issued (for the next chunk wait).
+        auto aggregate_pieces = [&](const Act<H, PREC>& m) -> int {
+            const int64_t wave_base = tile * kTileEdges + wave * 32;
+            const int n_live = n_edges - wave_base >= 32 ? 32 : (n_edges > wave_base ? (int)(n_edges - wave_base) : 0);
+            const int f = lane & 31, half = lane >> 5;
+            // boundary mask of this lane's half: bit i set = the piece ends AFTER edge 16 half + i
+            uint32_t ends = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e0 = 16 * half + i;
+                const bool last = i == 15 || e0 + 1 >= n_live || seg_src[e0 + 1] != seg_src[e0];
+                if (e0 < n_live && last) ends |= 1u << i;
+            }
+            int stores = 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                // stage slice t: lane (col, h) holds features 32 t + 8 g + 4 h + (0..3) of its edge
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 y;
+                    if constexpr (PREC == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) y[i] = m.v[16 * t + 4 * g + i] * kLn2;
+                    } else {
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const int r0 = 4 * g;
+                        const u32x4 vh = __builtin_bit_cast(u32x4, m.hi[2 * t + (r0 >> 3)]), vl = __builtin_bit_cast(u32x4, m.lo[2 * t + (r0 >> 3)]);
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const uint32_t ph = vh[((r0 & 7) >> 1) + pr], pl = vl[((r0 & 7) >> 1) + pr];
+                            float y0, y1;
+                            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(ph), "v"(pl));
+                            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(y1) : "v"(ph), "v"(pl));
+                            y[2 * pr] = y0 * kLn2;
+                            y[2 * pr + 1] = y1 * kLn2;
+                        }
+                    }
+                    *(__attribute__((address_space(3))) f32x4*)(seg + col * kSegRow + 8 * g + 4 * h) = y;
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                float acc = 0.0f;
+                float* out = p.messages + (wave_base + 16 * half) * H + 32 * t + f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    acc += seg[(16 * half + i) * kSegRow + f];
+                    if (ends & (1u << i)) {
+                        if constexpr (PREC == 1) out_of_range = out_of_range || !(__builtin_fabsf(acc) <= 3.0e38f);
+                        out[(int64_t)i * H] = acc;
+                        acc = 0.0f;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);         // one slice at a time: the register file is full here
+            }
+            // store instructions this wavefront issued: one per (slice, bit set in either half's mask) -- wave-uniform
+            const uint32_t m0 = __builtin_amdgcn_readlane(ends, 0), m1 = __builtin_amdgcn_readlane(ends, 32);
+            stores = NT * __builtin_popcount(m0 | m1);
+            return stores;
+        };
         // the head: one more tile whose image row 0 is w_out (no bias, no activation): s_e = row 0 of the accumulator
         auto head_tile = [&](Act<H, PREC>& in) {
             Act<H, PREC> unused;
@@ -521,14 +621,20 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         if (!done) {
             for (int l = 1;;) {
                 layer(std::false_type{}, xb, xa, l);
-                if (MODE == 0 && l == p.n_message) store_messages(xb);
+                if (MODE == 0 && l == p.n_message) {
+                    if (p.piece_sums) ch.stores_count = aggregate_pieces(xb);
+                    else store_messages(xb);
+                }
                 if (++l >= layers) {
                     if constexpr (MODE == 0) head_tile(xa);
                     else finish_rows(xa);
                     break;
                 }
                 layer(std::false_type{}, xa, xb, l);
-                if (MODE == 0 && l == p.n_message) store_messages(xa);
+                if (MODE == 0 && l == p.n_message) {
+                    if (p.piece_sums) ch.stores_count = aggregate_pieces(xa);
+                    else store_messages(xa);
+                }
                 if (++l >= layers) {
                     if constexpr (MODE == 0) head_tile(xb);
                     else finish_rows(xb);
@@ -607,11 +713,36 @@ __global__ __launch_bounds__(256) void egnn_coord_aggregate_kernel(const float* 
     }
 }
 
+// out[i,:] = (1/degree_i if mean) x sum of node i's pieces: rows e with e in [offset_i, offset_i + degree_i) and
+// (e % 16 == 15 or e == offset_i + degree_i - 1), in increasing e.  One wavefront per node, 16 bytes per lane.
+__global__ __launch_bounds__(256) void segment_combine_kernel(const float* __restrict__ pieces, const int64_t* __restrict__ offsets,
+                                                              const int64_t* __restrict__ degree, int64_t n_nodes, int H,
+                                                              int mean, float* __restrict__ out)
+{
+    const int lane = threadIdx.x % kWave;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / kWave;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) / kWave;
+    const int quads = H >> 2;
+    for (int64_t node = wave; node < n_nodes; node += n_waves) {
+        const int64_t e0 = offsets[node], deg = degree[node], e1 = e0 + deg;
+        const float scale = (mean && deg > 0) ? 1.0f / (float)deg : 1.0f;
+        for (int q = lane; q < quads; q += kWave) {
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int64_t e = e0 | 15; e < e1 - 1; e += 16) acc += reinterpret_cast<const f32x4*>(pieces + e * H)[q];
+            if (deg > 0) acc += reinterpret_cast<const f32x4*>(pieces + (e1 - 1) * H)[q];
+            if (mean) acc *= scale;
+            reinterpret_cast<f32x4*>(out + node * H)[q] = acc;
+        }
+    }
+}
+
 template <int H, int PREC, int MODE>
 int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
 {
     using C = Chain<H, PREC>;
-    const size_t lds = (size_t)kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H);
+    // ring | biases + first-layer vectors | per-wavefront staging of the in-kernel aggregation (32 x 36 floats + 32 ids)
+    const size_t lds = (size_t)kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H) +
+                       (MODE == 0 && a.piece_sums ? sizeof(float) * kWaves * (32 * 36 + 32) : 0);
     static bool granted[64] = {};       // (one flag per instantiation: function-local static of a template)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MDX_ERR_HIP;
@@ -665,7 +796,8 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
                         float* edge_scalar_out, uint32_t* status, mdx_stream_t stream)
 {
     if (!c || n_edges < 0 || coord_dimension < 1) return MDX_ERR_INVALID_ARG;
-    if (c->n_message_layers < 1 || c->n_coord_layers < 1 || (c->precision != 0 && c->precision != 1))
+    if (c->n_message_layers < 1 || c->n_coord_layers < 1 || (c->precision != 0 && c->precision != 1) ||
+        (c->message_mode != MDX_EGNN_MESSAGES_ROWS && c->message_mode != MDX_EGNN_MESSAGES_PIECE_SUMS))
         return MDX_ERR_INVALID_ARG;
     if (c->n_message_layers + c->n_coord_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     if (c->hidden != 32 && c->hidden != 64 && c->hidden != 128 && c->hidden != 256) return MDX_ERR_UNSUPPORTED;
@@ -678,6 +810,7 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
     a.node_proj = node_proj; a.coord = coord; a.edges = edges; a.n_edges_dev = n_edges_dev;
     a.n_edges = n_edges; a.n_message = c->n_message_layers; a.n_coord = c->n_coord_layers; a.D = coord_dimension;
     a.messages = messages_out; a.edge_scalar = edge_scalar_out; a.status = status;
+    a.piece_sums = c->message_mode == MDX_EGNN_MESSAGES_PIECE_SUMS;
 #ifdef MDX_CHAIN_STAMPS
     {
         int zero = 0;
@@ -698,6 +831,20 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
     }
 #undef MDX_CHAIN_CASE
     return MDX_ERR_UNSUPPORTED;
+}
+
+int mdx_segment_combine(const float* pieces, const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int H, int mean,
+                        float* out, mdx_stream_t stream)
+{
+    if (n_nodes < 0 || H < 4) return MDX_ERR_INVALID_ARG;
+    if (H & 3) return MDX_ERR_UNSUPPORTED;
+    if (n_nodes == 0) return MDX_OK;
+    if (!pieces || !offsets || !degree || !out) return MDX_ERR_INVALID_ARG;
+    int64_t blocks = (n_nodes * kWave + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(segment_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       pieces, offsets, degree, n_nodes, H, mean, out);
+    return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 
 int mdx_mlp_chain_rows(const mdx_egnn_chain_t* c, const float* x, const float* residual, int64_t n_rows,

@@ -583,8 +583,11 @@ class EdgeChainPack:
         self.bias_in = first_message_layer.bias.detach().to(F32).contiguous()
         self.w_radial = first_message_layer.weight.detach()[:, 2 * input_size].to(F32).contiguous()
         self.c_struct = _hip.EgnnChain(H, len(list(message_layers)), len(list(coord_layers)),
-                                       EDGE_CHAIN_PRECISIONS[precision], self.image.data_ptr(), self.biases.data_ptr(),
-                                       self.bias_in.data_ptr(), self.w_radial.data_ptr())
+                                       EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
+                                       self.biases.data_ptr(), self.bias_in.data_ptr(), self.w_radial.data_ptr())
+        # aggregation inside the kernel needs 18.5 KB more LDS: available unless the chain is very long at H = 256
+        lds = 4 * 32 * H * 4 + 4 * (len(layers) * H + 2 * H) + 4 * 4 * (32 * 36 + 32)
+        self.piece_sums_ok = lds <= 160 * 1024
         self._keep = []                    # the image holds its own copy (temporaries are freed in stream order)
         self.device = dev
 
@@ -619,7 +622,7 @@ class RowChainPack:
             check(lib().mdx_egnn_chain_pack(array, len(layers), None, H, EDGE_CHAIN_PRECISIONS[precision],
                                             C.c_void_p(self.image.data_ptr()), stream_handle()), "mdx_egnn_chain_pack")
         self.biases = torch.stack([layer.bias.detach().to(F32) for layer in layers]).contiguous()
-        self.c_struct = _hip.EgnnChain(H, len(layers), 0, EDGE_CHAIN_PRECISIONS[precision], self.image.data_ptr(),
+        self.c_struct = _hip.EgnnChain(H, len(layers), 0, EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
                                        self.biases.data_ptr(), None, None)
 
     @staticmethod
@@ -643,10 +646,12 @@ def mlp_chain_rows(pack: RowChainPack, x, residual=None, status=None) -> torch.T
     return out
 
 
-def egnn_edge_chain(pack: EdgeChainPack, node_proj, coord, edges, status=None, n_edges_dev=None):
+def egnn_edge_chain(pack: EdgeChainPack, node_proj, coord, edges, status=None, n_edges_dev=None, piece_sums: bool = False):
     """messages [E,H], edge_scalar [E] of the fused per-edge chain (mdx_egnn_edge_chain); edges sorted by source.
-    n_edges_dev (int64 [1], device): the actual number of edge rows when `edges` is a capacity-sized list."""
+    n_edges_dev (int64 [1], device): the actual number of edge rows when `edges` is a capacity-sized list.
+    piece_sums: the first output holds per-node piece sums instead of the messages (feed it to segment_combine)."""
     E, H = edges.shape[0], pack.hidden
+    pack.c_struct.message_mode = 1 if piece_sums else 0
     assert node_proj.shape[1] == 2 * H and coord.shape[0] == node_proj.shape[0]
     messages = torch.empty(E, H, dtype=F32, device=edges.device)
     scalar = torch.empty(E, dtype=F32, device=edges.device)
@@ -656,6 +661,16 @@ def egnn_edge_chain(pack: EdgeChainPack, node_proj, coord, edges, status=None, n
                                    ptr(status, I32, "status"), stream_handle())
     check(rc, "mdx_egnn_edge_chain")
     return messages, scalar
+
+
+def segment_combine(pieces, offsets, degree, mean: bool) -> torch.Tensor:
+    """Sum (or mean) over each node's edges from the piece sums of egnn_edge_chain(..., piece_sums=True) -> [n_nodes, H]."""
+    n_nodes, H = degree.shape[0], pieces.shape[1]
+    out = torch.empty(n_nodes, H, dtype=F32, device=pieces.device)
+    rc = lib().mdx_segment_combine(ptr(pieces, F32, "pieces"), ptr(offsets, I64, "offsets"), ptr(degree, I64, "degree"),
+                                   n_nodes, H, int(bool(mean)), ptr(out, F32, "out"), stream_handle())
+    check(rc, "mdx_segment_combine")
+    return out
 
 
 def egnn_coord_aggregate(edge_scalar, coord, edges, offsets, degree, mean: bool) -> torch.Tensor:

@@ -255,10 +255,15 @@ class E_GCL(nn.Module):
         w = first.weight
         proj = torch.nn.functional.linear(h, torch.cat([w[:, :n_in], w[:, n_in:2 * n_in]], dim=0))
         coord = coord.contiguous()
+        # the messages are added up per node inside the kernel (piece sums) and never written out as [E, H]
+        in_kernel = pack.piece_sums_ok and h.shape[0] < (1 << 31)
         messages, edge_scalar = kernels.egnn_edge_chain(pack, proj.contiguous(), coord, edge_index, status=self.status_word,
-                                                        n_edges_dev=n_edges)
+                                                        n_edges_dev=n_edges, piece_sums=in_kernel)
         coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean)
-        agg = kernels.segment_rows(messages, offsets, degree, self.message_mean)
+        if in_kernel:
+            agg = kernels.segment_combine(messages, offsets, degree, self.message_mean)
+        else:
+            agg = kernels.segment_rows(messages, offsets, degree, self.message_mean)
         node_in = torch.cat([h, agg], dim=1)
         node_pack = self._node_chain_pack()
         if node_pack is not None and (not self.residual or h.shape[1] == node_pack.hidden):

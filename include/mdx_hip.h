@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 5
+#define MDX_ABI_VERSION 6
 
 /* status codes */
 #define MDX_OK 0
@@ -361,8 +361,11 @@ MDX_API int mdx_segment_rows(const float* data, const int64_t* offsets, const in
  * n_edges: number of edge rows to process = capacity of the outputs; n_edges_dev (nullable): device word with the actual
  * count (<= n_edges), for callers that size the edge list without reading it back. */
 #define MDX_EGNN_CHAIN_MAX_LAYERS 16
+#define MDX_EGNN_MESSAGES_ROWS 0        /* messages_out [E,H] = the messages                                            */
+#define MDX_EGNN_MESSAGES_PIECE_SUMS 1  /* messages_out [E,H] = per-node piece sums (see mdx_segment_combine)           */
 typedef struct mdx_egnn_chain {
     int32_t hidden, n_message_layers, n_coord_layers, precision;
+    int32_t message_mode, reserved;     /* MDX_EGNN_MESSAGES_*; reserved = 0 */
     const void* weight_image;
     const float* biases;       /* [n_message_layers + n_coord_layers, H] */
     const float* bias_in;      /* [H]  bias of the first message layer                       */
@@ -374,6 +377,16 @@ MDX_API int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, 
 MDX_API int mdx_egnn_edge_chain(const mdx_egnn_chain_t* chain_host, const float* node_proj, const float* coord,
                                 int coord_dimension, const int64_t* edges, int64_t n_edges, const int64_t* n_edges_dev,
                                 float* messages_out, float* edge_scalar_out, uint32_t* status, mdx_stream_t stream);
+/* Message aggregation without the [E,H] round trip: with message_mode = MDX_EGNN_MESSAGES_PIECE_SUMS the edge chain adds
+ * the messages of a node's edges up INSIDE the kernel, per group of 16 consecutive edge rows (the list is sorted by source),
+ * and writes only those sums: the sum over the edges of node i inside group [16 k, 16 k + 16) lands in the row of the last
+ * such edge; every other row of messages_out is left untouched.  mdx_segment_combine then gives
+ * out[i,:] = (1/degree_i if mean) sum of node i's pieces, read in row order -- unsorted_segment_sum / _mean of the messages
+ * (models/egnn_utils.py:11-70) with a fixed summation order and no atomics; it replaces mdx_segment_rows, reads ~2 rows
+ * per node instead of degree_i, and the messages themselves never reach memory.  Node indices must be < 2^31. */
+MDX_API int mdx_segment_combine(const float* pieces, const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int H,
+                                int mean, float* out, mdx_stream_t stream);
+
 /* The same pipeline over the ROWS of a matrix (the per-node MLP of an EGNN layer, models/egnn.py:202-230, after its first
  * layer): out[r,:] = residual[r,:] + W_L (SiLU(W_{L-1} ... SiLU(W_1 x[r,:] + b_1) ...)) + b_L -- L = chain->n_message_layers
  * layers of H x H (chain->n_coord_layers must be 0; bias_in / w_radial unused; image packed with w_out = NULL), every layer

@@ -21,6 +21,7 @@ ap.add_argument("--modes", default="f32,f16x3,library")
 ap.add_argument("--n-msg", type=int, default=4)
 ap.add_argument("--n-crd", type=int, default=5)
 ap.add_argument("--eager", action="store_true", help="time eager launches with HIP events (no hipGraph: safe under rocprofv3 --pmc)")
+ap.add_argument("--piece-sums", action="store_true", help="aggregate the messages inside the kernel (piece sums)")
 ap.add_argument("--stamps", action="store_true", help="with a -DMDX_CHAIN_STAMPS build: print the stamped intervals")
 ap.add_argument("--lib", default=None, help="alternative libmdx_hip.so (ablation builds)")
 args = ap.parse_args()
@@ -60,7 +61,7 @@ with torch.no_grad():
             stamps = torch.zeros(8192, dtype=torch.int32, device=dev) if args.stamps else None
 
             def launch(pack=pack):
-                return kernels.egnn_edge_chain(pack, proj, coord, edges, status=stamps)
+                return kernels.egnn_edge_chain(pack, proj, coord, edges, status=stamps, piece_sums=args.piece_sums)
             if args.stamps:
                 launch(); launch()
                 torch.cuda.synchronize()
