@@ -292,7 +292,8 @@ def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
     edges = torch.stack([src, dst], 1).contiguous()
     proj = torch.randn(n_nodes, 2 * H, device=device)
     coord = torch.rand(n_nodes, 6, device=device)
-    ms = time_launches(lambda: kernels.egnn_edge_chain(pack, proj, coord, edges), device, launches)
+    pieces = bool(pack.piece_sums_ok)                 # the mode the network's forward uses (models/egnn.py)
+    ms = time_launches(lambda: kernels.egnn_edge_chain(pack, proj, coord, edges, piece_sums=pieces), device, launches)
     flops = 2.0 * edges.shape[0] * H * H * n_layers
     split = pack.precision == "f16x3"
     executed = flops * (3 if split else 1) / (ms * 1e-3) / 1e12
@@ -305,8 +306,9 @@ def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
     except (OSError, KeyError, ValueError):
         pass
     return dict(bound="mfma", achieved=round(executed, 2), peak=peak, unit="TFLOP/s", frac=round(executed / peak, 4),
-                traffic=traffic, kernel=f"egnn_edge_chain_kernel<{H},{1 if split else 0}> ({'split-f16: 3 x v_mfma_f32_32x32x16_f16' if split else 'v_mfma_f32_32x32x2_f32'}"
-                f" per product; {n_layers} fused H->H layers, {edges.shape[0]} edges per launch; 4 launches per network forward)",
+                traffic=traffic, kernel=f"egnn_edge_chain_kernel<{H},{1 if split else 0},{2 if pieces else 0}> ({'split-f16: 3 x v_mfma_f32_32x32x16_f16' if split else 'v_mfma_f32_32x32x2_f32'}"
+                f" per product; {n_layers} fused H->H layers + per-node message sums, {edges.shape[0]} edges per launch; 4 launches per "
+                f"network forward)",
                 avg_launch_us=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
                 algorithmic_tflops=round(flops / (ms * 1e-3) / 1e12, 2))
 

@@ -268,8 +268,8 @@ __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const 
     }
 }
 
-// MODE 0: the EGNN edge chain (gathered first layer, messages + head out).  MODE 1: the same pipeline over the rows of a
-// matrix -- out = residual + W_L (SiLU(W_{L-1} ... SiLU(W_1 x + b_1) ...)) + b_L -- used for the per-node MLP of an EGNN layer.
+// MODE 0: the EGNN edge chain (gathered first layer, messages + head out); MODE 2: the same with the messages added up per
+// node inside the kernel (piece sums out).  MODE 1: the same pipeline over the rows of a matrix -- out = residual + W_L (SiLU(W_{L-1} ... SiLU(W_1 x + b_1) ...)) + b_L -- used for the per-node MLP of an EGNN layer.
 template <int H, int PREC, int MODE>
 __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(ChainArgs p)
 {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     if ((int64_t)blockIdx.x >= n_tiles) return;             // uniform per workgroup
 
     for (int i = threadIdx.x; i < layers * H; i += kWaves * kWave) par[i] = p.biases[i] * kLog2e;
-    if constexpr (MODE == 0) {
+    if constexpr (MODE != 1) {
         for (int i = threadIdx.x; i < H; i += kWaves * kWave) {
             par_in[i] = p.bias_in[i];
             par_wr[i] = p.w_radial[i];
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     __syncthreads();
 
     C ch;
-    ch.image = p.image; ch.chunks_total = layers * NT + (MODE == 0 ? 1 : 0); ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
+    ch.image = p.image; ch.chunks_total = layers * NT + (MODE != 1 ? 1 : 0); ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
     ch.ring = ring; ch.wave = wave; ch.lane = lane;
     ch.stores_behind = false;
     ch.stores_count = 0;
@@ -355,9 +355,9 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         const bool live = e_raw < n_edges;
         const int64_t e = live ? e_raw : n_edges - 1;
         Act<H, PREC> xa, xb;
-        if constexpr (MODE == 0) {
+        if constexpr (MODE != 1) {
             const int64_t src = p.edges[2 * e], dst = p.edges[2 * e + 1];
-            if (p.piece_sums && h == 0) seg_src[col] = (int)src;      // (node indices fit 31 bits: checked on the host)
+            if (MODE == 2 && h == 0) seg_src[col] = (int)src;      // (node indices fit 31 bits: checked on the host)
             float radial = 0.0f;
             for (int k = 0; k < p.D; ++k) {
                 const float dlt = p.coord[src * p.D + k] - p.coord[dst * p.D + k];
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             for (int t = 0; t < NT; ++t) {
                 // the tile after this one: the next tile of this layer, the first of the next layer, or -- after the last
                 // layer -- the head (no bias; MODE 0) / layer 0 of the next rows (MODE 1)
-                const lds_f* next_bias = t + 1 < NT ? bias + 32 * (t + 1) : (l + 1 < layers ? bias + H : (MODE == 0 ? nullptr : par));
+                const lds_f* next_bias = t + 1 < NT ? bias + 32 * (t + 1) : (l + 1 < layers ? bias + H : (MODE != 1 ? nullptr : par));
                 // the epilogue beside tile 0 belongs to the previous layer (never the linear one); the others to this layer
                 if (t == 0) pend = run_tile(in, !FIRST, NT - 1, in, next_bias);
                 else pend = run_tile(in, true, t - 1, out, next_bias, l == layers - 1);
@@ -621,22 +621,22 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         if (!done) {
             for (int l = 1;;) {
                 layer(std::false_type{}, xb, xa, l);
-                if (MODE == 0 && l == p.n_message) {
-                    if (p.piece_sums) ch.stores_count = aggregate_pieces(xb);
+                if (MODE != 1 && l == p.n_message) {
+                    if constexpr (MODE == 2) ch.stores_count = aggregate_pieces(xb);
                     else store_messages(xb);
                 }
                 if (++l >= layers) {
-                    if constexpr (MODE == 0) head_tile(xa);
+                    if constexpr (MODE != 1) head_tile(xa);
                     else finish_rows(xa);
                     break;
                 }
                 layer(std::false_type{}, xa, xb, l);
-                if (MODE == 0 && l == p.n_message) {
-                    if (p.piece_sums) ch.stores_count = aggregate_pieces(xa);
+                if (MODE != 1 && l == p.n_message) {
+                    if constexpr (MODE == 2) ch.stores_count = aggregate_pieces(xa);
                     else store_messages(xa);
                 }
                 if (++l >= layers) {
-                    if constexpr (MODE == 0) head_tile(xb);
+                    if constexpr (MODE != 1) head_tile(xb);
                     else finish_rows(xb);
                     break;
                 }
@@ -742,7 +742,7 @@ int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
     using C = Chain<H, PREC>;
     // ring | biases + first-layer vectors | per-wavefront staging of the in-kernel aggregation (32 x 36 floats + 32 ids)
     const size_t lds = (size_t)kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H) +
-                       (MODE == 0 && a.piece_sums ? sizeof(float) * kWaves * (32 * 36 + 32) : 0);
+                       (MODE == 2 ? sizeof(float) * kWaves * (32 * 36 + 32) : 0);
     static bool granted[64] = {};       // (one flag per instantiation: function-local static of a template)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MDX_ERR_HIP;
@@ -821,8 +821,10 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
 #endif
     const int layers = a.n_message + a.n_coord;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define MDX_CHAIN_CASE(HH)                                                                         \
-    case HH: return c->precision == 0 ? launch_chain<HH, 0, 0>(a, layers, st) : launch_chain<HH, 1, 0>(a, layers, st);
+#define MDX_CHAIN_CASE(HH)                                                                                            \
+    case HH:                                                                                                          \
+        if (a.piece_sums) return c->precision == 0 ? launch_chain<HH, 0, 2>(a, layers, st) : launch_chain<HH, 1, 2>(a, layers, st); \
+        return c->precision == 0 ? launch_chain<HH, 0, 0>(a, layers, st) : launch_chain<HH, 1, 0>(a, layers, st);
     switch (c->hidden) {
         MDX_CHAIN_CASE(32)
         MDX_CHAIN_CASE(64)
