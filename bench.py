@@ -185,8 +185,22 @@ def time_fused_kernel(gen, loop, batch, w, device, iterations=None):
     # the bytes the un-fused algorithm moves per iteration: predictor 52+4C, each corrector 36 B/atom;
     # the persistent kernel keeps them in LDS and touches HBM only at the ends of the launch
     bytes_per_launch = batch * n * ((52 + 4 * c) + 36 * m) * iterations
+    # The byte figure is the UN-fused algorithm's: the persistent kernel keeps that state in LDS by design, so
+    # what actually bounds it is instruction issue / latency of one wavefront per SIMD.  Its compute side, for the record:
+    # MACs of the network forward (every nn.Linear of the module, as the reference evaluates it) x forwards per iteration.
+    net, pack = gen.axl_network, loop.pack
+    hidden, n_hidden = net._hyper_params.hidden_dimensions_size, len(net.mlp_layers)
+    if pack.folded is not None and pack.folded_out is not None and not gen.fused_sampler_options:
+        # executed: folded input layer (padded to quads) + middle layers + folded output layer
+        macs = (pack.folded.numel() - hidden) + hidden * hidden * (n_hidden - 2) + \
+            (pack.folded_out.numel() - (n * c + n * 3 + 6))
+    else:
+        macs = sum(mod.in_features * mod.out_features for mod in net.modules() if isinstance(mod, torch.nn.Linear))
+    tflops = 2.0 * macs * (1 + m) * batch * iterations / (ms * 1e-3) / 1e12
     return dict(kernel=f"mlp_pc_sample_kernel (persistent: {iterations} iterations of MLP forward + fused update per launch)",
-                ms=ms, bytes=bytes_per_launch)
+                ms=ms, bytes=bytes_per_launch,
+                compute=dict(tflops=round(tflops, 2), peak=MFMA_F32_PEAK_TFLOPS, frac_of_fp32_vector_peak=round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                             note="latency / issue bound: one wavefront per SIMD at B = 1024 (DESIGN.md section 4)"))
 
 
 def time_launches(launch, device, launches):
@@ -310,7 +324,10 @@ def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
                 f" per product; {n_layers} fused H->H layers + per-node message sums, {edges.shape[0]} edges per launch; 4 launches per "
                 f"network forward)",
                 avg_launch_us=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
-                algorithmic_tflops=round(flops / (ms * 1e-3) / 1e12, 2))
+                algorithmic_tflops=round(flops / (ms * 1e-3) / 1e12, 2),
+                note="peak = datasheet dense MFMA rate; under a dense f16 MFMA stream on random data this chip holds "
+                     "1.5-1.7 GHz (a launch issuing nothing but this kernel's MFMAs takes 2.12 ms at the C3 shape: "
+                     "profiles/r02_chain_ablation.md)" if split else "")
 
 
 def cpu_baseline(w, name, budget_s=15.0, resampling=0):
@@ -585,6 +602,8 @@ def main():
             roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, kernel=m["kernel"],
                             avg_launch_us=round(m["ms"] * 1e3, 3), algorithmic_bytes_per_launch=m["bytes"])
+            if "compute" in m:
+                roofline["compute"] = m["compute"]
 
     if rank != 0:
         if dist is not None:
