@@ -545,6 +545,9 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 float acc = 0.0f;
                 float* out = p.messages + (wave_base + 16 * half) * H + 32 * t + f;
+                // (opaque per slice: otherwise the sixteen row addresses are formed once, ahead of the whole phase, and kept
+                // -- 32 registers this point of the kernel does not have: they were spilled)
+                asm volatile("" : "+v"(out));
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     acc += seg[(16 * half + i) * kSegRow + f];
@@ -562,6 +565,13 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             const uint32_t m0 = __builtin_amdgcn_readlane(ends, 0), m1 = __builtin_amdgcn_readlane(ends, 32);
             stores = NT * __builtin_popcount(m0 | m1);
             return stores;
+        };
+        // The aggregation phase needs registers of its own while both operand sets are live: the next tile's prefetched
+        // fragments and initial accumulator (32 registers) are simply read again from LDS afterwards instead of being kept.
+        auto reload_prefetch = [&](const lds_f* bias_row) {
+#pragma unroll
+            for (int s2 = 0; s2 < PFD; ++s2) pre[s2] = read_frag(w_cur, s2);
+            acc_next = read_bias(bias_row);
         };
         // the head: one more tile whose image row 0 is w_out (no bias, no activation): s_e = row 0 of the accumulator
         auto head_tile = [&](Act<H, PREC>& in) {
@@ -622,8 +632,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             for (int l = 1;;) {
                 layer(std::false_type{}, xb, xa, l);
                 if (MODE != 1 && l == p.n_message) {
-                    if constexpr (MODE == 2) ch.stores_count = aggregate_pieces(xb);
-                    else store_messages(xb);
+                    if constexpr (MODE == 2) {
+                        ch.stores_count = aggregate_pieces(xb);
+                        reload_prefetch(l + 1 < layers ? par + (l + 1) * H : nullptr);
+                    } else {
+                        store_messages(xb);
+                    }
                 }
                 if (++l >= layers) {
                     if constexpr (MODE != 1) head_tile(xa);
@@ -632,8 +646,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 }
                 layer(std::false_type{}, xa, xb, l);
                 if (MODE != 1 && l == p.n_message) {
-                    if constexpr (MODE == 2) ch.stores_count = aggregate_pieces(xa);
-                    else store_messages(xa);
+                    if constexpr (MODE == 2) {
+                        ch.stores_count = aggregate_pieces(xa);
+                        reload_prefetch(l + 1 < layers ? par + (l + 1) * H : nullptr);
+                    } else {
+                        store_messages(xa);
+                    }
                 }
                 if (++l >= layers) {
                     if constexpr (MODE != 1) head_tile(xb);

@@ -9,7 +9,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_WAVES" \
            "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d ${OUT}_$tag -o pmc -- python3 $GRAFT_REPO_ROOT/tools/chain_bench.py --modes $MODE --eager --launches 3 > ${OUT}_$tag.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d ${OUT}_$tag -o pmc -- python3 $GRAFT_REPO_ROOT/tools/chain_bench.py --modes $MODE --eager --launches 3 --piece-sums > ${OUT}_$tag.log 2>&1
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
