@@ -441,6 +441,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #pragma unroll
             for (int s = 0; s < PFD; ++s) pre[s] = fr[STEPS + s];
             w_cur = w_next;
+#ifndef MDX_CHAIN_NO_TILE_PIN
+            // keep every tile's share of vector work beside ITS MFMAs: left free, the scheduler sinks the epilogues of the
+            // first tiles of a layer into its last ones (their results are not needed before the next layer), which then
+            // carry twice the vector work and are bound by instruction issue
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             return acc;
         };
         // One layer: tiles t = 0 .. NT-1.  The epilogue beside tile t is that of the tile before it: tile t-1 of this layer
