@@ -521,6 +521,8 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 const bool last = i == 15 || e0 + 1 >= n_live || seg_src[e0 + 1] != seg_src[e0];
                 if (e0 < n_live && last) ends |= 1u << i;
             }
+            // bit r set = a piece ends at edge r of this wavefront (wave-uniform)
+            const uint32_t rows_mask = __builtin_amdgcn_readlane(ends, 0) | (__builtin_amdgcn_readlane(ends, 32) << 16);
             int stores = 0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -549,27 +551,44 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                float acc = 0.0f;
-                float* out = p.messages + (wave_base + 16 * half) * H + 32 * t + f;
-                // (opaque per slice: otherwise the sixteen row addresses are formed once, ahead of the whole phase, and kept
-                // -- 32 registers this point of the kernel does not have: they were spilled)
-                asm volatile("" : "+v"(out));
+                // all sixteen reads first (one wait): read-add per edge would expose the LDS latency sixteen times per slice
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = seg[(16 * half + i) * kSegRow + f];
+                // running sums inside the pieces, branch-free, written back in place: the row of a piece's LAST edge then
+                // holds the piece sum
+                float run = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    acc += seg[(16 * half + i) * kSegRow + f];
-                    if (ends & (1u << i)) {
-                        if constexpr (PREC == 1) out_of_range = out_of_range || !(__builtin_fabsf(acc) <= 3.0e38f);
-                        out[(int64_t)i * H] = acc;
-                        acc = 0.0f;
+                    run += v[i];
+                    seg[(16 * half + i) * kSegRow + f] = run;
+                    run = (ends & (1u << i)) ? 0.0f : run;
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // the piece rows leave two at a time (one per half-wavefront, 128 contiguous bytes each) in a wave-uniform
+                // loop over the set bits: sixteen predicated stores per lane cost sixteen exec-mask sequences per slice
+                typedef __attribute__((address_space(1))) float gbl_f;
+                gbl_f* out_t = (gbl_f*)(p.messages + wave_base * H + 32 * t + f);
+                uint32_t todo = rows_mask;
+                while (todo) {
+                    const int ra = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    const int rb = todo ? __builtin_ctz(todo) : -1;
+                    todo &= todo - 1;                               // (0 & -1 = 0)
+                    const int r = half == 0 ? ra : rb;
+                    if (r >= 0) {
+                        const float sum = seg[r * kSegRow + f];
+                        if constexpr (PREC == 1) out_of_range = out_of_range || !(__builtin_fabsf(sum) <= 3.0e38f);
+                        out_t[(int64_t)r * H] = sum;
                     }
+                    ++stores;
                 }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);         // one slice at a time: the register file is full here
             }
             // store instructions this wavefront issued: one per (slice, bit set in either half's mask) -- wave-uniform
-            const uint32_t m0 = __builtin_amdgcn_readlane(ends, 0), m1 = __builtin_amdgcn_readlane(ends, 32);
-            stores = NT * __builtin_popcount(m0 | m1);
             return stores;
         };
         // The aggregation phase needs registers of its own while both operand sets are live: the next tile's prefetched
