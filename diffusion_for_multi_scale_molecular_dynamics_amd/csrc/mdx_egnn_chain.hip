@@ -140,23 +140,39 @@ struct Chain {
                             // same order at nearly the same time: without it every CU of an XCD asks its L2 for the same
                             // lines -- the same channels -- at once)
 
-    __device__ __forceinline__ void issue_chunk()
+    // The chunk being requested, piece by piece (wave-uniform): LPW direct-to-LDS loads per wavefront, ONE per
+    // STEPS / LPW k-steps, each in the issue shadow of an MFMA.  (All LPW at once, right behind the barrier, is 32 KB
+    // through the CU's one address path at 64 B per clock: every wavefront sat ~370 cycles per tile in the issue of its
+    // eight loads, with its matrix pipe idle.)
+    int issue_id, issue_slot;
+
+    __device__ __forceinline__ void issue_piece(int i)
     {
-        const char* src = image + (size_t)next_issue * CHUNK + lane * 16;
-        lds_c* dst = ring + slot_issue * CHUNK;
+#if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 4))
         constexpr int PIECES = CHUNK / 1024;
-#pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            const int piece = (wave * LPW + i + rot) & (PIECES - 1);
-            __builtin_amdgcn_global_load_lds((gbl_c*)(src + piece * 1024), (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
-        }
+        const int piece = (wave * LPW + i + rot) & (PIECES - 1);
+        const char* src = image + ((size_t)issue_id * CHUNK + (size_t)piece * 1024) + lane * 16;
+        lds_c* dst = ring + issue_slot * CHUNK + piece * 1024;
+        __builtin_amdgcn_global_load_lds((gbl_c*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#endif
+    }
+    // the next chunk of the stream becomes the one being requested
+    __device__ __forceinline__ void begin_chunk()
+    {
+        issue_id = next_issue;
+        issue_slot = slot_issue;
         next_issue = next_issue + 1 == chunks_total ? 0 : next_issue + 1;
         slot_issue = slot_issue + 1 == kRing ? 0 : slot_issue + 1;
     }
+    // pieces requested in the SAME tile as the chunk's begin_chunk() (behind the acquire in the middle of the tile); the
+    // others follow in the first half of the next tile
+    // (split-f16 only: the exact-f32 chain, whose MFMAs are twice as long, measured 2 % faster with the burst)
+    static constexpr bool SPREAD = PREC == 1;
+    static constexpr int FIRST_HALF = !SPREAD ? LPW : (LPW >= 2 ? LPW / 2 : 1);
 
     // Called in the MIDDLE of a tile's MFMA stream: makes the NEXT chunk readable (so that its first fragments can be read
-    // beside the second half of the current tile's MFMAs) and requests the chunk three ahead into the slot of the chunk
-    // before the current one -- every wavefront is past that one.  Returns the LDS address of the next chunk.
+    // beside the second half of the current tile's MFMAs) and opens the requests of the chunk three ahead into the slot of
+    // the chunk before the current one -- every wavefront is past that one.  Returns the LDS address of the next chunk.
     bool stores_behind;     // the message stores of this tile were issued after the last chunk request: they are younger
                             // than the chunk waited for next, so that wait may leave them pending too
     int stores_count;       // the same for a data-dependent number of stores (piece sums): at least this many were issued
@@ -208,23 +224,38 @@ struct Chain {
 #endif
         asm volatile("" ::: "memory");
         MDX_STAMP(3);
-#if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 4))
-        issue_chunk();
+        begin_chunk();
+        if constexpr (!SPREAD) {
+#pragma unroll
+            for (int i = 0; i < LPW; ++i) issue_piece(i);
+        }
+#ifdef MDX_CHAIN_SKEW
+        // a few cycles between the wavefronts, so that their requests do not meet at the address path
+        if (wave & 1) asm volatile("s_nop 15" ::: "memory");
+        if (wave & 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #endif
         slot_read = slot_read + 1 == kRing ? 0 : slot_read + 1;
         return ring + slot_read * CHUNK;
     }
 
-    // Once per workgroup, before the first tile: three chunks requested, the first one readable.
+    // Once per workgroup, before the first tile: two chunks and the first half of the third requested, the first one readable.
     __device__ __forceinline__ lds_c* prime()
     {
-        issue_chunk();
-        issue_chunk();
-        issue_chunk();
-        if constexpr (LPW == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr (LPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        for (int c = 0; c < 3; ++c) {
+            begin_chunk();
+#pragma unroll
+            for (int i = 0; i < LPW; ++i)
+                if (c < 2 || i < FIRST_HALF) issue_piece(i);
+        }
+        // the first chunk has landed once at most the LPW + FIRST_HALF younger requests are pending
+        constexpr int YOUNGER = LPW + FIRST_HALF;
+        if constexpr (YOUNGER == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if constexpr (YOUNGER == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if constexpr (YOUNGER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (YOUNGER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (YOUNGER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if constexpr (YOUNGER == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else { static_assert(YOUNGER == 2, "unexpected chunk geometry"); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         return ring + slot_read * CHUNK;
@@ -295,7 +326,21 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 
     const int64_t n_edges = p.n_edges_dev ? (*p.n_edges_dev < p.n_edges ? *p.n_edges_dev : p.n_edges) : p.n_edges;
     const int64_t n_tiles = (n_edges + kTileEdges - 1) / kTileEdges;
-    if ((int64_t)blockIdx.x >= n_tiles) return;             // uniform per workgroup
+    // Tile order: workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b mod 8), each with its own 4-MB
+    // L2.  Every XCD takes ONE contiguous eighth of the tiles and its workgroups walk it side by side, so the node rows an
+    // XCD gathers at any moment belong to two or three structures (the edges are sorted by source) and stay in its L2
+    // beside the 2.4-MB weight image; dealing tile b + k gridDim to workgroup b instead spreads every structure over all
+    // eight L2s (6x the unique bytes fetched, PMC of round 2) and pushes the weight image out.
+#ifndef MDX_CHAIN_LINEAR_TILES
+    const int n_xcd = gridDim.x >= 8 ? 8 : 1;
+#else
+    const int n_xcd = 1;
+#endif
+    const int xcd = blockIdx.x % n_xcd, xcd_slot = blockIdx.x / n_xcd;
+    const int xcd_wgs = (gridDim.x - xcd + n_xcd - 1) / n_xcd;               // workgroups on this XCD
+    const int64_t xcd_tiles = (n_tiles + n_xcd - 1) / n_xcd;
+    const int64_t tile_lo = xcd * xcd_tiles, tile_hi = tile_lo + xcd_tiles < n_tiles ? tile_lo + xcd_tiles : n_tiles;
+    if (tile_lo + xcd_slot >= tile_hi) return;              // uniform per workgroup
 
     for (int i = threadIdx.x; i < layers * H; i += kWaves * kWave) par[i] = p.biases[i] * kLog2e;
     if constexpr (MODE != 1) {
@@ -348,7 +393,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     f32x16 acc_next = read_bias(par);
 
     bool out_of_range = false;       // split-f16: a non-finite output (see epilogue_elements)
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int64_t tile = tile_lo + xcd_slot; tile < tile_hi; tile += xcd_wgs) {
         MDX_STAMP(9);
         // ---- this lane's edge (or row) -----------------------------------------------------------------------------
         const int64_t e_raw = tile * kTileEdges + wave * 32 + col;
@@ -425,14 +470,25 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #else
                 if (have && s == 0) asm volatile("" ::"v"(pend));      // keep the MFMAs alive without their epilogue
 #endif
+                // one weight-stream request per STEPS / LPW k-steps, behind the step's first MFMA; g = steps since the acquire
+                constexpr int PERIOD = STEPS / C::LPW;
+                const int g = (s + STEPS - STEPS / 2) % STEPS;
                 if constexpr (PREC == 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i) {
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s].f[i], in.v[4 * s + i], acc, 0, 0, 0);
+                        if (C::SPREAD && i == 0 && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
+                    }
                 } else {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].hi, in.hi[s], acc, 0, 0, 0);
+#ifndef MDX_CHAIN_DMA_LATE
+                    if (C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
+#endif
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].hi, in.lo[s], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].lo, in.hi[s], acc, 0, 0, 0);
+#ifdef MDX_CHAIN_DMA_LATE
+                    if (g % PERIOD == 0) ch.issue_piece(g / PERIOD);
+#endif
                 }
 #ifdef MDX_CHAIN_PIN_STEPS
                 __builtin_amdgcn_sched_barrier(0);      // keep each k-step's share of vector work beside ITS MFMAs
