@@ -107,17 +107,32 @@ __device__ __forceinline__ void put(Act<H, 1>& a, int t, int r, float y)
 
 // Timing diagnostics (never in the shipped build): -DMDX_CHAIN_STAMPS makes wavefront 0 of workgroup 0 write s_memtime at
 // marked points into the buffer passed as `status` (uint64 [4096]); tools/chain_bench.py --stamps prints the intervals.
+// -DMDX_CHAIN_STAMPS=2: only the two ends of the kernel, with s_memtime (shader clock) AND s_memrealtime (100 MHz): the
+// clock the chip held during the launch (tools/chain_bench.py --clocks).
 #ifdef MDX_CHAIN_STAMPS
-#define MDX_STAMP(id)                                                                                              \
+#define MDX_STAMP_ALWAYS(id)                                                                                       \
     do {                                                                                                           \
         if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 4000) {                                               \
             ((unsigned long long*)stamp_buf)[stamp_n++] = ((unsigned long long)(id) << 48) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffull); \
         }                                                                                                          \
     } while (0)
+#define MDX_STAMP_REALTIME(id)                                                                                     \
+    do {                                                                                                           \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 4000) {                                               \
+            ((unsigned long long*)stamp_buf)[stamp_n++] = ((unsigned long long)(id) << 48) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffffffull); \
+        }                                                                                                          \
+    } while (0)
+#if MDX_CHAIN_STAMPS == 2
+#define MDX_STAMP(id)
+#else
+#define MDX_STAMP(id) MDX_STAMP_ALWAYS(id)
+#endif
 __device__ void* stamp_buf;
 __device__ int stamp_n;
 #else
 #define MDX_STAMP(id)
+#define MDX_STAMP_ALWAYS(id)
+#define MDX_STAMP_REALTIME(id)
 #endif
 
 template <int H, int PREC>
@@ -351,6 +366,8 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     }
     __syncthreads();
 
+    MDX_STAMP_ALWAYS(20);
+    MDX_STAMP_REALTIME(21);
     C ch;
     ch.image = p.image; ch.chunks_total = layers * NT + (MODE != 1 ? 1 : 0); ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
     ch.ring = ring; ch.wave = wave; ch.lane = lane;
@@ -744,6 +761,8 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     }
     // requests still in flight target this workgroup's LDS: let them land before the workgroup ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MDX_STAMP_ALWAYS(22);
+    MDX_STAMP_REALTIME(23);
     if constexpr (PREC == 1) {
         if (p.status && out_of_range) atomicOr(p.status, MDX_STATUS_EGNN_F16_RANGE);
     }

@@ -23,6 +23,7 @@ ap.add_argument("--n-crd", type=int, default=5)
 ap.add_argument("--eager", action="store_true", help="time eager launches with HIP events (no hipGraph: safe under rocprofv3 --pmc)")
 ap.add_argument("--piece-sums", action="store_true", help="aggregate the messages inside the kernel (piece sums)")
 ap.add_argument("--stamps", action="store_true", help="with a -DMDX_CHAIN_STAMPS build: print the stamped intervals")
+ap.add_argument("--clocks", action="store_true", help="with a -DMDX_CHAIN_STAMPS=2 build: the shader clock during a launch")
 ap.add_argument("--lib", default=None, help="alternative libmdx_hip.so (ablation builds)")
 args = ap.parse_args()
 if args.lib:
@@ -58,10 +59,20 @@ with torch.no_grad():
         else:
             pack = kernels.EdgeChainPack(lin0, msg, crd, out, input_size=n_in, precision=mode)
 
-            stamps = torch.zeros(8192, dtype=torch.int32, device=dev) if args.stamps else None
+            stamps = torch.zeros(8192, dtype=torch.int32, device=dev) if args.stamps or args.clocks else None
 
             def launch(pack=pack):
                 return kernels.egnn_edge_chain(pack, proj, coord, edges, status=stamps, piece_sums=args.piece_sums)
+            if args.clocks:
+                for _ in range(8):
+                    launch()                        # (each launch restarts the stamp list: the last one is read)
+                torch.cuda.synchronize()
+                raw = stamps.view(torch.int64).cpu().numpy()
+                val = {int(r >> 48): int(r & ((1 << 48) - 1)) for r in raw if r >> 48}
+                cyc, ref = val[22] - val[20], val[23] - val[21]
+                res[mode] = {"shader_cycles": cyc, "refclk_ticks_100MHz": ref, "us": ref / 100.0,
+                             "shader_clock_GHz": round(cyc / (ref * 10.0), 3)}
+                continue
             if args.stamps:
                 launch(); launch()
                 torch.cuda.synchronize()
