@@ -122,7 +122,7 @@ __device__ __forceinline__ void put(Act<H, 1>& a, int t, int r, float y)
             ((unsigned long long*)stamp_buf)[stamp_n++] = ((unsigned long long)(id) << 48) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffffffull); \
         }                                                                                                          \
     } while (0)
-#if MDX_CHAIN_STAMPS == 2
+#if MDX_CHAIN_STAMPS >= 2
 #define MDX_STAMP(id)
 #else
 #define MDX_STAMP(id) MDX_STAMP_ALWAYS(id)
@@ -160,6 +160,9 @@ struct Chain {
     // through the CU's one address path at 64 B per clock: every wavefront sat ~370 cycles per tile in the issue of its
     // eight loads, with its matrix pipe idle.)
     int issue_id, issue_slot;
+#if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
+    unsigned long long dma_cycles = 0, dma_count = 0;
+#endif
 
     __device__ __forceinline__ void issue_piece(int i)
     {
@@ -167,8 +170,32 @@ struct Chain {
         constexpr int PIECES = CHUNK / 1024;
         const int piece = (wave * LPW + i + rot) & (PIECES - 1);
         const char* src = image + ((size_t)issue_id * CHUNK + (size_t)piece * 1024) + lane * 16;
-        lds_c* dst = ring + issue_slot * CHUNK + piece * 1024;
-        __builtin_amdgcn_global_load_lds((gbl_c*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        // Written as assembly ON PURPOSE.  The compiler's wait-count pass files the builtin (a FLAT-encoded instruction
+        // with an LDS operand) as an access that may complete out of order on BOTH counters; with one always in flight,
+        // every wait for a weight fragment became `s_waitcnt lgkmcnt(0)` -- the fragments just requested for the steps
+        // ahead included, i.e. the full LDS latency once per k-step (320 of them in this kernel; counted waits without the
+        // requests).  The requests are waited for by hand anyway (acquire_next); the compiler's own vmcnt waits stay
+        // correct with instructions it does not see in flight: they can only wait for more than they need.
+        const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring + issue_slot * CHUNK + piece * 1024));
+#if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
+        // issue cost of one request: shader clock before and behind it, summed per wavefront (read at the end of the kernel)
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#if defined(MDX_CHAIN_DMA_EXPERIMENT)
+        // (timing experiments: what a register-staged request would cost to issue; results are wrong by construction)
+        const uint32_t dst_lane = dst + lane * 16;
+        if (MDX_CHAIN_DMA_EXPERIMENT & 1) asm volatile("global_load_dwordx4 a[240:243], %0, off" ::"v"(src) : "a240", "a241", "a242", "a243");
+        if (MDX_CHAIN_DMA_EXPERIMENT & 2) asm volatile("ds_write_b128 %0, a[240:243]" ::"v"(dst_lane) : "memory");
+#else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst));
+#endif
+#if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_cycles += t1 - t0;
+        ++dma_count;
+#endif      // (m0 is reserved: the compiler never keeps a value in it)
 #endif
     }
     // the next chunk of the stream becomes the one being requested
@@ -314,6 +341,18 @@ __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const 
     }
 }
 
+// One step of the segmented scan over a DPP row of 16 lanes: x[r] += (the value D lanes down the row; 0 beyond the row's
+// first lane) * gate, gate = 1.0 where that lane belongs to this lane's piece, else 0.0.
+template <int D>
+__device__ __forceinline__ void segmented_step(float (&x)[16], float gate)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float below = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[r]), 0x110 + D, 0xf, 0xf, true));
+        x[r] = __builtin_fmaf(below, gate, x[r]);
+    }
+}
+
 // MODE 0: the EGNN edge chain (gathered first layer, messages + head out); MODE 2: the same with the messages added up per
 // node inside the kernel (piece sums out).  MODE 1: the same pipeline over the rows of a matrix -- out = residual + W_L (SiLU(W_{L-1} ... SiLU(W_1 x + b_1) ...)) + b_L -- used for the per-node MLP of an EGNN layer.
 template <int H, int PREC, int MODE>
@@ -332,12 +371,8 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     lds_f* par = (lds_f*)(lds_raw + kRing * C::CHUNK);      // [layers][H] biases | bias_in | w_radial
     lds_f* par_in = par + layers * H;
     lds_f* par_wr = par_in + H;
-    // per-wavefront staging for the in-kernel message aggregation: one 32-feature slice of the wavefront's 32 edges
-    // ([edge][36]: the row pad keeps the 16-byte writes off each other's banks) + the edges' source nodes
-    constexpr int kSegRow = 36;
-    lds_f* seg_all = par_wr + H;
-    lds_f* seg = seg_all + wave * (32 * kSegRow + 32);
-    __attribute__((address_space(3))) int* seg_src = (__attribute__((address_space(3))) int*)(seg + 32 * kSegRow);
+    // the source nodes of this wavefront's 32 edges (in-kernel message aggregation: where the pieces end)
+    __attribute__((address_space(3))) int* seg_src = (__attribute__((address_space(3))) int*)(par_wr + H) + wave * 32;
 
     const int64_t n_edges = p.n_edges_dev ? (*p.n_edges_dev < p.n_edges ? *p.n_edges_dev : p.n_edges) : p.n_edges;
     const int64_t n_tiles = (n_edges + kTileEdges - 1) / kTileEdges;
@@ -411,7 +446,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 
     bool out_of_range = false;       // split-f16: a non-finite output (see epilogue_elements)
     for (int64_t tile = tile_lo + xcd_slot; tile < tile_hi; tile += xcd_wgs) {
-        MDX_STAMP(9);
+        MDX_STAMP_ALWAYS(9);
         // ---- this lane's edge (or row) -----------------------------------------------------------------------------
         const int64_t e_raw = tile * kTileEdges + wave * 32 + col;
         const bool live = e_raw < n_edges;
@@ -457,7 +492,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        MDX_STAMP(10);
+        MDX_STAMP_ALWAYS(10);
         // ---- the chain ----------------------------------------------------------------------------------------------
         f32x16 pend;                                          // accumulators whose epilogue is outstanding
 
@@ -576,36 +611,34 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             ch.stores_behind = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(live) != 0);
         };
         // Message aggregation inside the kernel (piece_sums): the edges are sorted by source node, so a node's edges are a
-        // run of consecutive lanes.  Per 32-feature slice the wavefront stages its 32 x 32 block in LDS, then lane (f, half)
-        // walks the 16 edges of its half and adds feature f up, emitting the running sum whenever the source node changes
-        // and at the end of the half: a PIECE = the sum over a node's edges inside one 16-edge group, written to the row of
-        // the piece's last edge (128 contiguous bytes per half-wavefront store).  mdx_segment_combine adds a node's pieces
-        // (its last row and every row = 15 mod 16 inside its segment) in row order: fixed order, no atomics.  The messages
-        // themselves never reach memory.  Returns the number of store instructions issued (for the next chunk wait).
+        // run of consecutive edges = consecutive lanes of the accumulator layout (lane = 32 h + edge).  A PIECE = a node's
+        // edges inside one 16-edge group = inside one DPP row; its sum is a segmented scan over the row, four
+        // shift-and-add steps (`row_shr` 1, 2, 4, 8, each gated by "the edge that far down is in my piece") on the
+        // registers where the messages already are -- no staging, no transposition.  The lane of a piece's LAST edge then
+        // holds the piece sum of its 128 features and writes them to that edge's row; mdx_segment_combine adds a node's
+        // pieces (its last row and every row = 15 mod 16 inside its segment) in row order: fixed order, no atomics.  The
+        // messages themselves never reach memory.  Returns the number of store instructions issued (for the next chunk wait).
         auto aggregate_pieces = [&](const Act<H, PREC>& m) -> int {
             const int64_t wave_base = tile * kTileEdges + wave * 32;
             const int n_live = n_edges - wave_base >= 32 ? 32 : (n_edges > wave_base ? (int)(n_edges - wave_base) : 0);
-            const int f = lane & 31, half = lane >> 5;
-            // boundary mask of this lane's half: bit i set = the piece ends AFTER edge 16 half + i
-            uint32_t ends = 0;
+            const int c16 = col & 15;
+            const int my_src = seg_src[col];
+            float gate[4];                                  // 1.0: the edge 1 / 2 / 4 / 8 below is in this lane's piece
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int e0 = 16 * half + i;
-                const bool last = i == 15 || e0 + 1 >= n_live || seg_src[e0 + 1] != seg_src[e0];
-                if (e0 < n_live && last) ends |= 1u << i;
+            for (int k = 0; k < 4; ++k) {
+                const int d = 1 << k;
+                gate[k] = (c16 >= d && seg_src[c16 >= d ? col - d : col] == my_src) ? 1.0f : 0.0f;
             }
-            // bit r set = a piece ends at edge r of this wavefront (wave-uniform)
-            const uint32_t rows_mask = __builtin_amdgcn_readlane(ends, 0) | (__builtin_amdgcn_readlane(ends, 32) << 16);
-            int stores = 0;
+            const bool ends = col < n_live && (c16 == 15 || col + 1 >= n_live || seg_src[col + 1 < 32 ? col + 1 : col] != my_src);
+            float* row = p.messages + (wave_base + col) * H + 4 * h;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                // stage slice t: lane (col, h) holds features 32 t + 8 g + 4 h + (0..3) of its edge
+                float x[16];                                // features 32 t + 8 g + 4 h + i of this lane's edge, x[4 g + i]
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    f32x4 y;
                     if constexpr (PREC == 0) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) y[i] = m.v[16 * t + 4 * g + i] * kLn2;
+                        for (int i = 0; i < 4; ++i) x[4 * g + i] = m.v[16 * t + 4 * g + i] * kLn2;
                     } else {
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         const int r0 = 4 * g;
@@ -616,53 +649,30 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                             float y0, y1;
                             asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(ph), "v"(pl));
                             asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(y1) : "v"(ph), "v"(pl));
-                            y[2 * pr] = y0 * kLn2;
-                            y[2 * pr + 1] = y1 * kLn2;
+                            x[4 * g + 2 * pr] = y0 * kLn2;
+                            x[4 * g + 2 * pr + 1] = y1 * kLn2;
                         }
                     }
-                    *(__attribute__((address_space(3))) f32x4*)(seg + col * kSegRow + 8 * g + 4 * h) = y;
                 }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                // all sixteen reads first (one wait): read-add per edge would expose the LDS latency sixteen times per slice
-                float v[16];
+                segmented_step<1>(x, gate[0]);
+                segmented_step<2>(x, gate[1]);
+                segmented_step<4>(x, gate[2]);
+                segmented_step<8>(x, gate[3]);
+                if (ends) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = seg[(16 * half + i) * kSegRow + f];
-                // running sums inside the pieces, branch-free, written back in place: the row of a piece's LAST edge then
-                // holds the piece sum
-                float run = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    run += v[i];
-                    seg[(16 * half + i) * kSegRow + f] = run;
-                    run = (ends & (1u << i)) ? 0.0f : run;
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                // the piece rows leave two at a time (one per half-wavefront, 128 contiguous bytes each) in a wave-uniform
-                // loop over the set bits: sixteen predicated stores per lane cost sixteen exec-mask sequences per slice
-                typedef __attribute__((address_space(1))) float gbl_f;
-                gbl_f* out_t = (gbl_f*)(p.messages + wave_base * H + 32 * t + f);
-                uint32_t todo = rows_mask;
-                while (todo) {
-                    const int ra = __builtin_ctz(todo);
-                    todo &= todo - 1;
-                    const int rb = todo ? __builtin_ctz(todo) : -1;
-                    todo &= todo - 1;                               // (0 & -1 = 0)
-                    const int r = half == 0 ? ra : rb;
-                    if (r >= 0) {
-                        const float sum = seg[r * kSegRow + f];
-                        if constexpr (PREC == 1) out_of_range = out_of_range || !(__builtin_fabsf(sum) <= 3.0e38f);
-                        out_t[(int64_t)r * H] = sum;
+                    for (int g = 0; g < 4; ++g) {
+                        // (split-f16: no range check here -- a message beyond the f16 range is an infinity or a NaN in
+                        // the operand registers the coordinate layers read next, and reaches this edge's head output,
+                        // which is checked)
+                        const f32x4 y = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+                        *(f32x4*)(row + 32 * t + 8 * g) = y;
                     }
-                    ++stores;
                 }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);         // one slice at a time: the register file is full here
             }
-            // store instructions this wavefront issued: one per (slice, bit set in either half's mask) -- wave-uniform
-            return stores;
+            // store instructions this wavefront issued: H / 8, each with the piece-end lanes active (none: none issued)
+            const bool any = __builtin_amdgcn_ballot_w64(ends) != 0;
+            return any ? H / 8 : 0;
         };
         // The aggregation phase needs registers of its own while both operand sets are live: the next tile's prefetched
         // fragments and initial accumulator (32 registers) are simply read again from LDS afterwards instead of being kept.
@@ -731,8 +741,10 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 layer(std::false_type{}, xb, xa, l);
                 if (MODE != 1 && l == p.n_message) {
                     if constexpr (MODE == 2) {
+                        MDX_STAMP_ALWAYS(30);
                         ch.stores_count = aggregate_pieces(xb);
                         reload_prefetch(l + 1 < layers ? par + (l + 1) * H : nullptr);
+                        MDX_STAMP_ALWAYS(31);
                     } else {
                         store_messages(xb);
                     }
@@ -745,8 +757,10 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 layer(std::false_type{}, xa, xb, l);
                 if (MODE != 1 && l == p.n_message) {
                     if constexpr (MODE == 2) {
+                        MDX_STAMP_ALWAYS(30);
                         ch.stores_count = aggregate_pieces(xa);
                         reload_prefetch(l + 1 < layers ? par + (l + 1) * H : nullptr);
+                        MDX_STAMP_ALWAYS(31);
                     } else {
                         store_messages(xa);
                     }
@@ -763,6 +777,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MDX_STAMP_ALWAYS(22);
     MDX_STAMP_REALTIME(23);
+#if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ((unsigned long long*)stamp_buf)[stamp_n++] = (24ull << 48) | (ch.dma_cycles & 0xffffffffffffull);
+        ((unsigned long long*)stamp_buf)[stamp_n++] = (25ull << 48) | (ch.dma_count & 0xffffffffffffull);
+    }
+#endif
     if constexpr (PREC == 1) {
         if (p.status && out_of_range) atomicOr(p.status, MDX_STATUS_EGNN_F16_RANGE);
     }
@@ -858,9 +878,9 @@ template <int H, int PREC, int MODE>
 int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
 {
     using C = Chain<H, PREC>;
-    // ring | biases + first-layer vectors | per-wavefront staging of the in-kernel aggregation (32 x 36 floats + 32 ids)
+    // ring | biases + first-layer vectors | per-wavefront source ids of the in-kernel aggregation
     const size_t lds = (size_t)kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H) +
-                       (MODE == 2 ? sizeof(float) * kWaves * (32 * 36 + 32) : 0);
+                       (MODE == 2 ? sizeof(int) * kWaves * 32 : 0);
     static bool granted[64] = {};       // (one flag per instantiation: function-local static of a template)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MDX_ERR_HIP;

@@ -69,9 +69,17 @@ with torch.no_grad():
                 torch.cuda.synchronize()
                 raw = stamps.view(torch.int64).cpu().numpy()
                 val = {int(r >> 48): int(r & ((1 << 48) - 1)) for r in raw if r >> 48}
+                # phases of workgroup 0's edge tiles: 9 tile start, 10 first layer built, 30 / 31 around the aggregation
+                seq = [(int(r >> 48), int(r & ((1 << 48) - 1))) for r in raw if (r >> 48) in (9, 10, 30, 31)]
+                phase = {}
+                for (a, ta), (b, tb) in zip(seq, seq[1:]):
+                    phase.setdefault(f"{a}->{b}", []).append(tb - ta)
+                phases = {k: int(sum(v) / len(v)) for k, v in phase.items()}
                 cyc, ref = val[22] - val[20], val[23] - val[21]
                 res[mode] = {"shader_cycles": cyc, "refclk_ticks_100MHz": ref, "us": ref / 100.0,
-                             "shader_clock_GHz": round(cyc / (ref * 10.0), 3)}
+                             "shader_clock_GHz": round(cyc / (ref * 10.0), 3), "phase_cycles": phases}
+                if 24 in val:       # -DMDX_CHAIN_STAMPS=3: issue cost of the weight-stream requests of wavefront 0
+                    res[mode].update(requests=val[25], cycles_per_request=round(val[24] / max(val[25], 1), 1))
                 continue
             if args.stamps:
                 launch(); launch()
