@@ -531,6 +531,10 @@ def main():
         # fixed cost once per K.  So the job time is measured directly: one whole T-iteration trajectory, timed the same way.
         trajectory_ms = None
         if mlp:
+            # (one untimed trajectory first: the first T-iteration launch of a process also sizes and first-touches its
+            # 328-MB noise workspace)
+            loop = new_loop()
+            advance(loop, T, T)
             loop = new_loop()
             trajectory_ms = timed(lambda: advance(loop, T, T)) * 1e3
         # the single collective of the job: ONE all-gather of the packed final compositions

@@ -585,8 +585,8 @@ class EdgeChainPack:
         self.c_struct = _hip.EgnnChain(H, len(list(message_layers)), len(list(coord_layers)),
                                        EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
                                        self.biases.data_ptr(), self.bias_in.data_ptr(), self.w_radial.data_ptr())
-        # aggregation inside the kernel needs 18.5 KB more LDS: available unless the chain is very long at H = 256
-        lds = 4 * 32 * H * 4 + 4 * (len(layers) * H + 2 * H) + 4 * 4 * (32 * 36 + 32)
+        # the kernel's LDS: weight ring + small vectors + the source ids of the in-kernel aggregation
+        lds = 4 * 32 * H * 4 + 4 * (len(layers) * H + 2 * H) + 4 * 4 * 32
         self.piece_sums_ok = lds <= 160 * 1024
         self._keep = []                    # the image holds its own copy (temporaries are freed in stream order)
         self.device = dev
