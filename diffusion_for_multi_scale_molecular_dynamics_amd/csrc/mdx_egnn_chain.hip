@@ -151,15 +151,22 @@ struct Chain {
     lds_c* ring;
     int wave, lane;
 
-    int rot;                // this workgroup's rotation of the 1-KB piece order (all workgroups stream the same image in the
-                            // same order at nearly the same time: without it every CU of an XCD asks its L2 for the same
-                            // lines -- the same channels -- at once)
+    int share;              // byte offset, inside every chunk, of the quarter this wavefront requests: (wave + workgroup's
+                            // rotation) mod 4 quarters (all workgroups stream the same image in the same order at nearly
+                            // the same time: without the rotation every CU of an XCD asks its L2 for the same lines at once)
+    uint32_t lane16;        // lane * 16: the per-lane part of every request's address
 
-    // The chunk being requested, piece by piece (wave-uniform): LPW direct-to-LDS loads per wavefront, ONE per
-    // STEPS / LPW k-steps, each in the issue shadow of an MFMA.  (All LPW at once, right behind the barrier, is 32 KB
-    // through the CU's one address path at 64 B per clock: every wavefront sat ~370 cycles per tile in the issue of its
-    // eight loads, with its matrix pipe idle.)
+    // The chunk being requested, piece by piece: LPW direct-to-LDS loads per wavefront (1 KB each: its quarter of the
+    // chunk), ONE per STEPS / LPW k-steps, each in the issue shadow of an MFMA.  (All LPW at once, right behind the
+    // barrier, is 32 KB through the CU's one address path: every wavefront sat ~370 cycles per tile in the issue of its
+    // eight loads, with its matrix pipe idle.)  Addresses are scalar: begin_chunk() forms the quarter's global base and LDS
+    // base once; a piece's kilobytes are its instruction offset.
     int issue_id, issue_slot;
+#ifdef MDX_CHAIN_VERIFY
+    uint32_t* verify_status = nullptr;
+#endif
+    uint32_t issue_src;     // byte offset of (chunk, share) in the image   (SGPR; the image is a few megabytes)
+    uint32_t issue_dst;     // LDS byte address of slot + share           (SGPR)
 #if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
     unsigned long long dma_cycles = 0, dma_count = 0;
 #endif
@@ -167,35 +174,42 @@ struct Chain {
     __device__ __forceinline__ void issue_piece(int i)
     {
 #if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 4))
-        constexpr int PIECES = CHUNK / 1024;
-        const int piece = (wave * LPW + i + rot) & (PIECES - 1);
-        const char* src = image + ((size_t)issue_id * CHUNK + (size_t)piece * 1024) + lane * 16;
         // Written as assembly ON PURPOSE.  The compiler's wait-count pass files the builtin (a FLAT-encoded instruction
         // with an LDS operand) as an access that may complete out of order on BOTH counters; with one always in flight,
         // every wait for a weight fragment became `s_waitcnt lgkmcnt(0)` -- the fragments just requested for the steps
-        // ahead included, i.e. the full LDS latency once per k-step (320 of them in this kernel; counted waits without the
-        // requests).  The requests are waited for by hand anyway (acquire_next); the compiler's own vmcnt waits stay
+        // ahead included.  The requests are waited for by hand anyway (acquire_next); the compiler's own vmcnt waits stay
         // correct with instructions it does not see in flight: they can only wait for more than they need.
-        const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring + issue_slot * CHUNK + piece * 1024));
+        // (m0 is a reserved register: the compiler never keeps a value in it across statements.)
+        // Scalar base (image + the offset begin_chunk() left in a scalar register, + 4 KB for pieces 4 .. 7) as the SADDR
+        // operand, lane * 16 as the 32-bit vector offset, the piece's kilobytes as the instruction offset -- which applies
+        // to BOTH the global and the LDS address (tools/... probe of round 2): no vector instruction per request.
+        const uint64_t src = (uint64_t)(uintptr_t)image + (uint64_t)(issue_src + (uint32_t)((i >> 2) * 4096));
+        const uint32_t dst = issue_dst + (uint32_t)((i >> 2) * 4096);
 #if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
         // issue cost of one request: shader clock before and behind it, summed per wavefront (read at the end of the kernel)
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-#if defined(MDX_CHAIN_DMA_EXPERIMENT)
-        // (timing experiments: what a register-staged request would cost to issue; results are wrong by construction)
-        const uint32_t dst_lane = dst + lane * 16;
-        if (MDX_CHAIN_DMA_EXPERIMENT & 1) asm volatile("global_load_dwordx4 a[240:243], %0, off" ::"v"(src) : "a240", "a241", "a242", "a243");
-        if (MDX_CHAIN_DMA_EXPERIMENT & 2) asm volatile("ds_write_b128 %0, a[240:243]" ::"v"(dst_lane) : "memory");
+#ifdef MDX_CHAIN_VERIFY
+        {
+            // debugging aid: the addresses a request is about to use against the plain formula; a mismatch is reported in the
+            // status word (bit 30 source, bit 31 destination) and the plain values are used
+            const uint64_t ref_src = (uint64_t)(uintptr_t)image + (uint64_t)issue_id * CHUNK + (uint64_t)share + (uint64_t)(i * 1024) + lane16;
+            const uint32_t ref_dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ring + (uint32_t)(issue_slot * CHUNK + share + i * 1024));
+            if (verify_status && src + lane16 + (i & 3) * 1024 != ref_src) atomicOr(verify_status, 1u << 30);
+            if (verify_status && dst + (i & 3) * 1024 != ref_dst) atomicOr(verify_status, 1u << 31);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(ref_src), "s"(ref_dst));
+        }
 #else
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane16), "s"(src), "s"(dst),
+                     "n"((i & 3) * 1024));
 #endif
 #if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         dma_cycles += t1 - t0;
         ++dma_count;
-#endif      // (m0 is reserved: the compiler never keeps a value in it)
+#endif
 #endif
     }
     // the next chunk of the stream becomes the one being requested
@@ -203,8 +217,26 @@ struct Chain {
     {
         issue_id = next_issue;
         issue_slot = slot_issue;
+        scalar_addresses();
         next_issue = next_issue + 1 == chunks_total ? 0 : next_issue + 1;
         slot_issue = slot_issue + 1 == kRing ? 0 : slot_issue + 1;
+    }
+    // issue_src / issue_dst of the chunk being requested, in scalar registers.  v_readfirstlane as assembly: the builtin is
+    // folded away on a value the compiler knows to be uniform, which then stays in the vector registers it has chosen for
+    // the ring state -- and an "s" operand of the request would be handed a vector register.  Also called at the top of
+    // every edge tile: a value carried around the tile loop may be moved to vector registers again.
+    __device__ __forceinline__ void scalar_addresses()
+    {
+        const uint32_t src = (uint32_t)issue_id * (uint32_t)CHUNK + (uint32_t)share;
+        const uint32_t dst = (uint32_t)(uintptr_t)ring + (uint32_t)(issue_slot * CHUNK + share);
+        uint32_t s_src, s_dst;
+        // (s_nop 1 first: a vector register written by the instruction just before is not yet readable by v_readfirstlane --
+        // a wait state the compiler inserts for its own instructions and cannot see into this statement; without it the
+        // first of the two came back wrong now and then.  s_nop 4 last: a scalar register written by a vector
+        // instruction must not be read as a memory instruction's address within five wait states.)
+        asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3\n\ts_nop 4" : "=s"(s_src), "=s"(s_dst) : "v"(src), "v"(dst));
+        issue_src = s_src;
+        issue_dst = s_dst;
     }
     // pieces requested in the SAME tile as the chunk's begin_chunk() (behind the acquire in the middle of the tile); the
     // others follow in the first half of the next tile
@@ -283,6 +315,7 @@ struct Chain {
     // Once per workgroup, before the first tile: two chunks and the first half of the third requested, the first one readable.
     __device__ __forceinline__ lds_c* prime()
     {
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
             begin_chunk();
 #pragma unroll
@@ -374,7 +407,15 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     // the source nodes of this wavefront's 32 edges (in-kernel message aggregation: where the pieces end)
     __attribute__((address_space(3))) int* seg_src = (__attribute__((address_space(3))) int*)(par_wr + H) + wave * 32;
 
-    const int64_t n_edges = p.n_edges_dev ? (*p.n_edges_dev < p.n_edges ? *p.n_edges_dev : p.n_edges) : p.n_edges;
+    // (the device-side count arrives through a vector load: made scalar by hand, or every loop bound derived from it -- and
+    // with them the whole ring state of the tile loop -- lives in vector registers and is updated by the vector ALU)
+    int64_t n_edges = p.n_edges;
+    if (p.n_edges_dev) {
+        const int64_t dev_count = *p.n_edges_dev;
+        const int64_t uniform = ((int64_t)__builtin_amdgcn_readfirstlane((int)(dev_count >> 32)) << 32) |
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)dev_count);
+        n_edges = uniform < p.n_edges ? uniform : p.n_edges;
+    }
     const int64_t n_tiles = (n_edges + kTileEdges - 1) / kTileEdges;
     // Tile order: workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b mod 8), each with its own 4-MB
     // L2.  Every XCD takes ONE contiguous eighth of the tiles and its workgroups walk it side by side, so the node rows an
@@ -408,7 +449,11 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     ch.ring = ring; ch.wave = wave; ch.lane = lane;
     ch.stores_behind = false;
     ch.stores_count = 0;
-    ch.rot = (int)((blockIdx.x * 5u) & (unsigned)(C::CHUNK / 1024 - 1));
+    ch.share = (int)(((unsigned)wave + blockIdx.x / 8u) & 3u) * (C::CHUNK / 4);      // (blockIdx / 8: its slot on its XCD)
+    ch.lane16 = (uint32_t)lane * 16u;
+#ifdef MDX_CHAIN_VERIFY
+    ch.verify_status = p.status;
+#endif
 
     // Weight fragments of a k-step, and the state that flows from one tile to the next: the LDS address of the tile's
     // chunk, its first PFD fragments and its initial accumulator (= the bias), all read beside the previous tile's MFMAs.
@@ -493,6 +538,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             }
         }
         MDX_STAMP_ALWAYS(10);
+        ch.scalar_addresses();
         // ---- the chain ----------------------------------------------------------------------------------------------
         f32x16 pend;                                          // accumulators whose epilogue is outstanding
 
