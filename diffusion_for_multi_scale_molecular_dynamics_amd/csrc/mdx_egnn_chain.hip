@@ -182,7 +182,7 @@ struct Chain {
         // (m0 is a reserved register: the compiler never keeps a value in it across statements.)
         // Scalar base (image + the offset begin_chunk() left in a scalar register, + 4 KB for pieces 4 .. 7) as the SADDR
         // operand, lane * 16 as the 32-bit vector offset, the piece's kilobytes as the instruction offset -- which applies
-        // to BOTH the global and the LDS address (tools/... probe of round 2): no vector instruction per request.
+        // to BOTH the global and the LDS address (tools/dma_probe.hip): no vector instruction per request.
         const uint64_t src = (uint64_t)(uintptr_t)image + (uint64_t)(issue_src + (uint32_t)((i >> 2) * 4096));
         const uint32_t dst = issue_dst + (uint32_t)((i >> 2) * 4096);
 #if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
