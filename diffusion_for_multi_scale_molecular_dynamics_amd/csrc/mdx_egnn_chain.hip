@@ -105,6 +105,32 @@ __device__ __forceinline__ void put(Act<H, 1>& a, int t, int r, float y)
     a.lo[2 * t + (r >> 3)][r & 7] = (_Float16)(y - (float)hi);
 }
 
+// Elements r, r + 1 (r even) of tile t.  Split-f16: hi = f16(y) (packed convert), lo = f16(y - hi) with the subtraction
+// straight off the packed halves (v_fma_mix_f32: f16 operand x -1 + f32 operand, exact) -- four instructions per pair.
+template <int H>
+__device__ __forceinline__ void put_pair(Act<H, 0>& a, int t, int r, float y0, float y1)
+{
+    a.v[16 * t + r] = y0;
+    a.v[16 * t + r + 1] = y1;
+}
+template <int H>
+__device__ __forceinline__ void put_pair(Act<H, 1>& a, int t, int r, float y0, float y1)
+{
+    uint32_t hi, lo;
+    float l0, l1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(y0), "v"(y1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(y0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(y1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(l0), "v"(l1));
+    const int s = 2 * t + (r >> 3), j = (r & 7) >> 1;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 vh = __builtin_bit_cast(u32x4, a.hi[s]), vl = __builtin_bit_cast(u32x4, a.lo[s]);
+    vh[j] = hi;
+    vl[j] = lo;
+    a.hi[s] = __builtin_bit_cast(half8, vh);
+    a.lo[s] = __builtin_bit_cast(half8, vl);
+}
+
 // Timing diagnostics (never in the shipped build): -DMDX_CHAIN_STAMPS makes wavefront 0 of workgroup 0 write s_memtime at
 // marked points into the buffer passed as `status` (uint64 [4096]); tools/chain_bench.py --stamps prints the intervals.
 // -DMDX_CHAIN_STAMPS=2: only the two ends of the kernel, with s_memtime (shader clock) AND s_memrealtime (100 MHz): the
@@ -352,24 +378,11 @@ __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const 
     for (int r = 0; r < 16; ++r) {
         if (r < r0 || r >= r1) continue;
         if constexpr (PREC == 0) {
+            // (one value at a time: in pairs this instantiation nearly doubles its run time -- 7.25 -> 12.9 ms at H = 256)
             put<H>(dst, tp, r, linear ? pend[r] : silu_scaled(pend[r]));
         } else if (!(r & 1)) {
-            // a pair of elements: hi = f16(y) (packed convert), lo = f16(y - hi) with the subtraction straight off the
-            // packed halves (v_fma_mix_f32: f16 operand x -1 + f32 operand, exact)
             const float y0 = linear ? pend[r] : silu_scaled(pend[r]), y1 = linear ? pend[r + 1] : silu_scaled(pend[r + 1]);
-            uint32_t hi, lo;
-            float l0, l1;
-            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(y0), "v"(y1));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(y0));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(y1));
-            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(l0), "v"(l1));
-            const int s = 2 * tp + (r >> 3), j = (r & 7) >> 1;
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 vh = __builtin_bit_cast(u32x4, dst.hi[s]), vl = __builtin_bit_cast(u32x4, dst.lo[s]);
-            vh[j] = hi;
-            vl[j] = lo;
-            dst.hi[s] = __builtin_bit_cast(half8, vh);
-            dst.lo[s] = __builtin_bit_cast(half8, vl);
+            put_pair<H>(dst, tp, r, y0, y1);
         }
     }
 }
@@ -436,8 +449,8 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     for (int i = threadIdx.x; i < layers * H; i += kWaves * kWave) par[i] = p.biases[i] * kLog2e;
     if constexpr (MODE != 1) {
         for (int i = threadIdx.x; i < H; i += kWaves * kWave) {
-            par_in[i] = p.bias_in[i];
-            par_wr[i] = p.w_radial[i];
+            par_in[i] = p.bias_in[i] * kLog2e;
+            par_wr[i] = p.w_radial[i] * kLog2e;
         }
     }
     __syncthreads();
@@ -517,11 +530,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #endif
                 const f32x4 b0 = *(const __attribute__((address_space(3))) f32x4*)(par_in + 8 * q + 4 * h);
                 const f32x4 wr = *(const __attribute__((address_space(3))) f32x4*)(par_wr + 8 * q + 4 * h);
+                // z = log2(e) ((a + b) + b0 + radial wr): b0 and wr are staged pre-scaled, two fused multiply-adds per value
+                float y[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float y = silu_scaled((((a[i] + b[i]) + b0[i]) + radial * wr[i]) * kLog2e);
-                    put<H>(xa, q >> 2, 4 * (q & 3) + i, y);
-                }
+                for (int i = 0; i < 4; ++i) y[i] = silu_scaled(__builtin_fmaf(a[i] + b[i], kLog2e, __builtin_fmaf(radial, wr[i], b0[i])));
+                put_pair<H>(xa, q >> 2, 4 * (q & 3), y[0], y[1]);
+                put_pair<H>(xa, q >> 2, 4 * (q & 3) + 2, y[2], y[3]);
                 // half of the two gathers in flight at a time (the other operand set and the accumulators are free here):
                 // hoisting all of them costs 256 registers
                 if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
@@ -533,7 +547,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             for (int q = 0; q < H / 8; ++q) {
                 const f32x4 a = *(const f32x4*)(px + 8 * q);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) put<H>(xa, q >> 2, 4 * (q & 3) + i, a[i] * kLog2e);
+                for (int i = 0; i < 4; i += 2) put_pair<H>(xa, q >> 2, 4 * (q & 3) + i, a[i] * kLog2e, a[i + 1] * kLog2e);
                 if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
         }
