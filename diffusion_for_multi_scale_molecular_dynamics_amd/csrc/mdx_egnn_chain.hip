@@ -227,8 +227,15 @@ struct Chain {
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(ref_src), "s"(ref_dst));
         }
 #else
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane16), "s"(src), "s"(dst),
-                     "n"((i & 3) * 1024));
+        if constexpr (SPREAD) {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane16), "s"(src), "s"(dst),
+                         "n"((i & 3) * 1024));
+        } else {
+            // (the burst form of the exact-f32 chain: the per-lane address as a vector-register pair -- with eight scalar-base
+            // requests in a row the row-chain instantiation at H = 256 spills 3.6 KB per lane)
+            const uint64_t lane_src = src + lane16;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" ::"v"(lane_src), "s"(dst), "n"((i & 3) * 1024));
+        }
 #endif
 #if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -255,6 +262,12 @@ struct Chain {
     {
         const uint32_t src = (uint32_t)issue_id * (uint32_t)CHUNK + (uint32_t)share;
         const uint32_t dst = (uint32_t)(uintptr_t)ring + (uint32_t)(issue_slot * CHUNK + share);
+        if constexpr (!SPREAD) {
+            // the burst form (exact-f32 chain) uses them at once, the source as part of a vector address: no assembly needed
+            issue_src = src;
+            issue_dst = __builtin_amdgcn_readfirstlane(dst);
+            return;
+        }
         uint32_t s_src, s_dst;
         // (s_nop 1 first: a vector register written by the instruction just before is not yet readable by v_readfirstlane --
         // a wait state the compiler inserts for its own instructions and cannot see into this statement; without it the
@@ -521,24 +534,47 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             // first message layer, straight into B-operand registers
             const float* ps = p.node_proj + src * 2 * H + 4 * h;
             const float* pd = p.node_proj + dst * 2 * H + H + 4 * h;
+            // The gathers are software-pipelined by hand: batches of QB float4 pairs, requested DEPTH batches before they are
+            // used, with scheduling pins between "request" and "compute" (left to itself the compiler keeps six to ten of
+            // the 64 loads in flight -- the operand sets fill the register file -- and the phase is a chain of L2 latencies:
+            // 25 k cycles per tile against 7 k of arithmetic).
+            constexpr int NQ = H / 8, QB = NQ >= 8 ? 4 : NQ, NB = NQ / QB, DEPTH = 2;
+            f32x4 ga[NB][QB], gb[NB][QB];
+            auto request = [&](int batch) {
 #pragma unroll
-            for (int q = 0; q < H / 8; ++q) {               // features 8 q + 4 h + (0..3)
+                for (int k = 0; k < QB; ++k) {
+                    const int q = batch * QB + k;           // features 8 q + 4 h + (0..3)
 #if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 2)
-                const f32x4 a = {radial, 1.0f, 2.0f, radial}, b = {0.5f, radial, 0.25f, 1.0f};
+                    ga[batch][k] = f32x4{radial, 1.0f, 2.0f, radial};
+                    gb[batch][k] = f32x4{0.5f, radial, 0.25f, 1.0f};
+                    (void)q;
 #else
-                const f32x4 a = *(const f32x4*)(ps + 8 * q), b = *(const f32x4*)(pd + 8 * q);
+                    ga[batch][k] = *(const f32x4*)(ps + 8 * q);
+                    gb[batch][k] = *(const f32x4*)(pd + 8 * q);
 #endif
-                const f32x4 b0 = *(const __attribute__((address_space(3))) f32x4*)(par_in + 8 * q + 4 * h);
-                const f32x4 wr = *(const __attribute__((address_space(3))) f32x4*)(par_wr + 8 * q + 4 * h);
-                // z = log2(e) ((a + b) + b0 + radial wr): b0 and wr are staged pre-scaled, two fused multiply-adds per value
-                float y[4];
+                }
+            };
 #pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = silu_scaled(__builtin_fmaf(a[i] + b[i], kLog2e, __builtin_fmaf(radial, wr[i], b0[i])));
-                put_pair<H>(xa, q >> 2, 4 * (q & 3), y[0], y[1]);
-                put_pair<H>(xa, q >> 2, 4 * (q & 3) + 2, y[2], y[3]);
-                // half of the two gathers in flight at a time (the other operand set and the accumulators are free here):
-                // hoisting all of them costs 256 registers
-                if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+            for (int batch = 0; batch < DEPTH && batch < NB; ++batch) request(batch);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int batch = 0; batch < NB; ++batch) {
+                if (batch + DEPTH < NB) request(batch + DEPTH);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < QB; ++k) {
+                    const int q = batch * QB + k;
+                    const f32x4 a = ga[batch][k], b = gb[batch][k];
+                    const f32x4 b0 = *(const __attribute__((address_space(3))) f32x4*)(par_in + 8 * q + 4 * h);
+                    const f32x4 wr = *(const __attribute__((address_space(3))) f32x4*)(par_wr + 8 * q + 4 * h);
+                    // z = log2(e) ((a + b) + b0 + radial wr): b0 and wr are staged pre-scaled, two fused multiply-adds per value
+                    float y[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = silu_scaled(__builtin_fmaf(a[i] + b[i], kLog2e, __builtin_fmaf(radial, wr[i], b0[i])));
+                    put_pair<H>(xa, q >> 2, 4 * (q & 3), y[0], y[1]);
+                    put_pair<H>(xa, q >> 2, 4 * (q & 3) + 2, y[2], y[3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             // the row itself (the caller's activations, carried as log2(e) x inside the chain)
@@ -547,12 +583,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             for (int q = 0; q < H / 8; ++q) {
                 const f32x4 a = *(const f32x4*)(px + 8 * q);
 #pragma unroll
-                for (int i = 0; i < 4; i += 2) put_pair<H>(xa, q >> 2, 4 * (q & 3) + i, a[i] * kLog2e, a[i + 1] * kLog2e);
+                for (int i = 0; i < 4; ++i) put<H>(xa, q >> 2, 4 * (q & 3) + i, a[i] * kLog2e);
                 if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
         }
         MDX_STAMP_ALWAYS(10);
-        ch.scalar_addresses();
+        if constexpr (C::SPREAD) ch.scalar_addresses();       // (the burst form sets them right before its requests)
         // ---- the chain ----------------------------------------------------------------------------------------------
         f32x16 pend;                                          // accumulators whose epilogue is outstanding
 

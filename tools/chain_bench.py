@@ -24,6 +24,7 @@ ap.add_argument("--eager", action="store_true", help="time eager launches with H
 ap.add_argument("--piece-sums", action="store_true", help="aggregate the messages inside the kernel (piece sums)")
 ap.add_argument("--stamps", action="store_true", help="with a -DMDX_CHAIN_STAMPS build: print the stamped intervals")
 ap.add_argument("--clocks", action="store_true", help="with a -DMDX_CHAIN_STAMPS=2 build: the shader clock during a launch")
+ap.add_argument("--rows", action="store_true", help="also time the row chain (mdx_mlp_chain_rows): --nodes rows, --n-crd layers + residual")
 ap.add_argument("--lib", default=None, help="alternative libmdx_hip.so (ablation builds)")
 args = ap.parse_args()
 if args.lib:
@@ -115,4 +116,13 @@ with torch.no_grad():
         else:
             ms = bench.time_launches(launch, dev, args.launches)
         res[mode] = {"ms": round(ms, 4), "algorithmic_tflops": round(flops / ms / 1e9, 2)}
+if args.rows:
+    with torch.no_grad():
+        x = torch.randn(n_nodes, H, device=dev)
+        for mode in args.modes.split(","):
+            if mode == "library":
+                continue
+            rpack = kernels.RowChainPack(crd, mode)
+            ms = bench.time_launches(lambda rpack=rpack: kernels.mlp_chain_rows(rpack, x, residual=x), dev, args.launches)
+            res.setdefault("rows", {})[mode] = {"ms": round(ms, 4), "rows": n_nodes, "layers": len(crd)}
 print(json.dumps(res))
