@@ -260,7 +260,11 @@ struct Chain {
     // every edge tile: a value carried around the tile loop may be moved to vector registers again.
     __device__ __forceinline__ void scalar_addresses()
     {
+#if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 64)
+        const uint32_t src = (uint32_t)share;       // (timing experiment: every chunk from the first 32 KB of the image)
+#else
         const uint32_t src = (uint32_t)issue_id * (uint32_t)CHUNK + (uint32_t)share;
+#endif
         const uint32_t dst = (uint32_t)(uintptr_t)ring + (uint32_t)(issue_slot * CHUNK + share);
         if constexpr (!SPREAD) {
             // the burst form (exact-f32 chain) uses them at once, the source as part of a vector address: no assembly needed
@@ -421,7 +425,10 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     using C = Chain<H, PREC>;
     constexpr int NT = C::NT;
     constexpr int STEPS = PREC == 0 ? H / 8 : H / 16;        // k-steps of a tile: 4 f32 MFMAs | 3 f16 MFMAs each
-    constexpr int PFD = STEPS >= 4 ? 2 : 1;                   // weight fragments are read from LDS this many steps ahead
+#ifndef MDX_CHAIN_PFD
+#define MDX_CHAIN_PFD 2
+#endif
+    constexpr int PFD = STEPS >= 2 * MDX_CHAIN_PFD ? MDX_CHAIN_PFD : 1;     // weight fragments are read from LDS this many steps ahead
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
     const int h = lane >> 5, col = lane & 31;
     const int layers = p.n_message + p.n_coord;
