@@ -369,13 +369,33 @@ def cpu_baseline(w, name, budget_s=15.0, resampling=0):
                        f"({elapsed:.1f} s, {per_iter * 1e3:.2f} ms/iteration), extrapolated to the {T}-step job")
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """gloo prints a connection banner on the process's stdout (file descriptor 1, from C++): keep this program's stdout
+    to its one JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def rehearse_launch(args, w, world, rank):
     """The multi-rank control flow of the job on host tensors: what the CPU test of `--gpus N` exercises."""
     import torch.distributed as dist
     from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import AXL
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if world > 1:
-        dist.init_process_group(backend="gloo")
+        with stdout_to_stderr():
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
     batch, n = 4, w["n_atoms"]
     gen = torch.Generator().manual_seed(BASE_SEED + rank)
     comp = AXL(A=torch.randint(0, 2, (batch, n), generator=gen), X=torch.rand(batch, n, 3, generator=gen),
@@ -463,7 +483,9 @@ def main():
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)      # RCCL over xGMI
         else:
-            dist.init_process_group(backend="gloo")
+            with stdout_to_stderr():
+                dist.init_process_group(backend="gloo")
+                dist.barrier()
     coll = (lambda t: t) if args.backend == "nccl" else (lambda t: t.cpu())   # gloo rehearsal: collectives on host copies
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 

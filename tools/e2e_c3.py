@@ -19,12 +19,16 @@ use_graph = "--no-graph" not in sys.argv
 gen, noise, sampling, net = bench.build_generator(w, device, 0, w["batch"], use_graph)
 precision = next((a.split("=")[1] for a in sys.argv if a.startswith("--precision=")), "f16x3")
 net.edge_chain_precision = precision
+repeat = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--repeat=")), 1)
 with torch.no_grad():
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = gen.sample(w["batch"], device)
-    torch.cuda.synchronize()
-    seconds = time.perf_counter() - t0
+    for k in range(repeat):              # (--repeat=2: the second job has no first-call costs: library load, packs, capture)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = gen.sample(w["batch"], device)
+        torch.cuda.synchronize()
+        seconds = time.perf_counter() - t0
+        if k + 1 < repeat:
+            print(json.dumps({"job": f"{name} call {k + 1} of {repeat}", "seconds": round(seconds, 2)}), flush=True)
 assert (out.A != w["num_atom_types"]).all() and torch.isfinite(out.X).all() and (out.X >= 0).all() and (out.X < 1).all()
 print(json.dumps({"job": f"{name} generator.sample({w['batch']}), {w['noise']['total_time_steps']} iterations, end to end",
                   "hip_graph": use_graph, "edge_chain": net.edge_chain_precision,
