@@ -325,9 +325,10 @@ def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
                 f"network forward)",
                 avg_launch_us=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
                 algorithmic_tflops=round(flops / (ms * 1e-3) / 1e12, 2),
-                note="peak = datasheet dense MFMA rate; under a dense f16 MFMA stream on random data this chip holds "
-                     "1.5-1.7 GHz (a launch issuing nothing but this kernel's MFMAs takes 2.12 ms at the C3 shape: "
-                     "profiles/r02_chain_ablation.md)" if split else "")
+                note="peak = datasheet dense MFMA rate at 2.4 GHz; measured inside this kernel (s_memtime / s_memrealtime): "
+                     "1.9-2.0 GHz, matrix pipe busy 59 % of the wavefront's cycles; a launch issuing nothing but this "
+                     "kernel's MFMAs, first layer and stores takes 1.9 ms at the C3 shape (profiles/r02_chain_ablation.md)"
+                if split else "")
 
 
 def cpu_baseline(w, name, budget_s=15.0, resampling=0):
