@@ -161,7 +161,7 @@ __device__ int stamp_n;
 #define MDX_STAMP_REALTIME(id)
 #endif
 
-template <int H, int PREC>
+template <int H, int PREC, bool GUARD = true>
 struct Chain {
     static constexpr int NT = H / 32;                 // accumulator tiles (= weight chunks) per layer
     static constexpr int CHUNK = H * 32 * 4;          // bytes: 32 rows x H k x (4 B f32 | 2 B hi + 2 B lo)
@@ -228,8 +228,16 @@ struct Chain {
         }
 #else
         if constexpr (SPREAD) {
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane16), "s"(src), "s"(dst),
-                         "n"((i & 3) * 1024));
+            // (s_nop 3: with the s_mov, five wait states between whatever precedes this statement and the request.  The
+            // compiler may restore a spilled scalar register with v_readlane right before it, and a scalar register written
+            // by a vector instruction is not yet readable as a memory instruction's address for five wait states -- a rule
+            // it enforces for its own instructions only.)
+            if constexpr (GUARD)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane16), "s"(src), "s"(dst),
+                             "n"((i & 3) * 1024));
+            else
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane16), "s"(src), "s"(dst),
+                             "n"((i & 3) * 1024));
         } else {
             // (the burst form of the exact-f32 chain: the per-lane address as a vector-register pair -- with eight scalar-base
             // requests in a row the row-chain instantiation at H = 256 spills 3.6 KB per lane)
@@ -422,7 +430,9 @@ template <int H, int PREC, int MODE>
 __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(ChainArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    using C = Chain<H, PREC>;
+    // (GUARD: see issue_piece.  The piece-sums instantiations have no scalar-register spills -- checked in the build's
+    // resource listing -- and skip the three wait states: 1 % of the launch.)
+    using C = Chain<H, PREC, MODE != 2>;
     constexpr int NT = C::NT;
     constexpr int STEPS = PREC == 0 ? H / 8 : H / 16;        // k-steps of a tile: 4 f32 MFMAs | 3 f16 MFMAs each
 #ifndef MDX_CHAIN_PFD

@@ -311,3 +311,17 @@ def test_cif_and_xyz_writers(tmp_path):
     assert len(list((tmp_path / "out" / "xyz_files_trajectory_0").iterdir())) == samples
     with pytest.raises(NotImplementedError):
         io.create_io_files(["Si"], tmp_path, None, final, None, "pdb")
+
+
+def test_edge_chain_instantiations_keep_their_request_form_valid():
+    """The piece-sums instantiations of the edge chain (the product's) issue their weight-stream requests without the guard
+    wait states that protect a scalar register restored from a spill (csrc/mdx_egnn_chain.hip, issue_piece): they must not
+    spill scalar registers.  tools/chain_resources.sh cross-compiles the file and reads the code object's metadata."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    out = subprocess.run([os.path.join(ROOT, "tools", "chain_resources.sh")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "<256,1,2>" in out.stdout and "no scalar-register spills" in out.stdout
