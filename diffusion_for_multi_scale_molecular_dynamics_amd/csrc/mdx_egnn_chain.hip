@@ -1007,6 +1007,9 @@ int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
     int64_t tiles = (a.n_edges + kTileEdges - 1) / kTileEdges;
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+#ifdef MDX_CHAIN_MAX_GRID
+    cus = MDX_CHAIN_MAX_GRID;          // (experiment: fewer CUs share the L2s)
+#endif
     const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);       // persistent: one workgroup per CU
     hipLaunchKernelGGL((egnn_edge_chain_kernel<H, PREC, MODE>), dim3(grid), dim3(kWaves * kWave), lds, st, a);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
