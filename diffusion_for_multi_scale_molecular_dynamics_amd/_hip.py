@@ -21,10 +21,11 @@ MAX_CLASSES = 8
 TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
     TAG_INIT_LATTICE, TAG_RESAMPLE_Z, TAG_RESAMPLE_U = range(11)
 
-ABI_VERSION = 6          # MDX_ABI_VERSION of include/mdx_hip.h
+ABI_VERSION = 7          # MDX_ABI_VERSION of include/mdx_hip.h
 ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
+    "mdx_relative_coordinates_update_dev", "mdx_lattice_parameters_update_dev",
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
     "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_radius_graph_fill_capped", "mdx_mlp_forward",
     "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_variant", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
@@ -131,6 +132,10 @@ def _declare(L):
     L.mdx_relative_coordinates_update.argtypes = [vp, vp, vp, f32, f32, f32, i64, vp, vp]
     L.mdx_lattice_parameters_update.restype = i32
     L.mdx_lattice_parameters_update.argtypes = [vp, vp, vp, f32, f32, f32, i64, vp, vp]
+    L.mdx_relative_coordinates_update_dev.restype = i32
+    L.mdx_relative_coordinates_update_dev.argtypes = [vp, vp, vp, vp, i64, vp, vp]
+    L.mdx_lattice_parameters_update_dev.restype = i32
+    L.mdx_lattice_parameters_update_dev.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     L.mdx_atom_types_update.restype = i32
     L.mdx_atom_types_update.argtypes = [vp] * 7 + [i64, i32, i32, f32, i32, i32, vp, vp, vp]
     L.mdx_pc_step_update.restype = i32

@@ -230,8 +230,14 @@ __device__ __forceinline__ float coord_update(float x, float s, float z, float w
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void coords_update_kernel(const float* __restrict__ x, const float* __restrict__ s,
                                                                const float* __restrict__ z, float w, float n,
-                                                               float sigma, int64_t count, float* __restrict__ out)
+                                                               float sigma, int64_t count, float* __restrict__ out,
+                                                               const float* __restrict__ weights_dev)
 {
+    if (weights_dev) {                  // {score weight, noise weight, sigma} computed on the device (adaptive corrector)
+        w = weights_dev[0];
+        n = weights_dev[1];
+        sigma = weights_dev[2];
+    }
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     if (VEC == 4) {
         const int64_t nvec = count >> 2;
@@ -257,8 +263,14 @@ __global__ __launch_bounds__(kBlock) void coords_update_kernel(const float* __re
 }
 
 __global__ __launch_bounds__(kBlock) void lattice_update_kernel(const float* l, const float* s, const float* z, float w,
-                                                                float n, float sigma_n, int64_t count, float* out)
+                                                                float n, float sigma_n, int64_t count, float* out,
+                                                                const float* weights_dev)
 {
+    if (weights_dev) {
+        w = weights_dev[0];
+        n = weights_dev[1];
+        sigma_n = weights_dev[2];
+    }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (l[i] + (w * s[i]) / sigma_n) + n * z[i];
 }
@@ -1860,18 +1872,41 @@ int mdx_fill_time_sigma(const mdx_schedule_t* sched_host, int mode, int index_i,
     return launch_status();
 }
 
-int mdx_relative_coordinates_update(const float* x, const float* s, const float* z, float score_weight,
-                                    float gaussian_noise_weight, float sigma, int64_t count, float* out,
-                                    mdx_stream_t stream)
+static int coordinates_update(const float* x, const float* s, const float* z, float score_weight, float gaussian_noise_weight,
+                              float sigma, const float* weights_dev, int64_t count, float* out, mdx_stream_t stream)
 {
     if (count < 0 || (count > 0 && (!x || !s || !z || !out))) return MDX_ERR_INVALID_ARG;
     if (count == 0) return MDX_OK;
     if (aligned16(x) && aligned16(s) && aligned16(z) && aligned16(out))
         hipLaunchKernelGGL(coords_update_kernel<4>, dim3(flat_grid(cdiv(count, 4))), dim3(kBlock), 0, as_stream(stream), x,
-                           s, z, score_weight, gaussian_noise_weight, sigma, count, out);
+                           s, z, score_weight, gaussian_noise_weight, sigma, count, out, weights_dev);
     else
         hipLaunchKernelGGL(coords_update_kernel<1>, dim3(flat_grid(count)), dim3(kBlock), 0, as_stream(stream), x, s, z,
-                           score_weight, gaussian_noise_weight, sigma, count, out);
+                           score_weight, gaussian_noise_weight, sigma, count, out, weights_dev);
+    return launch_status();
+}
+
+int mdx_relative_coordinates_update(const float* x, const float* s, const float* z, float score_weight,
+                                    float gaussian_noise_weight, float sigma, int64_t count, float* out,
+                                    mdx_stream_t stream)
+{
+    return coordinates_update(x, s, z, score_weight, gaussian_noise_weight, sigma, nullptr, count, out, stream);
+}
+
+int mdx_relative_coordinates_update_dev(const float* x, const float* s, const float* z, const float* weights, int64_t count,
+                                        float* out, mdx_stream_t stream)
+{
+    if (!weights) return MDX_ERR_INVALID_ARG;
+    return coordinates_update(x, s, z, 0.0f, 0.0f, 1.0f, weights, count, out, stream);
+}
+
+static int lattice_update(const float* l, const float* s, const float* z, float score_weight, float gaussian_noise_weight,
+                          float sigma_n, const float* weights_dev, int64_t count, float* out, mdx_stream_t stream)
+{
+    if (count < 0 || (count > 0 && (!l || !s || !z || !out))) return MDX_ERR_INVALID_ARG;
+    if (count == 0) return MDX_OK;
+    hipLaunchKernelGGL(lattice_update_kernel, dim3(flat_grid(count)), dim3(kBlock), 0, as_stream(stream), l, s, z,
+                       score_weight, gaussian_noise_weight, sigma_n, count, out, weights_dev);
     return launch_status();
 }
 
@@ -1879,11 +1914,14 @@ int mdx_lattice_parameters_update(const float* l, const float* s, const float* z
                                   float gaussian_noise_weight, float sigma_n, int64_t count, float* out,
                                   mdx_stream_t stream)
 {
-    if (count < 0 || (count > 0 && (!l || !s || !z || !out))) return MDX_ERR_INVALID_ARG;
-    if (count == 0) return MDX_OK;
-    hipLaunchKernelGGL(lattice_update_kernel, dim3(flat_grid(count)), dim3(kBlock), 0, as_stream(stream), l, s, z,
-                       score_weight, gaussian_noise_weight, sigma_n, count, out);
-    return launch_status();
+    return lattice_update(l, s, z, score_weight, gaussian_noise_weight, sigma_n, nullptr, count, out, stream);
+}
+
+int mdx_lattice_parameters_update_dev(const float* l, const float* s, const float* z, const float* weights, int64_t count,
+                                      float* out, mdx_stream_t stream)
+{
+    if (!weights) return MDX_ERR_INVALID_ARG;
+    return lattice_update(l, s, z, 0.0f, 0.0f, 1.0f, weights, count, out, stream);
 }
 
 int mdx_atom_types_update(const float* logits, const int64_t* atom_types, const float* q, const float* q_bar,

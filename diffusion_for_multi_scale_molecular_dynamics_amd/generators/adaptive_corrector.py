@@ -101,9 +101,9 @@ class AdaptiveCorrectorGenerator(LangevinGenerator):
         else:
             z = self._draw_coordinates_gaussian_sample(batch).to(device).contiguous()
         eps = self._step_size(sigma, predictions.X, z, coordinates=True)
-        eps_h, sigma_h = float(eps), float(sigma)                   # one host read per corrector step
-        x_out = kernels.relative_coordinates_update(x.contiguous(), predictions.X.contiguous(), z, eps_h,
-                                                    float(torch.sqrt(2 * eps)), sigma_h)
+        # the step size is a batch statistic: it stays on the device ({eps, sqrt(2 eps), sigma} read by the kernel)
+        x_out = kernels.relative_coordinates_update(x.contiguous(), predictions.X.contiguous(), z,
+                                                    weights=torch.stack([eps, torch.sqrt(2 * eps), sigma]).float())
         lattice = composition_i.L
         if not device_rng:
             z_lattice = self._draw_lattice_gaussian_sample(batch).to(device)
@@ -117,7 +117,7 @@ class AdaptiveCorrectorGenerator(LangevinGenerator):
                 z_used = self._draw_lattice_gaussian_sample(batch).to(device).contiguous()   # the reference's 2nd draw
             eps_l = self._step_size(sigma_n, predictions.L, z_lattice, coordinates=False)
             lattice = kernels.lattice_parameters_update(lattice.contiguous(), predictions.L.contiguous(), z_used,
-                                                        float(eps_l), float(torch.sqrt(2 * eps_l)), float(sigma_n))
+                                                        weights=torch.stack([eps_l, torch.sqrt(2 * eps_l), sigma_n]).float())
         out = AXL(A=composition_i.A, X=x_out, L=lattice)
         if self.record_corrector:
             self._record_step("corrector_step", ["composition_i", "corrected_composition_i", "model_predictions_i"],

@@ -94,9 +94,18 @@ def fill_time_sigma(sched: DeviceSchedule, mode: int, index_i: int, d_index: Opt
 # ----------------------------------------------------------------------------------------------------------------
 # P1 / P2 / P3 with explicit operands (mirror the reference's private update methods)
 # ----------------------------------------------------------------------------------------------------------------
-def relative_coordinates_update(x, s, z, score_weight: float, gaussian_noise_weight: float, sigma: float, out=None):
+def relative_coordinates_update(x, s, z, score_weight=None, gaussian_noise_weight=None, sigma=None, out=None, weights=None):
+    """P1.  The three scalars as host numbers, or -- `weights`, float32 [3] on the device: {score weight, noise weight,
+    sigma} -- read by the kernel (no host synchronisation: AdaptiveCorrectorGenerator)."""
     assert x.shape == s.shape == z.shape
     out = torch.empty_like(x) if out is None else out
+    if weights is not None:
+        assert weights.numel() == 3
+        rc = lib().mdx_relative_coordinates_update_dev(ptr(x, F32, "x"), ptr(s, F32, "sigma_normalized_scores"), ptr(z, F32, "z"),
+                                                       ptr(weights, F32, "weights"), x.numel(), ptr(out, F32, "out"),
+                                                       stream_handle())
+        check(rc, "mdx_relative_coordinates_update_dev")
+        return out
     rc = lib().mdx_relative_coordinates_update(ptr(x, F32, "x"), ptr(s, F32, "sigma_normalized_scores"),
                                                ptr(z, F32, "z"), float(score_weight), float(gaussian_noise_weight),
                                                float(sigma), x.numel(), ptr(out, F32, "out"), stream_handle())
@@ -104,9 +113,17 @@ def relative_coordinates_update(x, s, z, score_weight: float, gaussian_noise_wei
     return out
 
 
-def lattice_parameters_update(l, s, z, score_weight: float, gaussian_noise_weight: float, sigma_n: float, out=None):
+def lattice_parameters_update(l, s, z, score_weight=None, gaussian_noise_weight=None, sigma_n=None, out=None, weights=None):
+    """P3; `weights` as in relative_coordinates_update."""
     assert l.shape == s.shape == z.shape
     out = torch.empty_like(l) if out is None else out
+    if weights is not None:
+        assert weights.numel() == 3
+        rc = lib().mdx_lattice_parameters_update_dev(ptr(l, F32, "l"), ptr(s, F32, "sigma_normalized_scores"), ptr(z, F32, "z"),
+                                                     ptr(weights, F32, "weights"), l.numel(), ptr(out, F32, "out"),
+                                                     stream_handle())
+        check(rc, "mdx_lattice_parameters_update_dev")
+        return out
     rc = lib().mdx_lattice_parameters_update(ptr(l, F32, "l"), ptr(s, F32, "sigma_normalized_scores"),
                                              ptr(z, F32, "z"), float(score_weight), float(gaussian_noise_weight),
                                              float(sigma_n), l.numel(), ptr(out, F32, "out"), stream_handle())

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 6
+#define MDX_ABI_VERSION 7
 
 /* status codes */
 #define MDX_OK 0
@@ -135,6 +135,14 @@ MDX_API int mdx_relative_coordinates_update(const float* x, const float* sigma_n
 MDX_API int mdx_lattice_parameters_update(const float* l, const float* sigma_normalized_scores, const float* z,
                                   float score_weight, float gaussian_noise_weight, float sigma_n, int64_t count,
                                   float* out, mdx_stream_t stream);
+
+/* P1 / P3 with the three scalars read on the device: weights = {score_weight, gaussian_noise_weight, sigma (sigma_n)}.
+ * AdaptiveCorrectorGenerator (generators/adaptive_corrector.py:97-148): its step size eps_i is a batch statistic of the
+ * scores and the noise -- computed on the device and never read by the host. */
+MDX_API int mdx_relative_coordinates_update_dev(const float* x, const float* sigma_normalized_scores, const float* z,
+                                        const float* weights, int64_t count, float* out, mdx_stream_t stream);
+MDX_API int mdx_lattice_parameters_update_dev(const float* l, const float* sigma_normalized_scores, const float* z,
+                                      const float* weights, int64_t count, float* out, mdx_stream_t stream);
 
 /* P2 -- LangevinGenerator._atom_types_update (generators/langevin_generator.py:247-439) with
  * get_probability_at_previous_time_step / get_probability_from_logits (utils/d3pm_utils.py:64-150).

@@ -472,3 +472,20 @@ def test_bench_contract(cuda, workload):
         assert d["config"]["egnn_edge_chain"] == "f16x3" and d["other_edge_chain_mode"]["egnn_edge_chain"] == "f32"
         assert 0 < d["other_edge_chain_mode"]["value"] < d["value"]
         assert d["config"]["hip_graph"] is True
+
+
+def test_updates_with_device_scalars_equal_host_scalars(cuda):
+    """mdx_relative_coordinates_update_dev / mdx_lattice_parameters_update_dev (the adaptive corrector's step size stays on
+    the device) against the host-scalar entry points: the same bits, aligned and unaligned buffers."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    g = torch.Generator().manual_seed(77)
+    for count, offset in ((4096, 0), (1003, 1)):
+        x, s, z = (torch.rand(count + offset, generator=g).to(cuda)[offset:] for _ in range(3))
+        s, z = (s - 0.5) * 7.0, (z - 0.5) * 5.0
+        w, n, sigma = 0.0123, 0.157, 0.31
+        weights = torch.tensor([w, n, sigma], dtype=torch.float32, device=cuda)
+        w32, n32, s32 = (float(v) for v in weights.cpu())
+        assert torch.equal(kernels.relative_coordinates_update(x, s, z, weights=weights),
+                           kernels.relative_coordinates_update(x, s, z, w32, n32, s32))
+        assert torch.equal(kernels.lattice_parameters_update(x, s, z, weights=weights),
+                           kernels.lattice_parameters_update(x, s, z, w32, n32, s32))
