@@ -404,3 +404,38 @@ def test_edge_chain_piece_sums_against_fp64(cuda, precision, H, n_nodes, deg):
     assert (got_sum[degree == 0] == 0).all()
     node_err = ((got_mean.double().cpu() - want_mean).norm(dim=1) / want_mean.norm(dim=1).clamp(min=1e-30))[degree > 0].max()
     assert float(node_err) < 20 * tol, float(node_err)
+
+
+@pytest.mark.parametrize("n_tiles", [1, 7, 8, 9, 15, 17, 255, 256, 257, 300, 513])
+def test_edge_chain_tile_order_covers_every_tile(cuda, n_tiles):
+    """The XCD-contiguous tile order of the edge chain (one eighth of the tiles per XCD, walked by that XCD's workgroups):
+    every 128-edge tile is computed exactly once whatever the number of tiles is relative to 8, to the number of CUs and to
+    their multiples -- rows mode, every edge's message and scalar against fp64; the last tile ragged; with and without a
+    device-side edge count smaller than the list's capacity."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    H, n_in, D = 32, 6, 3
+    E = 128 * (n_tiles - 1) + 37
+    n_nodes = max(E // 9, 2)
+    g = torch.Generator().manual_seed(n_tiles)
+    torch.manual_seed(n_tiles)
+    lin0, msg, crd = torch.nn.Linear(2 * n_in + 1, H), [torch.nn.Linear(H, H)], [torch.nn.Linear(H, H)]
+    out = torch.nn.Linear(H, 1, bias=False)
+    src = torch.sort(torch.randint(0, n_nodes, (E,), generator=g)).values
+    dst = torch.randint(0, n_nodes, (E,), generator=g)
+    edges = torch.stack([src, dst], 1)
+    h = torch.randn(n_nodes, n_in, generator=g)
+    coord = torch.rand(n_nodes, D, generator=g) * 2 - 1
+    want_m, want_s = _chain_reference(lin0, msg, crd, out, n_in, h, coord, edges)
+    mods = [m.to(cuda) for m in [lin0] + msg + crd + [out]]
+    pack = kernels.EdgeChainPack(mods[0], mods[1:2], mods[2:3], mods[3], input_size=n_in, precision="f32")
+    w = mods[0].weight.detach()
+    proj = torch.nn.functional.linear(h.to(cuda), torch.cat([w[:, :n_in], w[:, n_in:2 * n_in]], 0)).contiguous()
+    coord_d = coord.to(cuda).contiguous()
+    for capacity in (E, E + 1000):
+        edges_d = torch.zeros(capacity, 2, dtype=torch.int64, device=cuda)
+        edges_d[:E] = edges.to(cuda)
+        count = torch.tensor([E], dtype=torch.int64, device=cuda) if capacity > E else None
+        got_m, got_s = kernels.egnn_edge_chain(pack, proj, coord_d, edges_d, n_edges_dev=count)
+        row_err = (got_m[:E].double().cpu() - want_m).norm(dim=1) / want_m.norm(dim=1).clamp(min=1e-30)
+        assert float(row_err.max()) < 1e-4, (capacity, int(row_err.argmax()) // 128, float(row_err.max()))
+        assert _rel_l2(got_s[:E], want_s) < 1e-5
