@@ -599,6 +599,9 @@ class EdgeChainPack:
         self.biases = torch.stack([layer.bias.detach().to(F32) for layer in layers]).contiguous()
         self.bias_in = first_message_layer.bias.detach().to(F32).contiguous()
         self.w_radial = first_message_layer.weight.detach()[:, 2 * input_size].to(F32).contiguous()
+        # [2H, n_in]: the per-node projections of the first message layer (source half | destination half) as ONE matrix
+        w0 = first_message_layer.weight.detach().to(F32)
+        self.proj_weight = torch.cat([w0[:, :input_size], w0[:, input_size:2 * input_size]], dim=0).contiguous()
         self.c_struct = _hip.EgnnChain(H, len(list(message_layers)), len(list(coord_layers)),
                                        EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
                                        self.biases.data_ptr(), self.bias_in.data_ptr(), self.w_radial.data_ptr())

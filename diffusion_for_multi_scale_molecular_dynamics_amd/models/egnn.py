@@ -251,9 +251,7 @@ class E_GCL(nn.Module):
         """E_GCL.forward with the per-edge work in one MFMA kernel: node projections (library GEMM, per node) -> fused
         chain -> the two sorted-segment reductions -> node MLP."""
         from .. import kernels
-        first, n_in = self.message_mlp[0], self.input_size
-        w = first.weight
-        proj = torch.nn.functional.linear(h, torch.cat([w[:, :n_in], w[:, n_in:2 * n_in]], dim=0))
+        proj = torch.nn.functional.linear(h, pack.proj_weight)      # (the pack is rebuilt when a parameter changes)
         coord = coord.contiguous()
         # the messages are added up per node inside the kernel (piece sums) and never written out as [E, H]
         in_kernel = pack.piece_sums_ok and h.shape[0] < (1 << 31)
