@@ -1,0 +1,23 @@
+"""The kernels of ONE network forward of the C3 iteration, in launch order with their durations, from a rocprofv3 kernel trace:
+    rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline
+    python3 tools/kernel_sequence.py /tmp/tr
+(a forward = the launches between two fills of the radius graph)."""
+import csv
+import glob
+import re
+import sys
+
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+names = [(r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows]
+marks = [i for i, (n, _) in enumerate(names) if "radius_graph_kernel<true>" in n]
+spans = [(a, b) for a, b in zip(marks, marks[1:]) if b - a > 10]
+a, b = spans[-1]
+total = 0.0
+for n, us in names[a:b]:
+    short = re.sub(r"\(anonymous namespace\)::", "", n)
+    short = re.sub(r"^void ", "", short)
+    short = re.split(r"\(", short)[0][:95]
+    print(f"{us:9.1f} us  {short}")
+    total += us
+print(f"{total:9.1f} us in {b - a} kernels")
