@@ -188,7 +188,7 @@ def _declare(L):
     L.mdx_egnn_edge_chain.restype = i32
     L.mdx_egnn_edge_chain.argtypes = [C.POINTER(EgnnChain), vp, vp, i32, vp, i64, vp, vp, vp, vp, vp]
     L.mdx_segment_combine.restype = i32
-    L.mdx_segment_combine.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp]
+    L.mdx_segment_combine.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.mdx_mlp_chain_rows.restype = i32
     L.mdx_mlp_chain_rows.argtypes = [C.POINTER(EgnnChain), vp, vp, i64, vp, vp, vp, vp]
     L.mdx_egnn_coord_aggregate.restype = i32

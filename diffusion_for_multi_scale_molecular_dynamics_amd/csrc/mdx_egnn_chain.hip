@@ -966,9 +966,11 @@ __global__ __launch_bounds__(256) void egnn_coord_aggregate_kernel(const float* 
 
 // out[i,:] = (1/degree_i if mean) x sum of node i's pieces: rows e with e in [offset_i, offset_i + degree_i) and
 // (e % 16 == 15 or e == offset_i + degree_i - 1), in increasing e.  One wavefront per node, 16 bytes per lane.
+// `left` (nullable): out rows are [left[i,:] | sum_i] of width 2 H -- the input of the node MLP's first layer (h | agg), written
+// in the one pass over the nodes instead of a concatenation afterwards.
 __global__ __launch_bounds__(256) void segment_combine_kernel(const float* __restrict__ pieces, const int64_t* __restrict__ offsets,
                                                               const int64_t* __restrict__ degree, int64_t n_nodes, int H,
-                                                              int mean, float* __restrict__ out)
+                                                              int mean, float* __restrict__ out, const float* __restrict__ left)
 {
     const int lane = threadIdx.x % kWave;
     const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / kWave;
@@ -982,7 +984,12 @@ __global__ __launch_bounds__(256) void segment_combine_kernel(const float* __res
             for (int64_t e = e0 | 15; e < e1 - 1; e += 16) acc += reinterpret_cast<const f32x4*>(pieces + e * H)[q];
             if (deg > 0) acc += reinterpret_cast<const f32x4*>(pieces + (e1 - 1) * H)[q];
             if (mean) acc *= scale;
-            reinterpret_cast<f32x4*>(out + node * H)[q] = acc;
+            if (left) {
+                reinterpret_cast<f32x4*>(out + node * 2 * H)[q] = reinterpret_cast<const f32x4*>(left + node * H)[q];
+                reinterpret_cast<f32x4*>(out + node * 2 * H + H)[q] = acc;
+            } else {
+                reinterpret_cast<f32x4*>(out + node * H)[q] = acc;
+            }
         }
     }
 }
@@ -1090,7 +1097,7 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
 }
 
 int mdx_segment_combine(const float* pieces, const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int H, int mean,
-                        float* out, mdx_stream_t stream)
+                        const float* left, float* out, mdx_stream_t stream)
 {
     if (n_nodes < 0 || H < 4) return MDX_ERR_INVALID_ARG;
     if (H & 3) return MDX_ERR_UNSUPPORTED;
@@ -1099,7 +1106,7 @@ int mdx_segment_combine(const float* pieces, const int64_t* offsets, const int64
     int64_t blocks = (n_nodes * kWave + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(segment_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       pieces, offsets, degree, n_nodes, H, mean, out);
+                       pieces, offsets, degree, n_nodes, H, mean, out, left);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 

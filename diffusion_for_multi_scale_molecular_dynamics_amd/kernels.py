@@ -683,12 +683,14 @@ def egnn_edge_chain(pack: EdgeChainPack, node_proj, coord, edges, status=None, n
     return messages, scalar
 
 
-def segment_combine(pieces, offsets, degree, mean: bool) -> torch.Tensor:
-    """Sum (or mean) over each node's edges from the piece sums of egnn_edge_chain(..., piece_sums=True) -> [n_nodes, H]."""
+def segment_combine(pieces, offsets, degree, mean: bool, left=None) -> torch.Tensor:
+    """Sum (or mean) over each node's edges from the piece sums of egnn_edge_chain(..., piece_sums=True) -> [n_nodes, H];
+    with `left` [n_nodes, H]: [left | sums], [n_nodes, 2H] (the node MLP's input, without a separate concatenation)."""
     n_nodes, H = degree.shape[0], pieces.shape[1]
-    out = torch.empty(n_nodes, H, dtype=F32, device=pieces.device)
+    assert left is None or tuple(left.shape) == (n_nodes, H)
+    out = torch.empty(n_nodes, H if left is None else 2 * H, dtype=F32, device=pieces.device)
     rc = lib().mdx_segment_combine(ptr(pieces, F32, "pieces"), ptr(offsets, I64, "offsets"), ptr(degree, I64, "degree"),
-                                   n_nodes, H, int(bool(mean)), ptr(out, F32, "out"), stream_handle())
+                                   n_nodes, H, int(bool(mean)), ptr(left, F32, "left"), ptr(out, F32, "out"), stream_handle())
     check(rc, "mdx_segment_combine")
     return out
 

@@ -258,11 +258,12 @@ class E_GCL(nn.Module):
         messages, edge_scalar = kernels.egnn_edge_chain(pack, proj.contiguous(), coord, edge_index, status=self.status_word,
                                                         n_edges_dev=n_edges, piece_sums=in_kernel)
         coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean)
-        if in_kernel:
-            agg = kernels.segment_combine(messages, offsets, degree, self.message_mean)
+        if in_kernel and h.shape[1] == messages.shape[1]:
+            node_in = kernels.segment_combine(messages, offsets, degree, self.message_mean, left=h.contiguous())     # [h | agg]
         else:
-            agg = kernels.segment_rows(messages, offsets, degree, self.message_mean)
-        node_in = torch.cat([h, agg], dim=1)
+            agg = (kernels.segment_combine(messages, offsets, degree, self.message_mean) if in_kernel
+                   else kernels.segment_rows(messages, offsets, degree, self.message_mean))
+            node_in = torch.cat([h, agg], dim=1)
         node_pack = self._node_chain_pack()
         if node_pack is not None and (not self.residual or h.shape[1] == node_pack.hidden):
             # first node layer (2H -> H, + SiLU): library GEMM per node; the other layers and the residual: one MFMA launch

@@ -391,9 +391,11 @@ MDX_API int mdx_egnn_edge_chain(const mdx_egnn_chain_t* chain_host, const float*
  * such edge; every other row of messages_out is left untouched.  mdx_segment_combine then gives
  * out[i,:] = (1/degree_i if mean) sum of node i's pieces, read in row order -- unsorted_segment_sum / _mean of the messages
  * (models/egnn_utils.py:11-70) with a fixed summation order and no atomics; it replaces mdx_segment_rows, reads ~2 rows
- * per node instead of degree_i, and the messages themselves never reach memory.  Node indices must be < 2^31. */
+ * per node instead of degree_i, and the messages themselves never reach memory.  Node indices must be < 2^31.
+ * left (nullable, [n_nodes,H]): out is [n_nodes, 2H] = [left | sums] -- torch.cat([h, agg], dim=1), the input of the node
+ * MLP (models/egnn.py:202-230), written in the same pass. */
 MDX_API int mdx_segment_combine(const float* pieces, const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int H,
-                                int mean, float* out, mdx_stream_t stream);
+                                int mean, const float* left, float* out, mdx_stream_t stream);
 
 /* The same pipeline over the ROWS of a matrix (the per-node MLP of an EGNN layer, models/egnn.py:202-230, after its first
  * layer): out[r,:] = residual[r,:] + W_L (SiLU(W_{L-1} ... SiLU(W_1 x[r,:] + b_1) ...)) + b_L -- L = chain->n_message_layers

@@ -402,6 +402,10 @@ def test_edge_chain_piece_sums_against_fp64(cuda, precision, H, n_nodes, deg):
     assert _rel_l2(got_mean, rows_mean) < 1e-6
     assert torch.equal(scalar, scalar2)                             # the coordinate branch does not depend on the mode
     assert (got_sum[degree == 0] == 0).all()
+    # [left | sums] in one pass: torch.cat([left, sums], 1), bit for bit
+    left = torch.randn(n_nodes, H, generator=g).to(cuda)
+    both = kernels.segment_combine(pieces, offsets, degree.to(cuda), True, left=left)
+    assert both.shape == (n_nodes, 2 * H) and torch.equal(both, torch.cat([left, got_mean], dim=1))
     node_err = ((got_mean.double().cpu() - want_mean).norm(dim=1) / want_mean.norm(dim=1).clamp(min=1e-30))[degree > 0].max()
     assert float(node_err) < 20 * tol, float(node_err)
 
