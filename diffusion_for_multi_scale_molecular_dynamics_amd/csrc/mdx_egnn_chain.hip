@@ -16,8 +16,12 @@
 //     in registers: no LDS round trip, no shuffles.  The k permutation is folded into the weight image once, at pack time.
 //   * the weights stream through LDS: the image of a layer is cut into chunks of 32 output rows (32 KB at H = 256, the A
 //     fragments of one accumulator tile, lane-linear => conflict-free ds_read_b128), copied global -> LDS by direct-to-LDS
-//     loads (no VGPRs) into a 3-slot ring, two chunks ahead of the MFMAs, one s_barrier per chunk.  All workgroups stream
-//     the same 2.3 MB per E_GCL layer: L2-resident.
+//     loads (no VGPRs) into a 4-slot ring, three chunks ahead of the MFMAs, one s_barrier per chunk in the middle of a
+//     tile; a wavefront requests one quarter of each chunk, one 1-KB piece per two k-steps.  All workgroups stream the
+//     same 2.4 MB per E_GCL layer: L2-resident.
+//   * tiles are dealt to workgroups XCD by XCD (each XCD one contiguous eighth of the edge list: its L2 holds the node rows of
+//     two or three structures beside the weight image); with message_mode = piece sums the messages are added up per node
+//     inside the kernel (a segmented scan over DPP rows) and only those sums are written.
 //   * two arithmetic modes (same kernel structure, same images' logical content):
 //       PREC 0  v_mfma_f32_32x32x2_f32: exact binary32 products and sums (== a k-ordered fmaf chain): the reference's
 //               arithmetic up to summation order.  Bound: 157 TFLOP/s.
