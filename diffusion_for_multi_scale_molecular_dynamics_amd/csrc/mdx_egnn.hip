@@ -53,6 +53,58 @@ __global__ __launch_bounds__(kBlock) void egnn_message_input_kernel(const float*
     }
 }
 
+// EGNNScoreNetwork's per-node inputs in one pass (models/score_networks/egnn_score_network.py:253-281, models/egnn.py:292-330):
+//   z[i, 2k] = cos(2 pi x_i . K_k),  z[i, 2k+1] = sin(2 pi x_i . K_k)           the torus uplift of the relative coordinates
+//   h[i, :]  = b + sigma_{s(i)} W[:, 0] + W[:, 1 + a_i]                         embedding_in applied to [sigma | one_hot(a_i)]
+// (the reference builds [sigma | one_hot] and multiplies by W^T; with a one-hot input that is a column pick -- the same
+// binary32 operations in the same order: fl(fl(b + fl(sigma w0)) + w_a), every other term an exact zero).
+__global__ __launch_bounds__(kBlock) void egnn_node_inputs_kernel(const float* __restrict__ x, const float* __restrict__ k_vectors,
+                                                                  int n_k, const float* __restrict__ sigma, int atoms_per_structure,
+                                                                  const int64_t* __restrict__ atom_types,
+                                                                  const float* __restrict__ w, const float* __restrict__ b,
+                                                                  int F, int H, int64_t n_nodes, float* __restrict__ z,
+                                                                  float* __restrict__ h)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int64_t t = t0; t < n_nodes * H; t += stride) {
+        const int64_t i = t / H;
+        const int j = (int)(t - i * H);
+        const float s = sigma[i / atoms_per_structure];
+        const int64_t a = atom_types[i];
+        float v = b[j] + s * w[(int64_t)j * F];
+        if (a >= 0 && a + 1 < F) v = v + w[(int64_t)j * F + 1 + a];
+        h[t] = v;
+    }
+    for (int64_t t = t0; t < n_nodes * n_k; t += stride) {
+        const int64_t i = t / n_k;
+        const int k = (int)(t - i * n_k);
+        float kr = 0.0f;
+        for (int d = 0; d < 3; ++d) kr = kr + (6.2831855f * x[3 * i + d]) * k_vectors[3 * k + d];
+        z[2 * t] = cosf(kr);
+        z[2 * t + 1] = sinf(kr);
+    }
+}
+
+// S^alpha_i = z_i . Gamma^alpha . xhat_i with Gamma^alpha = blockdiag_k(K_k[alpha] [[0,-1],[1,0]])  (egnn_score_network.py:103-133,
+// 283-290): per node and direction, sum_k K_k[alpha] (z_{2k+1} xhat_{2k} - z_{2k} xhat_{2k+1}).
+__global__ __launch_bounds__(kBlock) void egnn_scores_kernel(const float* __restrict__ z, const float* __restrict__ x_hat,
+                                                             const float* __restrict__ k_vectors, int n_k, int64_t n_nodes,
+                                                             float* __restrict__ scores)
+{
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_nodes * 3; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / 3;
+        const int alpha = (int)(t - 3 * i);
+        const float* zi = z + i * 2 * n_k;
+        const float* xi = x_hat + i * 2 * n_k;
+        float acc = 0.0f;
+        for (int k = 0; k < n_k; ++k) {
+            const float kk = k_vectors[3 * k + alpha];
+            acc = acc + ((zi[2 * k] * -kk) * xi[2 * k + 1] + (zi[2 * k + 1] * kk) * xi[2 * k]);
+        }
+        scores[t] = acc;
+    }
+}
+
 // Segment kernels on the radius graph's sorted edge list (edges of node i are rows [offset_i, offset_i + degree_i)):
 // one wavefront per node, a row of H floats read as 16-byte lane loads (H = 256: one fully coalesced 1-KB row per
 // instruction), four rows in flight.  No atomics; the summation order is fixed (edge order), run-to-run deterministic.
@@ -218,6 +270,34 @@ static unsigned node_grid(int64_t n_nodes)
     int64_t blocks = (n_nodes * kWave + kBlock - 1) / kBlock;       // one wavefront per node
     if (blocks > 16384) blocks = 16384;
     return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+int mdx_egnn_node_inputs(const float* x, const float* k_vectors, int n_k, const float* sigma, int atoms_per_structure,
+                         const int64_t* atom_types, const float* emb_weight, const float* emb_bias, int n_features, int H,
+                         int64_t n_nodes, float* z_out, float* h_out, mdx_stream_t stream)
+{
+    if (n_nodes < 0 || n_k < 1 || atoms_per_structure < 1 || n_features < 2 || H < 1) return MDX_ERR_INVALID_ARG;
+    if (n_nodes == 0) return MDX_OK;
+    if (!x || !k_vectors || !sigma || !atom_types || !emb_weight || !emb_bias || !z_out || !h_out) return MDX_ERR_INVALID_ARG;
+    int64_t blocks = (n_nodes * H + kBlock - 1) / kBlock;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(egnn_node_inputs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), x,
+                       k_vectors, n_k, sigma, atoms_per_structure, atom_types, emb_weight, emb_bias, n_features, H, n_nodes,
+                       z_out, h_out);
+    return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
+}
+
+int mdx_egnn_scores(const float* z, const float* x_hat, const float* k_vectors, int n_k, int64_t n_nodes, float* scores_out,
+                    mdx_stream_t stream)
+{
+    if (n_nodes < 0 || n_k < 1) return MDX_ERR_INVALID_ARG;
+    if (n_nodes == 0) return MDX_OK;
+    if (!z || !x_hat || !k_vectors || !scores_out) return MDX_ERR_INVALID_ARG;
+    int64_t blocks = (n_nodes * 3 + kBlock - 1) / kBlock;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(egnn_scores_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), z, x_hat,
+                       k_vectors, n_k, n_nodes, scores_out);
+    return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 
 int mdx_egnn_coord_head(const float* hidden, const float* w_out, const float* coord_diff, const int64_t* offsets,

@@ -695,6 +695,33 @@ def segment_combine(pieces, offsets, degree, mean: bool, left=None) -> torch.Ten
     return out
 
 
+def egnn_node_inputs(x, k_vectors, sigma, atom_types, emb_weight, emb_bias):
+    """z [n_nodes, 2 n_k] (torus uplift) and h [n_nodes, H] (embedding of [sigma | one_hot]) of EGNNScoreNetwork, one launch.
+    x [B, N, 3] relative coordinates, sigma [B] (or [B,1]), atom_types [B, N] int64."""
+    B, N, d = x.shape
+    assert d == 3 and k_vectors.shape[1] == 3
+    n_nodes, n_k, (H, F) = B * N, k_vectors.shape[0], emb_weight.shape
+    z = torch.empty(n_nodes, 2 * n_k, dtype=F32, device=x.device)
+    h = torch.empty(n_nodes, H, dtype=F32, device=x.device)
+    rc = lib().mdx_egnn_node_inputs(ptr(x, F32, "x"), ptr(k_vectors, F32, "k_vectors"), n_k, ptr(sigma, F32, "sigma"), N,
+                                    ptr(atom_types, I64, "atom_types"), ptr(emb_weight, F32, "emb_weight"),
+                                    ptr(emb_bias, F32, "emb_bias"), F, H, n_nodes, ptr(z, F32, "z"), ptr(h, F32, "h"),
+                                    stream_handle())
+    check(rc, "mdx_egnn_node_inputs")
+    return z, h
+
+
+def egnn_scores(z, x_hat, k_vectors):
+    """S^alpha = z . Gamma^alpha . x_hat per node -> [n_nodes, 3]  (mdx_egnn_scores)."""
+    n_nodes, n_k = z.shape[0], k_vectors.shape[0]
+    assert z.shape == x_hat.shape == (n_nodes, 2 * n_k)
+    out = torch.empty(n_nodes, 3, dtype=F32, device=z.device)
+    rc = lib().mdx_egnn_scores(ptr(z, F32, "z"), ptr(x_hat, F32, "x_hat"), ptr(k_vectors, F32, "k_vectors"), n_k, n_nodes,
+                               ptr(out, F32, "scores"), stream_handle())
+    check(rc, "mdx_egnn_scores")
+    return out
+
+
 def egnn_coord_aggregate(edge_scalar, coord, edges, offsets, degree, mean: bool) -> torch.Tensor:
     """coord + segment sum/mean of (coord_i - coord_dst) * edge_scalar over each node's sorted edges."""
     out = torch.empty_like(coord)

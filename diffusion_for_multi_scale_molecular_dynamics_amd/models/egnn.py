@@ -304,11 +304,14 @@ class EGNN(nn.Module):
                 act_fn=act_fn, residual=residual, attention=attention, normalize=normalize, coords_agg=coords_agg,
                 message_agg=message_agg, tanh=tanh))
 
-    def forward(self, h: torch.Tensor, edges: torch.Tensor, x: torch.Tensor, degree=None) -> AXL:
+    def forward(self, h: torch.Tensor, edges: torch.Tensor, x: torch.Tensor, degree=None, embedded: bool = False) -> AXL:
         """degree: None (a caller's own edge list, any order), the edge count per node [n_nodes] of a list sorted by source,
-        or the triple (degree, offsets, n_edges) of a capacity-sized list (utils/neighbors.get_edges_static)."""
+        or the triple (degree, offsets, n_edges) of a capacity-sized list (utils/neighbors.get_edges_static).
+        embedded: h is already embedding_in(node features) (kernels.egnn_node_inputs)."""
         emb = self.embedding_in
-        if h.is_cuda and emb.in_features <= 8:
+        if embedded:
+            assert h.shape[1] == emb.out_features
+        elif h.is_cuda and emb.in_features <= 8:
             # [sigma | one-hot type] -> hidden: with 2-4 input features the library GEMM spends 0.45 ms on a K = 3
             # problem; as rank-1 updates it is a few elementwise passes over [n_nodes, hidden]
             out = emb.bias.unsqueeze(0) + h[:, :1] * emb.weight[:, 0].unsqueeze(0)

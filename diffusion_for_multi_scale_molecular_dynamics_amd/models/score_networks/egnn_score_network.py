@@ -186,6 +186,22 @@ class EGNNScoreNetwork(ScoreNetwork):
             layer.status_word = self.graph_status if x.is_cuda else None
         edges, degree = self._build_edges(x, comp.L)
 
+        emb = self.egnn.embedding_in
+        sigma_in = batch[NOISE]
+        if (x.is_cuda and not torch.is_grad_enabled() and d == 3 and x.dtype == torch.float32 and
+                emb.in_features == self.num_atom_types + 2 and sigma_in.numel() == bsz):
+            # inputs and outputs around the EGNN as one launch each (mdx_egnn_node_inputs / mdx_egnn_scores) instead of
+            # ~25 elementwise passes per forward; the same arithmetic (see include/mdx_hip.h)
+            from ... import kernels
+            k_vectors = self.bloch_wave_reciprocal_lattice_vectors.to(x)
+            z, h = kernels.egnn_node_inputs(x.contiguous(), k_vectors.contiguous(),
+                                            sigma_in.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous(),
+                                            comp.A.reshape(bsz, n).long().contiguous(), emb.weight.detach().contiguous(),
+                                            emb.bias.detach().contiguous())
+            out = self.egnn(h=h, edges=edges, x=z, degree=degree, embedded=True)
+            scores = kernels.egnn_scores(z, out.X.contiguous(), k_vectors.contiguous())
+            return AXL(A=out.A.reshape(bsz, n, -1), X=scores.reshape(bsz, n, d), L=torch.zeros_like(comp.L))
+
         flat = x.reshape(bsz * n, d)
         k_vectors = self.bloch_wave_reciprocal_lattice_vectors.to(flat)
         if flat.is_cuda:      # K = d = 3: as a library GEMM this costs ~0.45 ms; as a broadcast product it is one small pass

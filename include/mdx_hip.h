@@ -397,6 +397,21 @@ MDX_API int mdx_egnn_edge_chain(const mdx_egnn_chain_t* chain_host, const float*
 MDX_API int mdx_segment_combine(const float* pieces, const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int H,
                                 int mean, const float* left, float* out, mdx_stream_t stream);
 
+/* EGNNScoreNetwork's per-node inputs and outputs around the EGNN (models/score_networks/egnn_score_network.py:253-290), one
+ * launch each instead of a dozen elementwise passes (spatial dimension 3):
+ *   mdx_egnn_node_inputs   z [n_nodes, 2 n_k] = (cos, sin)(2 pi x . K_k) interleaved -- the torus uplift of the relative
+ *                          coordinates x [n_nodes,3] with the Bloch wave vectors K [n_k,3] -- and h [n_nodes,H] =
+ *                          EGNN.embedding_in([sigma | one_hot(atom type)]) = b + sigma W[:,0] + W[:,1 + a]
+ *                          (emb_weight [H, n_features] row-major, n_features = 2 + number of atom types; sigma [B] per
+ *                          structure, atoms_per_structure nodes each; the same binary32 operations as the reference's);
+ *   mdx_egnn_scores        S^alpha = z . Gamma^alpha . x_hat, Gamma^alpha = blockdiag_k(K_k[alpha] [[0,-1],[1,0]]):
+ *                          scores [n_nodes,3] from the EGNN's coordinate output x_hat [n_nodes, 2 n_k]. */
+MDX_API int mdx_egnn_node_inputs(const float* x, const float* k_vectors, int n_k, const float* sigma, int atoms_per_structure,
+                                 const int64_t* atom_types, const float* emb_weight, const float* emb_bias, int n_features,
+                                 int H, int64_t n_nodes, float* z_out, float* h_out, mdx_stream_t stream);
+MDX_API int mdx_egnn_scores(const float* z, const float* x_hat, const float* k_vectors, int n_k, int64_t n_nodes,
+                            float* scores_out, mdx_stream_t stream);
+
 /* The same pipeline over the ROWS of a matrix (the per-node MLP of an EGNN layer, models/egnn.py:202-230, after its first
  * layer): out[r,:] = residual[r,:] + W_L (SiLU(W_{L-1} ... SiLU(W_1 x[r,:] + b_1) ...)) + b_L -- L = chain->n_message_layers
  * layers of H x H (chain->n_coord_layers must be 0; bias_in / w_radial unused; image packed with w_out = NULL), every layer

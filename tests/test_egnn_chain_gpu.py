@@ -1,5 +1,7 @@
 """The hand-written MFMA edge-chain kernel (csrc/mdx_egnn_chain.hip) against fp64 references, through the C ABI."""
 import numpy as np
+import math
+
 import pytest
 import torch
 
@@ -443,3 +445,34 @@ def test_edge_chain_tile_order_covers_every_tile(cuda, n_tiles):
         row_err = (got_m[:E].double().cpu() - want_m).norm(dim=1) / want_m.norm(dim=1).clamp(min=1e-30)
         assert float(row_err.max()) < 1e-4, (capacity, int(row_err.argmax()) // 128, float(row_err.max()))
         assert _rel_l2(got_s[:E], want_s) < 1e-5
+
+
+def test_egnn_node_inputs_and_scores_against_torch(cuda):
+    """mdx_egnn_node_inputs / mdx_egnn_scores against the expressions they replace in EGNNScoreNetwork: the embedded node
+    features bit for bit (a one-hot input is a column pick: the same binary32 operations), the torus uplift and the score
+    contraction to rounding (a different summation order over three / 2 n_k terms)."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import (
+        EGNNScoreNetwork, positive_bloch_wave_vectors)
+    g = torch.Generator().manual_seed(5)
+    B, N, C, H = 7, 13, 2, 96
+    x = torch.rand(B, N, 3, generator=g).to(cuda)
+    sigma = (torch.rand(B, 1, generator=g) * 0.5 + 0.01).to(cuda)
+    a = torch.randint(0, C + 1, (B, N), generator=g).to(cuda)             # MASK class included
+    emb = torch.nn.Linear(C + 2, H).to(cuda)
+    kv = positive_bloch_wave_vectors(2, 3).to(cuda)
+    z, h = kernels.egnn_node_inputs(x, kv, sigma.reshape(-1).contiguous(), a, emb.weight.detach(), emb.bias.detach())
+    feats = torch.cat([sigma.repeat_interleave(N, dim=0), torch.nn.functional.one_hot(a.reshape(-1), C + 1).float()], dim=1)
+    want_h = emb.bias.unsqueeze(0) + feats[:, :1] * emb.weight[:, 0].unsqueeze(0)
+    for k in range(1, C + 2):
+        want_h = torch.addcmul(want_h, feats[:, k:k + 1], emb.weight[:, k].unsqueeze(0))
+    assert torch.equal(h, want_h.detach())
+    flat = x.reshape(B * N, 3)
+    kr = ((2.0 * math.pi * flat)[:, None, :] * kv[None, :, :]).sum(dim=-1)
+    want_z = torch.stack([kr.cos(), kr.sin()], dim=2).reshape(B * N, -1)
+    assert (z - want_z).abs().max() < 2e-6
+    x_hat = torch.randn(B * N, 2 * kv.shape[0], generator=g).to(cuda)
+    gamma = EGNNScoreNetwork._projection_matrices(kv.cpu()).to(cuda)
+    want_s = torch.einsum("ni,aij,nj->na", want_z.double(), gamma.double(), x_hat.double())
+    got_s = kernels.egnn_scores(want_z.contiguous(), x_hat, kv)
+    assert _rel_l2(got_s, want_s) < 1e-6
