@@ -358,11 +358,6 @@ struct Chain {
 #pragma unroll
             for (int i = 0; i < LPW; ++i) issue_piece(i);
         }
-#ifdef MDX_CHAIN_SKEW
-        // a few cycles between the wavefronts, so that their requests do not meet at the address path
-        if (wave & 1) asm volatile("s_nop 15" ::: "memory");
-        if (wave & 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#endif
         slot_read = slot_read + 1 == kRing ? 0 : slot_read + 1;
         return ring + slot_read * CHUNK;
     }
@@ -650,14 +645,9 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     }
                 } else {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].hi, in.hi[s], acc, 0, 0, 0);
-#ifndef MDX_CHAIN_DMA_LATE
                     if (C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
-#endif
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].hi, in.lo[s], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].lo, in.hi[s], acc, 0, 0, 0);
-#ifdef MDX_CHAIN_DMA_LATE
-                    if (g % PERIOD == 0) ch.issue_piece(g / PERIOD);
-#endif
                 }
 #ifdef MDX_CHAIN_PIN_STEPS
                 __builtin_amdgcn_sched_barrier(0);      // keep each k-step's share of vector work beside ITS MFMAs
