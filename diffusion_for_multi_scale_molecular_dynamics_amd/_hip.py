@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_radius_graph_fill_capped", "mdx_mlp_forward",
     "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_variant", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
     "mdx_egnn_chain_image_bytes", "mdx_egnn_chain_pack", "mdx_egnn_edge_chain", "mdx_segment_combine", "mdx_mlp_chain_rows", "mdx_egnn_coord_aggregate",
-    "mdx_egnn_node_inputs", "mdx_egnn_scores",
+    "mdx_egnn_node_inputs", "mdx_egnn_scores", "mdx_node_mlp_rows",
     "mdx_rng_fill", "mdx_math_probe",
 )
 MLP_MAX_HIDDEN = 8
@@ -188,6 +188,8 @@ def _declare(L):
     L.mdx_egnn_chain_pack.argtypes = [C.POINTER(vp), i32, vp, i32, i32, vp, vp]
     L.mdx_egnn_edge_chain.restype = i32
     L.mdx_egnn_edge_chain.argtypes = [C.POINTER(EgnnChain), vp, vp, i32, vp, i64, vp, vp, vp, vp, vp]
+    L.mdx_node_mlp_rows.restype = i32
+    L.mdx_node_mlp_rows.argtypes = [vp, vp, i32, i64, vp, vp, vp, vp]
     L.mdx_egnn_node_inputs.restype = i32
     L.mdx_egnn_node_inputs.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i64, vp, vp, vp]
     L.mdx_egnn_scores.restype = i32

@@ -67,8 +67,9 @@ struct ChainArgs {
     float* edge_scalar;         // [E]
     uint32_t* status;
     // MODE 1 (a chain of H -> H layers over the ROWS of a matrix, last layer linear, optional residual): n_edges rows
-    const float* rows_in;       // [M][H]
-    const float* residual;      // [M][H], nullable
+    const float* rows_in;       // [M][ld_in]: the first H columns (MODE 3: [M][2H] = h | agg, ld_in = 2 H)
+    const float* residual;      // [M][ld_in] first H columns, nullable
+    int64_t ld_in;              // row stride of rows_in and residual, in floats
     float* rows_out;            // [M][H]
 };
 
@@ -423,6 +424,43 @@ __device__ __forceinline__ void segmented_step(float (&x)[16], float gate)
     }
 }
 
+// Raw accumulators of tile t parked in / taken from the sixteen registers that tile occupies in an operand set (MODE 3).
+template <int H>
+__device__ __forceinline__ void park(Act<H, 0>& a, int t, const f32x16& acc)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a.v[16 * t + r] = acc[r];
+}
+template <int H>
+__device__ __forceinline__ f32x16 unpark(const Act<H, 0>& a, int t)
+{
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = a.v[16 * t + r];
+    return acc;
+}
+template <int H>
+__device__ __forceinline__ void park(Act<H, 1>& a, int t, const f32x16& acc)
+{
+    f32x4 q[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) q[r >> 2][r & 3] = acc[r];
+    a.hi[2 * t] = __builtin_bit_cast(half8, q[0]);
+    a.hi[2 * t + 1] = __builtin_bit_cast(half8, q[1]);
+    a.lo[2 * t] = __builtin_bit_cast(half8, q[2]);
+    a.lo[2 * t + 1] = __builtin_bit_cast(half8, q[3]);
+}
+template <int H>
+__device__ __forceinline__ f32x16 unpark(const Act<H, 1>& a, int t)
+{
+    const f32x4 q[4] = {__builtin_bit_cast(f32x4, a.hi[2 * t]), __builtin_bit_cast(f32x4, a.hi[2 * t + 1]),
+                        __builtin_bit_cast(f32x4, a.lo[2 * t]), __builtin_bit_cast(f32x4, a.lo[2 * t + 1])};
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = q[r >> 2][r & 3];
+    return acc;
+}
+
 // MODE 0: the EGNN edge chain (gathered first layer, messages + head out); MODE 2: the same with the messages added up per
 // node inside the kernel (piece sums out).  MODE 1: the same pipeline over the rows of a matrix -- out = residual + W_L (SiLU(W_{L-1} ... SiLU(W_1 x + b_1) ...)) + b_L -- used for the per-node MLP of an EGNN layer.
 template <int H, int PREC, int MODE>
@@ -432,6 +470,11 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     // (GUARD: see issue_piece.  The piece-sums instantiations have no scalar-register spills -- checked in the build's
     // resource listing -- and skip the three wait states: 1 % of the launch.)
     using C = Chain<H, PREC, MODE != 2>;
+    // MODE 3 = MODE 1 whose first layer is 2 H -> H: the rows are [h | agg]; chain "layers" 0 and 1 are the two H x H halves of
+    // that layer's weight.  Pass A multiplies h by the first half and PARKS the raw accumulators (bias included) in the
+    // registers of the other operand set; pass B reloads the operand registers with agg, starts every tile from its parked
+    // accumulator, multiplies by the second half and runs the usual epilogue into the slot the parked tile has left.
+    constexpr bool ROWS = MODE == 1 || MODE == 3;
     constexpr int NT = C::NT;
     constexpr int STEPS = PREC == 0 ? H / 8 : H / 16;        // k-steps of a tile: 4 f32 MFMAs | 3 f16 MFMAs each
 #ifndef MDX_CHAIN_PFD
@@ -476,7 +519,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     if (tile_lo + xcd_slot >= tile_hi) return;              // uniform per workgroup
 
     for (int i = threadIdx.x; i < layers * H; i += kWaves * kWave) par[i] = p.biases[i] * kLog2e;
-    if constexpr (MODE != 1) {
+    if constexpr (!ROWS) {
         for (int i = threadIdx.x; i < H; i += kWaves * kWave) {
             par_in[i] = p.bias_in[i] * kLog2e;
             par_wr[i] = p.w_radial[i] * kLog2e;
@@ -487,7 +530,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     MDX_STAMP_ALWAYS(20);
     MDX_STAMP_REALTIME(21);
     C ch;
-    ch.image = p.image; ch.chunks_total = layers * NT + (MODE != 1 ? 1 : 0); ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
+    ch.image = p.image; ch.chunks_total = layers * NT + (!ROWS ? 1 : 0); ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
     ch.ring = ring; ch.wave = wave; ch.lane = lane;
     ch.stores_behind = false;
     ch.stores_count = 0;
@@ -539,7 +582,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         const bool live = e_raw < n_edges;
         const int64_t e = live ? e_raw : n_edges - 1;
         Act<H, PREC> xa, xb;
-        if constexpr (MODE != 1) {
+        if constexpr (!ROWS) {
             const int64_t src = p.edges[2 * e], dst = p.edges[2 * e + 1];
             if (MODE == 2 && h == 0) seg_src[col] = (int)src;      // (node indices fit 31 bits: checked on the host)
             float radial = 0.0f;
@@ -594,7 +637,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             }
         } else {
             // the row itself (the caller's activations, carried as log2(e) x inside the chain)
-            const float* px = p.rows_in + e * H + 4 * h;
+            const float* px = p.rows_in + e * p.ld_in + 4 * h;
 #pragma unroll
             for (int q = 0; q < H / 8; ++q) {
                 const f32x4 a = *(const f32x4*)(px + 8 * q);
@@ -630,7 +673,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #endif
                 if (s == STEPS - 1) acc_next = read_bias(next_bias);
 #if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 16))
-                if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, MODE == 1 && linear);
+                if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, ROWS && linear);
 #else
                 if (have && s == 0) asm volatile("" ::"v"(pend));      // keep the MFMAs alive without their epilogue
 #endif
@@ -674,7 +717,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             for (int t = 0; t < NT; ++t) {
                 // the tile after this one: the next tile of this layer, the first of the next layer, or -- after the last
                 // layer -- the head (no bias; MODE 0) / layer 0 of the next rows (MODE 1)
-                const lds_f* next_bias = t + 1 < NT ? bias + 32 * (t + 1) : (l + 1 < layers ? bias + H : (MODE != 1 ? nullptr : par));
+                const lds_f* next_bias = t + 1 < NT ? bias + 32 * (t + 1) : (l + 1 < layers ? bias + H : (!ROWS ? nullptr : par));
                 // the epilogue beside tile 0 belongs to the previous layer (never the linear one); the others to this layer
                 if (t == 0) pend = run_tile(in, !FIRST, NT - 1, in, next_bias);
                 else pend = run_tile(in, true, t - 1, out, next_bias, l == layers - 1);
@@ -799,7 +842,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         // MODE 1: the last tile of the last (linear) layer has no tile after it to run beside; then out = residual + y
         auto finish_rows = [&](Act<H, PREC>& y) {
             epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, y, true);
-            const float* res = p.residual ? p.residual + e * H + 4 * h : nullptr;
+            const float* res = p.residual ? p.residual + e * p.ld_in + 4 * h : nullptr;
             float* row = p.rows_out + e * H + 4 * h;
             if (live) {
 #pragma unroll
@@ -835,7 +878,37 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             }
             ch.stores_behind = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(live) != 0);
         };
-        layer(std::true_type{}, xa, xb, 0);
+        int l_first = 1;
+        if constexpr (MODE == 3) {
+            // pass A: layer 0 = the first half of the wide weight on h; no epilogue, the accumulators are parked in xb
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x16 acc = run_tile(xa, false, 0, xa, t + 1 < NT ? par + 32 * (t + 1) : nullptr);
+                park(xb, t, acc);
+            }
+            // the operand registers again, with agg (columns H .. 2H-1 of the row)
+            {
+                const float* px = p.rows_in + e * p.ld_in + H + 4 * h;
+#pragma unroll
+                for (int q = 0; q < H / 8; ++q) {
+                    const f32x4 a = *(const f32x4*)(px + 8 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) put<H>(xa, q >> 2, 4 * (q & 3) + i, a[i] * kLog2e);
+                    if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // pass B: layer 1 = the second half on agg, every tile started from its parked accumulator
+            acc_next = unpark(xb, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const lds_f* after = t + 1 < NT ? nullptr : par + 2 * H;          // layer 2, tile 0 (there always is one)
+                pend = run_tile(xa, t > 0, t - 1, xb, after);
+                if (t + 1 < NT) acc_next = unpark(xb, t + 1);
+            }
+            l_first = 2;
+        } else {
+            layer(std::true_type{}, xa, xb, 0);
+        }
         bool done = false;
         if constexpr (MODE == 1) {                      // (the edge chain always has a message and a coordinate layer)
             if (layers == 1) {
@@ -844,9 +917,9 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             }
         }
         if (!done) {
-            for (int l = 1;;) {
+            for (int l = l_first;;) {
                 layer(std::false_type{}, xb, xa, l);
-                if (MODE != 1 && l == p.n_message) {
+                if (!ROWS && l == p.n_message) {
                     if constexpr (MODE == 2) {
                         MDX_STAMP_ALWAYS(30);
                         ch.stores_count = aggregate_pieces(xb);
@@ -857,12 +930,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     }
                 }
                 if (++l >= layers) {
-                    if constexpr (MODE != 1) head_tile(xa);
+                    if constexpr (!ROWS) head_tile(xa);
                     else finish_rows(xa);
                     break;
                 }
                 layer(std::false_type{}, xa, xb, l);
-                if (MODE != 1 && l == p.n_message) {
+                if (!ROWS && l == p.n_message) {
                     if constexpr (MODE == 2) {
                         MDX_STAMP_ALWAYS(30);
                         ch.stores_count = aggregate_pieces(xa);
@@ -873,7 +946,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     }
                 }
                 if (++l >= layers) {
-                    if constexpr (MODE != 1) head_tile(xb);
+                    if constexpr (!ROWS) head_tile(xb);
                     else finish_rows(xb);
                     break;
                 }
@@ -1116,7 +1189,7 @@ int mdx_mlp_chain_rows(const mdx_egnn_chain_t* c, const float* x, const float* r
     ChainArgs a{};
     a.image = (const char*)c->weight_image; a.biases = c->biases;
     a.n_edges_dev = n_rows_dev; a.n_edges = n_rows; a.n_message = c->n_message_layers; a.n_coord = 0; a.D = 0;
-    a.rows_in = x; a.residual = residual; a.rows_out = out; a.status = status;
+    a.rows_in = x; a.residual = residual; a.rows_out = out; a.status = status; a.ld_in = c->hidden;
     const int layers = a.n_message;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define MDX_ROWS_CASE(HH)                                                                          \
@@ -1128,6 +1201,34 @@ int mdx_mlp_chain_rows(const mdx_egnn_chain_t* c, const float* x, const float* r
         MDX_ROWS_CASE(256)
     }
 #undef MDX_ROWS_CASE
+    return MDX_ERR_UNSUPPORTED;
+}
+
+int mdx_node_mlp_rows(const mdx_egnn_chain_t* c, const float* node_in, int add_residual, int64_t n_rows,
+                      const int64_t* n_rows_dev, float* out, uint32_t* status, mdx_stream_t stream)
+{
+    if (!c || n_rows < 0) return MDX_ERR_INVALID_ARG;
+    if (c->n_message_layers < 3 || c->n_coord_layers != 0 || (c->precision != 0 && c->precision != 1)) return MDX_ERR_INVALID_ARG;
+    if (c->n_message_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
+    if (c->hidden != 32 && c->hidden != 64 && c->hidden != 128 && c->hidden != 256) return MDX_ERR_UNSUPPORTED;
+    if (n_rows == 0) return MDX_OK;
+    if (!c->weight_image || !c->biases || !node_in || !out) return MDX_ERR_INVALID_ARG;
+    ChainArgs a{};
+    a.image = (const char*)c->weight_image; a.biases = c->biases;
+    a.n_edges_dev = n_rows_dev; a.n_edges = n_rows; a.n_message = c->n_message_layers; a.n_coord = 0; a.D = 0;
+    a.rows_in = node_in; a.residual = add_residual ? node_in : nullptr; a.rows_out = out; a.status = status;
+    a.ld_in = 2 * (int64_t)c->hidden;
+    const int layers = a.n_message;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define MDX_NODE_CASE(HH)                                                                          \
+    case HH: return c->precision == 0 ? launch_chain<HH, 0, 3>(a, layers, st) : launch_chain<HH, 1, 3>(a, layers, st);
+    switch (c->hidden) {
+        MDX_NODE_CASE(32)
+        MDX_NODE_CASE(64)
+        MDX_NODE_CASE(128)
+        MDX_NODE_CASE(256)
+    }
+#undef MDX_NODE_CASE
     return MDX_ERR_UNSUPPORTED;
 }
 

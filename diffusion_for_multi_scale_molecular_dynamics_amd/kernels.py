@@ -655,6 +655,54 @@ class RowChainPack:
                 all(l.in_features == H and l.out_features == H and l.bias is not None for l in layers))
 
 
+class NodeMlpPack:
+    """Device image of a whole EGNN node MLP -- Linear(2H, H), SiLU, [Linear(H, H), SiLU]*, Linear(H, H) -- for
+    mdx_node_mlp_rows: the first layer's [H, 2H] weight as two H x H chain layers."""
+
+    def __init__(self, layers, precision: str):
+        layers = list(layers)
+        if precision not in EDGE_CHAIN_PRECISIONS:
+            raise _hip.MdxError(f"chain precision must be one of {sorted(EDGE_CHAIN_PRECISIONS)}; got {precision!r}")
+        if not self.supported(layers):
+            raise _hip.MdxError("this layer stack is not covered by mdx_node_mlp_rows")
+        H = layers[0].out_features
+        dev = layers[0].weight.device
+        self.precision, self.hidden = precision, H
+        w0 = layers[0].weight.detach().to(F32)
+        keep = [w0[:, :H].contiguous(), w0[:, H:].contiguous()] + [l.weight.detach().to(F32).contiguous() for l in layers[1:]]
+        n = len(keep)
+        self.image = torch.empty(lib().mdx_egnn_chain_image_bytes(H, n), dtype=torch.uint8, device=dev)
+        array = (C.c_void_p * n)(*[w.data_ptr() for w in keep])
+        with torch.cuda.device(dev):
+            check(lib().mdx_egnn_chain_pack(array, n, None, H, EDGE_CHAIN_PRECISIONS[precision],
+                                            C.c_void_p(self.image.data_ptr()), stream_handle()), "mdx_egnn_chain_pack")
+        zeros = torch.zeros(H, dtype=F32, device=dev)
+        self.biases = torch.stack([layers[0].bias.detach().to(F32), zeros] +
+                                  [l.bias.detach().to(F32) for l in layers[1:]]).contiguous()
+        self.c_struct = _hip.EgnnChain(H, n, 0, EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
+                                       self.biases.data_ptr(), None, None)
+
+    @staticmethod
+    def supported(layers) -> bool:
+        layers = list(layers)
+        if len(layers) < 2:
+            return False
+        H = layers[0].out_features
+        return (H in (32, 64, 128, 256) and layers[0].in_features == 2 * H and len(layers) + 1 <= _hip.EGNN_CHAIN_MAX_LAYERS and
+                all(l.in_features == H and l.out_features == H for l in layers[1:]) and all(l.bias is not None for l in layers))
+
+
+def node_mlp_rows(pack: NodeMlpPack, node_in, add_residual: bool, status=None) -> torch.Tensor:
+    """(node_in[:, :H] if add_residual) + MLP(node_in) over the rows of node_in [M, 2H]  (mdx_node_mlp_rows)."""
+    M, W = node_in.shape
+    assert W == 2 * pack.hidden
+    out = torch.empty(M, pack.hidden, dtype=F32, device=node_in.device)
+    rc = lib().mdx_node_mlp_rows(C.byref(pack.c_struct), ptr(node_in, F32, "node_in"), int(bool(add_residual)), M, None,
+                                 ptr(out, F32, "out"), ptr(status, I32, "status"), stream_handle())
+    check(rc, "mdx_node_mlp_rows")
+    return out
+
+
 def mlp_chain_rows(pack: RowChainPack, x, residual=None, status=None) -> torch.Tensor:
     """residual + chain(x) over the rows of x [M, H] (mdx_mlp_chain_rows)."""
     M, H = x.shape

@@ -85,6 +85,7 @@ class E_GCL(nn.Module):
         self.status_word = None          # device int32 word for MDX_STATUS_EGNN_F16_RANGE (set by the score network)
         self._chain = (None, None)       # (stamp, kernels.EdgeChainPack)
         self._node_chain = (None, None)  # (stamp, kernels.RowChainPack): the node MLP after its first layer
+        self._node_mlp = (None, None)    # (stamp, kernels.NodeMlpPack): the whole node MLP
 
         mh, nh, ch = message_hidden_dimensions_size, node_hidden_dimensions_size, coordinate_hidden_dimensions_size
         layers = [nn.Linear(2 * input_size + 1, mh), act_fn]
@@ -114,6 +115,7 @@ class E_GCL(nn.Module):
         hold raw pointers and are rebuilt on first use."""
         state = dict(self.__dict__)
         state["_chain"], state["_node_chain"], state["status_word"] = (None, None), (None, None), None
+        state["_node_mlp"] = (None, None)
         return state
 
     def _messages(self, h: torch.Tensor, edge_index: torch.Tensor, radial: torch.Tensor, fused: bool) -> torch.Tensor:
@@ -192,6 +194,24 @@ class E_GCL(nn.Module):
             self._node_chain = (stamp, kernels.RowChainPack(rest, self.edge_chain_precision))
         return self._node_chain[1]
 
+    def _node_mlp_pack(self):
+        """kernels.NodeMlpPack of the WHOLE node MLP (Linear(2H, H) first), or None when it does not have that shape."""
+        if self.edge_chain_precision is None:
+            return None
+        node = list(self.node_mlp)
+        if len(node) < 3 or len(node) % 2 == 0:
+            return None
+        linears, acts = node[0::2], node[1::2]
+        if not all(isinstance(lin, nn.Linear) for lin in linears) or not all(isinstance(a, nn.SiLU) for a in acts):
+            return None
+        from .. import kernels
+        if not kernels.NodeMlpPack.supported(linears):
+            return None
+        stamp = (self.edge_chain_precision,) + tuple((t.data_ptr(), t._version) for lin in linears for t in (lin.weight, lin.bias))
+        if self._node_mlp[0] != stamp:
+            self._node_mlp = (stamp, kernels.NodeMlpPack(linears, self.edge_chain_precision))
+        return self._node_mlp[1]
+
     def _coord_head_is_plain(self) -> bool:
         last = self.coord_mlp[-1]
         return isinstance(last, nn.Linear) and last.out_features == 1 and last.bias is None and \
@@ -260,6 +280,10 @@ class E_GCL(nn.Module):
         coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean)
         if in_kernel and h.shape[1] == messages.shape[1]:
             node_in = kernels.segment_combine(messages, offsets, degree, self.message_mean, left=h.contiguous())     # [h | agg]
+            whole = self._node_mlp_pack()
+            if whole is not None and whole.hidden == h.shape[1]:
+                # the whole node MLP (its 2H -> H layer included) and the residual: one launch on the matrix cores
+                return kernels.node_mlp_rows(whole, node_in, self.residual, status=self.status_word), coord_out
         else:
             agg = (kernels.segment_combine(messages, offsets, degree, self.message_mean) if in_kernel
                    else kernels.segment_rows(messages, offsets, degree, self.message_mean))

@@ -418,6 +418,14 @@ MDX_API int mdx_egnn_scores(const float* z, const float* x_hat, const float* k_v
  * but the last followed by SiLU; residual nullable; x, residual, out [n_rows, H] row-major; n_rows_dev nullable as above. */
 MDX_API int mdx_mlp_chain_rows(const mdx_egnn_chain_t* chain_host, const float* x, const float* residual, int64_t n_rows,
                                const int64_t* n_rows_dev, float* out, uint32_t* status, mdx_stream_t stream);
+/* The WHOLE per-node MLP of an EGNN layer (models/egnn.py:202-230) in one launch: node_in [n_rows, 2H] = [h | agg] (what
+ * mdx_segment_combine writes with `left`), first layer Linear(2H, H) + SiLU, then H -> H layers as above, last one linear;
+ * out[r,:] = (node_in[r,:H] if add_residual) + MLP(node_in[r,:]).  The chain holds the first layer's weight [H, 2H] as TWO
+ * H x H layers -- W[:, :H] then W[:, H:] -- so n_message_layers = 1 + number of Linear modules (>= 3); biases [n, H]: row 0
+ * the first layer's bias, row 1 unused.  The first half is multiplied with h, its raw accumulators wait in registers, the
+ * second half with agg continues from them. */
+MDX_API int mdx_node_mlp_rows(const mdx_egnn_chain_t* chain_host, const float* node_in, int add_residual, int64_t n_rows,
+                              const int64_t* n_rows_dev, float* out, uint32_t* status, mdx_stream_t stream);
 /* coord_out[i,:] = coord[i,:] + (1/degree_i if mean) sum_{e in segment i} (coord[i,:] - coord[dst_e,:]) edge_scalar[e]
  * -- E_GCL.coord_model's trans = coord_diff * coord_mlp(m), unsorted_segment_sum / _mean and the residual add
  * (models/egnn.py:162-200), on the sorted segments; no atomics, fixed summation order. */

@@ -166,7 +166,8 @@ def test_egnn_forward_edge_chain_modes(cuda, hidden, n_layers, n_hidden):
             outs[mode] = net(batch, conditional=False)
         net.check_status()
     assert net.egnn.graph_layers[0]._chain[1] is not None           # the MFMA kernel really ran
-    assert net.egnn.graph_layers[0]._node_chain[1] is not None      # ... and the row chain of the node MLP
+    layer0 = net.egnn.graph_layers[0]                               # ... and the node MLP on the same pipeline
+    assert layer0._node_mlp[1] is not None or layer0._node_chain[1] is not None
     # fp64 yardstick: the same module in double precision on the same edges
     import copy
     net64 = copy.deepcopy(net).double()
@@ -476,3 +477,37 @@ def test_egnn_node_inputs_and_scores_against_torch(cuda):
     want_s = torch.einsum("ni,aij,nj->na", want_z.double(), gamma.double(), x_hat.double())
     got_s = kernels.egnn_scores(want_z.contiguous(), x_hat, kv)
     assert _rel_l2(got_s, want_s) < 1e-6
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("H,n_inner,M,with_residual", [(32, 0, 77, True), (64, 1, 500, False), (128, 2, 129, True),
+                                                       (256, 4, 1000, True), (256, 0, 5, False)])
+def test_node_mlp_rows_against_fp64(cuda, precision, H, n_inner, M, with_residual):
+    """mdx_node_mlp_rows: the whole node MLP -- Linear(2H, H), SiLU, n_inner x (Linear(H, H), SiLU), Linear(H, H) -- and the
+    residual on rows [h | agg], against fp64; ragged row counts (the first layer's two halves go through the matrix cores
+    one after the other, the accumulators of the first waiting in registers)."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    torch.manual_seed(3 * H + n_inner)
+    g = torch.Generator().manual_seed(M)
+    layers = [torch.nn.Linear(2 * H, H)] + [torch.nn.Linear(H, H) for _ in range(n_inner + 1)]
+    for layer in layers:
+        with torch.no_grad():
+            layer.weight.mul_(1.6)
+    x = torch.randn(M, 2 * H, generator=g)
+    y = x.double()
+    for k, layer in enumerate(layers):
+        y = y @ layer.weight.double().t() + layer.bias.double()
+        if k + 1 < len(layers):
+            y = y * torch.sigmoid(y)
+    want = (x[:, :H].double() + y) if with_residual else y
+    mods = [m.to(cuda) for m in layers]
+    assert kernels.NodeMlpPack.supported(mods)
+    pack = kernels.NodeMlpPack(mods, precision)
+    status = torch.zeros(1, dtype=torch.int32, device=cuda)
+    got = kernels.node_mlp_rows(pack, x.to(cuda).contiguous(), with_residual, status=status)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    tol = TOLERANCE[precision]
+    assert _rel_l2(got, want.detach()) < tol, _rel_l2(got, want.detach())
+    row_err = ((got.double().cpu() - want.detach()).norm(dim=1) / want.detach().norm(dim=1).clamp(min=1e-30)).max()
+    assert float(row_err) < 20 * tol, float(row_err)
