@@ -70,6 +70,7 @@ struct ChainArgs {
     const float* rows_in;       // [M][ld_in]: the first H columns (MODE 3: [M][2H] = h | agg, ld_in = 2 H)
     const float* residual;      // [M][ld_in] first H columns, nullable
     int64_t ld_in;              // row stride of rows_in and residual, in floats
+    float* proj_out;            // MODE 3, nullable: [M][2H] = out W_p^T for the 2 H x H layers that follow the MLP in the image
     float* rows_out;            // [M][H]
 };
 
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     MDX_STAMP_ALWAYS(20);
     MDX_STAMP_REALTIME(21);
     C ch;
-    ch.image = p.image; ch.chunks_total = layers * NT + (!ROWS ? 1 : 0); ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
+    ch.image = p.image; ch.chunks_total = (layers + (MODE == 3 && p.proj_out ? 2 : 0)) * NT + (!ROWS ? 1 : 0); ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
     ch.ring = ring; ch.wave = wave; ch.lane = lane;
     ch.stores_behind = false;
     ch.stores_count = 0;
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             for (int t = 0; t < NT; ++t) {
                 // the tile after this one: the next tile of this layer, the first of the next layer, or -- after the last
                 // layer -- the head (no bias; MODE 0) / layer 0 of the next rows (MODE 1)
-                const lds_f* next_bias = t + 1 < NT ? bias + 32 * (t + 1) : (l + 1 < layers ? bias + H : (!ROWS ? nullptr : par));
+                const lds_f* next_bias = t + 1 < NT ? bias + 32 * (t + 1) : (l + 1 < layers ? bias + H : (!ROWS || (MODE == 3 && p.proj_out) ? nullptr : par));
                 // the epilogue beside tile 0 belongs to the previous layer (never the linear one); the others to this layer
                 if (t == 0) pend = run_tile(in, !FIRST, NT - 1, in, next_bias);
                 else pend = run_tile(in, true, t - 1, out, next_bias, l == layers - 1);
@@ -840,8 +841,9 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             if (live && h == 0) p.edge_scalar[e] = acc[0];
         };
         // MODE 1: the last tile of the last (linear) layer has no tile after it to run beside; then out = residual + y
-        auto finish_rows = [&](Act<H, PREC>& y) {
+        auto finish_rows = [&](Act<H, PREC>& y, Act<H, PREC>& u) {
             epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, y, true);
+            const bool project = MODE == 3 && p.proj_out != nullptr;       // out is also the operand of two more linear layers
             const float* res = p.residual ? p.residual + e * p.ld_in + 4 * h : nullptr;
             float* row = p.rows_out + e * H + 4 * h;
             if (live) {
@@ -877,6 +879,42 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 }
             }
             ch.stores_behind = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(live) != 0);
+            if constexpr (MODE == 3) {
+                if (project) {
+                    // [out W_src^T | out W_dst^T]: 2 NT more tiles, each stored as it is (sixteen tiles per 128 rows: not worth
+                    // a pipelined epilogue).  Their operand: the rows just written, read back into the free register set
+                    // (filling it while y and the residual are live spills 480 B per lane); this lane reads what it wrote.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    {
+                        const float* pr = p.rows_out + e * H + 4 * h;
+#pragma unroll
+                        for (int q = 0; q < H / 8; ++q) {
+                            const f32x4 a = *(const f32x4*)(pr + 8 * q);
+                            put_pair<H>(u, q >> 2, 4 * (q & 3), a[0] * kLog2e, a[1] * kLog2e);
+                            put_pair<H>(u, q >> 2, 4 * (q & 3) + 2, a[2] * kLog2e, a[3] * kLog2e);
+                            if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    float* prow = p.proj_out + e * 2 * H + 4 * h;
+#pragma unroll 1
+                    for (int t2 = 0; t2 < 2 * NT; ++t2) {
+                        if constexpr (C::SPREAD) ch.scalar_addresses();    // (loop-carried: see scalar_addresses)
+                        const f32x16 acc = run_tile(u, false, 0, u, t2 + 1 < 2 * NT ? nullptr : par);
+                        if (live) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 v = {acc[4 * g] * kLn2, acc[4 * g + 1] * kLn2, acc[4 * g + 2] * kLn2, acc[4 * g + 3] * kLn2};
+                                if constexpr (PREC == 1) {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) out_of_range = out_of_range || !(__builtin_fabsf(v[i]) <= 3.0e38f);
+                                }
+                                *(f32x4*)(prow + 32 * t2 + 8 * g) = v;
+                            }
+                        }
+                        ch.stores_count = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(live) != 0) ? 4 : 0;
+                    }
+                }
+            }
         };
         int l_first = 1;
         if constexpr (MODE == 3) {
@@ -912,7 +950,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         bool done = false;
         if constexpr (MODE == 1) {                      // (the edge chain always has a message and a coordinate layer)
             if (layers == 1) {
-                finish_rows(xb);
+                finish_rows(xb, xa);
                 done = true;
             }
         }
@@ -931,7 +969,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 }
                 if (++l >= layers) {
                     if constexpr (!ROWS) head_tile(xa);
-                    else finish_rows(xa);
+                    else finish_rows(xa, xb);
                     break;
                 }
                 layer(std::false_type{}, xa, xb, l);
@@ -947,7 +985,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 }
                 if (++l >= layers) {
                     if constexpr (!ROWS) head_tile(xb);
-                    else finish_rows(xb);
+                    else finish_rows(xb, xa);
                     break;
                 }
             }
@@ -1205,7 +1243,7 @@ int mdx_mlp_chain_rows(const mdx_egnn_chain_t* c, const float* x, const float* r
 }
 
 int mdx_node_mlp_rows(const mdx_egnn_chain_t* c, const float* node_in, int add_residual, int64_t n_rows,
-                      const int64_t* n_rows_dev, float* out, uint32_t* status, mdx_stream_t stream)
+                      const int64_t* n_rows_dev, float* out, float* proj_out, uint32_t* status, mdx_stream_t stream)
 {
     if (!c || n_rows < 0) return MDX_ERR_INVALID_ARG;
     if (c->n_message_layers < 3 || c->n_coord_layers != 0 || (c->precision != 0 && c->precision != 1)) return MDX_ERR_INVALID_ARG;
@@ -1218,6 +1256,8 @@ int mdx_node_mlp_rows(const mdx_egnn_chain_t* c, const float* node_in, int add_r
     a.n_edges_dev = n_rows_dev; a.n_edges = n_rows; a.n_message = c->n_message_layers; a.n_coord = 0; a.D = 0;
     a.rows_in = node_in; a.residual = add_residual ? node_in : nullptr; a.rows_out = out; a.status = status;
     a.ld_in = 2 * (int64_t)c->hidden;
+    a.proj_out = proj_out;
+    if (proj_out && c->n_message_layers + 2 > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     const int layers = a.n_message;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define MDX_NODE_CASE(HH)                                                                          \

@@ -659,7 +659,9 @@ class NodeMlpPack:
     """Device image of a whole EGNN node MLP -- Linear(2H, H), SiLU, [Linear(H, H), SiLU]*, Linear(H, H) -- for
     mdx_node_mlp_rows: the first layer's [H, 2H] weight as two H x H chain layers."""
 
-    def __init__(self, layers, precision: str):
+    def __init__(self, layers, precision: str, next_projection=None):
+        """next_projection: [2H, H] = the next graph layer's per-node projection weight (EdgeChainPack.proj_weight): its
+        two H x H halves follow the MLP in the image, and node_mlp_rows also returns out @ next_projection.T."""
         layers = list(layers)
         if precision not in EDGE_CHAIN_PRECISIONS:
             raise _hip.MdxError(f"chain precision must be one of {sorted(EDGE_CHAIN_PRECISIONS)}; got {precision!r}")
@@ -671,10 +673,14 @@ class NodeMlpPack:
         w0 = layers[0].weight.detach().to(F32)
         keep = [w0[:, :H].contiguous(), w0[:, H:].contiguous()] + [l.weight.detach().to(F32).contiguous() for l in layers[1:]]
         n = len(keep)
-        self.image = torch.empty(lib().mdx_egnn_chain_image_bytes(H, n), dtype=torch.uint8, device=dev)
-        array = (C.c_void_p * n)(*[w.data_ptr() for w in keep])
+        self.projects = next_projection is not None and n + 2 <= _hip.EGNN_CHAIN_MAX_LAYERS
+        if self.projects:
+            assert tuple(next_projection.shape) == (2 * H, H)
+            keep += [next_projection[:H].detach().to(F32).contiguous(), next_projection[H:].detach().to(F32).contiguous()]
+        self.image = torch.empty(lib().mdx_egnn_chain_image_bytes(H, len(keep)), dtype=torch.uint8, device=dev)
+        array = (C.c_void_p * len(keep))(*[w.data_ptr() for w in keep])
         with torch.cuda.device(dev):
-            check(lib().mdx_egnn_chain_pack(array, n, None, H, EDGE_CHAIN_PRECISIONS[precision],
+            check(lib().mdx_egnn_chain_pack(array, len(keep), None, H, EDGE_CHAIN_PRECISIONS[precision],
                                             C.c_void_p(self.image.data_ptr()), stream_handle()), "mdx_egnn_chain_pack")
         zeros = torch.zeros(H, dtype=F32, device=dev)
         self.biases = torch.stack([layers[0].bias.detach().to(F32), zeros] +
@@ -692,15 +698,17 @@ class NodeMlpPack:
                 all(l.in_features == H and l.out_features == H for l in layers[1:]) and all(l.bias is not None for l in layers))
 
 
-def node_mlp_rows(pack: NodeMlpPack, node_in, add_residual: bool, status=None) -> torch.Tensor:
-    """(node_in[:, :H] if add_residual) + MLP(node_in) over the rows of node_in [M, 2H]  (mdx_node_mlp_rows)."""
+def node_mlp_rows(pack: NodeMlpPack, node_in, add_residual: bool, status=None):
+    """(node_in[:, :H] if add_residual) + MLP(node_in) over the rows of node_in [M, 2H]  (mdx_node_mlp_rows); with a pack
+    built with next_projection: (out, out @ next_projection.T [M, 2H])."""
     M, W = node_in.shape
     assert W == 2 * pack.hidden
     out = torch.empty(M, pack.hidden, dtype=F32, device=node_in.device)
+    proj = torch.empty(M, 2 * pack.hidden, dtype=F32, device=node_in.device) if pack.projects else None
     rc = lib().mdx_node_mlp_rows(C.byref(pack.c_struct), ptr(node_in, F32, "node_in"), int(bool(add_residual)), M, None,
-                                 ptr(out, F32, "out"), ptr(status, I32, "status"), stream_handle())
+                                 ptr(out, F32, "out"), ptr(proj, F32, "proj_out"), ptr(status, I32, "status"), stream_handle())
     check(rc, "mdx_node_mlp_rows")
-    return out
+    return (out, proj) if pack.projects else out
 
 
 def mlp_chain_rows(pack: RowChainPack, x, residual=None, status=None) -> torch.Tensor:

@@ -194,8 +194,9 @@ class E_GCL(nn.Module):
             self._node_chain = (stamp, kernels.RowChainPack(rest, self.edge_chain_precision))
         return self._node_chain[1]
 
-    def _node_mlp_pack(self):
-        """kernels.NodeMlpPack of the WHOLE node MLP (Linear(2H, H) first), or None when it does not have that shape."""
+    def _node_mlp_pack(self, next_layer=None):
+        """kernels.NodeMlpPack of the WHOLE node MLP (Linear(2H, H) first), or None when it does not have that shape; with
+        the per-node projections of `next_layer` appended when that layer runs the fused edge chain on the same width."""
         if self.edge_chain_precision is None:
             return None
         node = list(self.node_mlp)
@@ -207,9 +208,16 @@ class E_GCL(nn.Module):
         from .. import kernels
         if not kernels.NodeMlpPack.supported(linears):
             return None
-        stamp = (self.edge_chain_precision,) + tuple((t.data_ptr(), t._version) for lin in linears for t in (lin.weight, lin.bias))
+        next_pack = next_layer._edge_chain_pack() if next_layer is not None and next_layer.use_fused_ops else None
+        projection = None
+        if next_pack is not None and tuple(next_pack.proj_weight.shape) == (2 * linears[0].out_features, linears[0].out_features) \
+                and next_pack.hidden == linears[0].out_features:
+            projection = next_pack.proj_weight
+        first_next = next_layer.message_mlp[0].weight if projection is not None else None
+        stamp = (self.edge_chain_precision,) + tuple((t.data_ptr(), t._version) for lin in linears for t in (lin.weight, lin.bias)) + \
+            ((first_next.data_ptr(), first_next._version) if first_next is not None else (None,))
         if self._node_mlp[0] != stamp:
-            self._node_mlp = (stamp, kernels.NodeMlpPack(linears, self.edge_chain_precision))
+            self._node_mlp = (stamp, kernels.NodeMlpPack(linears, self.edge_chain_precision, next_projection=projection))
         return self._node_mlp[1]
 
     def _coord_head_is_plain(self) -> bool:
@@ -219,8 +227,12 @@ class E_GCL(nn.Module):
 
     def forward(self, h: torch.Tensor, edge_index: torch.Tensor, coord: torch.Tensor,
                 degree: Optional[torch.Tensor] = None, offsets: Optional[torch.Tensor] = None,
-                n_edges: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """h [n_nodes, F]; edge_index [E, 2] sorted by column 0; coord [n_nodes, D]; degree [n_nodes] edge counts;
+                n_edges: Optional[torch.Tensor] = None, node_proj: Optional[torch.Tensor] = None,
+                next_layer: Optional["E_GCL"] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """node_proj: this layer's per-node projections [n_nodes, 2H], when the previous layer's node kernel has already
+        computed them; next_layer: the graph layer that follows (its projections are then computed by this layer's node
+        kernel and left in self._next_proj).
+        h [n_nodes, F]; edge_index [E, 2] sorted by column 0; coord [n_nodes, D]; degree [n_nodes] edge counts;
         offsets [n_nodes] = exclusive scan of degree (enables the segment kernels on device tensors); n_edges: int64 [1]
         on the device when edge_index is a capacity-sized list whose first n_edges rows are the edges (fused chain only)."""
         row, col = edge_index[:, 0], edge_index[:, 1]
@@ -233,7 +245,7 @@ class E_GCL(nn.Module):
         if fused and offsets is not None and edge_index.shape[0] > 0:
             pack = self._edge_chain_pack()
             if pack is not None:
-                return self._forward_edge_chain(pack, h, edge_index, coord, degree, offsets, n_edges)
+                return self._forward_edge_chain(pack, h, edge_index, coord, degree, offsets, n_edges, node_proj, next_layer)
         assert n_edges is None, "a capacity-sized edge list needs the fused edge chain in every layer"
         inv_deg = (1.0 / degree.clamp(min=1).to(h.dtype)).unsqueeze(1)
 
@@ -267,11 +279,11 @@ class E_GCL(nn.Module):
         return out, coord
 
 
-    def _forward_edge_chain(self, pack, h, edge_index, coord, degree, offsets, n_edges=None):
+    def _forward_edge_chain(self, pack, h, edge_index, coord, degree, offsets, n_edges=None, node_proj=None, next_layer=None):
         """E_GCL.forward with the per-edge work in one MFMA kernel: node projections (library GEMM, per node) -> fused
         chain -> the two sorted-segment reductions -> node MLP."""
         from .. import kernels
-        proj = torch.nn.functional.linear(h, pack.proj_weight)      # (the pack is rebuilt when a parameter changes)
+        proj = node_proj if node_proj is not None else torch.nn.functional.linear(h, pack.proj_weight)
         coord = coord.contiguous()
         # the messages are added up per node inside the kernel (piece sums) and never written out as [E, H]
         in_kernel = pack.piece_sums_ok and h.shape[0] < (1 << 31)
@@ -280,10 +292,14 @@ class E_GCL(nn.Module):
         coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean)
         if in_kernel and h.shape[1] == messages.shape[1]:
             node_in = kernels.segment_combine(messages, offsets, degree, self.message_mean, left=h.contiguous())     # [h | agg]
-            whole = self._node_mlp_pack()
+            whole = self._node_mlp_pack(next_layer)
             if whole is not None and whole.hidden == h.shape[1]:
-                # the whole node MLP (its 2H -> H layer included) and the residual: one launch on the matrix cores
-                return kernels.node_mlp_rows(whole, node_in, self.residual, status=self.status_word), coord_out
+                # the whole node MLP (its 2H -> H layer included), the residual and -- when a graph layer follows -- that
+                # layer's per-node projections: one launch on the matrix cores
+                out = kernels.node_mlp_rows(whole, node_in, self.residual, status=self.status_word)
+                if whole.projects:
+                    out, self._next_proj = out
+                return out, coord_out
         else:
             agg = (kernels.segment_combine(messages, offsets, degree, self.message_mean) if in_kernel
                    else kernels.segment_rows(messages, offsets, degree, self.message_mean))
@@ -354,6 +370,9 @@ class EGNN(nn.Module):
             degree, offsets, n_edges = degree
         else:
             offsets = (torch.cumsum(degree, 0) - degree) if h.is_cuda else None
-        for layer in self.graph_layers:
-            h, x = layer(h, edges, x, degree, offsets, n_edges)
+        proj = None
+        for k, layer in enumerate(self.graph_layers):
+            following = self.graph_layers[k + 1] if k + 1 < len(self.graph_layers) else None
+            h, x = layer(h, edges, x, degree, offsets, n_edges, node_proj=proj, next_layer=following)
+            proj = layer.__dict__.pop("_next_proj", None)       # left there by the layer's node kernel, if it computed them
         return AXL(A=self.node_classification_layer(h), X=x, L=torch.zeros_like(x))

@@ -423,9 +423,12 @@ MDX_API int mdx_mlp_chain_rows(const mdx_egnn_chain_t* chain_host, const float* 
  * out[r,:] = (node_in[r,:H] if add_residual) + MLP(node_in[r,:]).  The chain holds the first layer's weight [H, 2H] as TWO
  * H x H layers -- W[:, :H] then W[:, H:] -- so n_message_layers = 1 + number of Linear modules (>= 3); biases [n, H]: row 0
  * the first layer's bias, row 1 unused.  The first half is multiplied with h, its raw accumulators wait in registers, the
- * second half with agg continues from them. */
+ * second half with agg continues from them.
+ * proj_out (nullable, [n_rows, 2H]): the image holds TWO MORE H x H layers behind the n_message_layers of the MLP -- the
+ * source and destination halves of the NEXT graph layer's first message layer (models/egnn.py:136-160) -- and
+ * proj_out[r,:] = [out[r,:] W_src^T | out[r,:] W_dst^T]: the node_proj input of that layer's mdx_egnn_edge_chain. */
 MDX_API int mdx_node_mlp_rows(const mdx_egnn_chain_t* chain_host, const float* node_in, int add_residual, int64_t n_rows,
-                              const int64_t* n_rows_dev, float* out, uint32_t* status, mdx_stream_t stream);
+                              const int64_t* n_rows_dev, float* out, float* proj_out, uint32_t* status, mdx_stream_t stream);
 /* coord_out[i,:] = coord[i,:] + (1/degree_i if mean) sum_{e in segment i} (coord[i,:] - coord[dst_e,:]) edge_scalar[e]
  * -- E_GCL.coord_model's trans = coord_diff * coord_mlp(m), unsorted_segment_sum / _mean and the residual add
  * (models/egnn.py:162-200), on the sorted segments; no atomics, fixed summation order. */

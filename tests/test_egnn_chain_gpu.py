@@ -511,3 +511,12 @@ def test_node_mlp_rows_against_fp64(cuda, precision, H, n_inner, M, with_residua
     assert _rel_l2(got, want.detach()) < tol, _rel_l2(got, want.detach())
     row_err = ((got.double().cpu() - want.detach()).norm(dim=1) / want.detach().norm(dim=1).clamp(min=1e-30)).max()
     assert float(row_err) < 20 * tol, float(row_err)
+    # with the next graph layer's projections appended: the same output bit for bit, and out @ P^T beside it
+    proj_w = torch.randn(2 * H, H, generator=g) * (1.5 / H ** 0.5)
+    pack_p = kernels.NodeMlpPack(mods, precision, next_projection=proj_w.to(cuda))
+    assert pack_p.projects
+    got2, proj = kernels.node_mlp_rows(pack_p, x.to(cuda).contiguous(), with_residual, status=status)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and torch.equal(got2, got)
+    want_p = want.detach() @ proj_w.double().t()
+    assert _rel_l2(proj, want_p) < tol, _rel_l2(proj, want_p)
