@@ -191,7 +191,7 @@ def _declare(L):
     L.mdx_node_mlp_rows.restype = i32
     L.mdx_node_mlp_rows.argtypes = [vp, vp, i32, i64, vp, vp, vp, vp, vp]
     L.mdx_egnn_node_inputs.restype = i32
-    L.mdx_egnn_node_inputs.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i64, vp, vp, vp]
+    L.mdx_egnn_node_inputs.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp]
     L.mdx_egnn_scores.restype = i32
     L.mdx_egnn_scores.argtypes = [vp, vp, vp, i32, i64, vp, vp]
     L.mdx_segment_combine.restype = i32

@@ -63,9 +63,23 @@ __global__ __launch_bounds__(kBlock) void egnn_node_inputs_kernel(const float* _
                                                                   const int64_t* __restrict__ atom_types,
                                                                   const float* __restrict__ w, const float* __restrict__ b,
                                                                   int F, int H, int64_t n_nodes, float* __restrict__ z,
-                                                                  float* __restrict__ h)
+                                                                  float* __restrict__ h, const float* __restrict__ w2,
+                                                                  const float* __restrict__ b2, int H2, float* __restrict__ h2)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    // a second linear map of the same [sigma | one_hot] input (nullable): the first graph layer's per-node projections,
+    // with w2 = P W, b2 = P b formed once on the host -- P (W x + b) without the [n_nodes, H] x [H, 2H] product
+    if (h2) {
+        for (int64_t t = t0; t < n_nodes * H2; t += stride) {
+            const int64_t i = t / H2;
+            const int j = (int)(t - i * H2);
+            const float s = sigma[i / atoms_per_structure];
+            const int64_t a = atom_types[i];
+            float v = b2[j] + s * w2[(int64_t)j * F];
+            if (a >= 0 && a + 1 < F) v = v + w2[(int64_t)j * F + 1 + a];
+            h2[t] = v;
+        }
+    }
     for (int64_t t = t0; t < n_nodes * H; t += stride) {
         const int64_t i = t / H;
         const int j = (int)(t - i * H);
@@ -274,16 +288,18 @@ static unsigned node_grid(int64_t n_nodes)
 
 int mdx_egnn_node_inputs(const float* x, const float* k_vectors, int n_k, const float* sigma, int atoms_per_structure,
                          const int64_t* atom_types, const float* emb_weight, const float* emb_bias, int n_features, int H,
-                         int64_t n_nodes, float* z_out, float* h_out, mdx_stream_t stream)
+                         int64_t n_nodes, float* z_out, float* h_out, const float* second_weight, const float* second_bias,
+                         int second_width, float* second_out, mdx_stream_t stream)
 {
     if (n_nodes < 0 || n_k < 1 || atoms_per_structure < 1 || n_features < 2 || H < 1) return MDX_ERR_INVALID_ARG;
     if (n_nodes == 0) return MDX_OK;
     if (!x || !k_vectors || !sigma || !atom_types || !emb_weight || !emb_bias || !z_out || !h_out) return MDX_ERR_INVALID_ARG;
+    if (second_out && (!second_weight || !second_bias || second_width < 1)) return MDX_ERR_INVALID_ARG;
     int64_t blocks = (n_nodes * H + kBlock - 1) / kBlock;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(egnn_node_inputs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), x,
                        k_vectors, n_k, sigma, atoms_per_structure, atom_types, emb_weight, emb_bias, n_features, H, n_nodes,
-                       z_out, h_out);
+                       z_out, h_out, second_weight, second_bias, second_width, second_out);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 

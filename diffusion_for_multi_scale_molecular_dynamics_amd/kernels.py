@@ -751,20 +751,26 @@ def segment_combine(pieces, offsets, degree, mean: bool, left=None) -> torch.Ten
     return out
 
 
-def egnn_node_inputs(x, k_vectors, sigma, atom_types, emb_weight, emb_bias):
+def egnn_node_inputs(x, k_vectors, sigma, atom_types, emb_weight, emb_bias, second=None):
     """z [n_nodes, 2 n_k] (torus uplift) and h [n_nodes, H] (embedding of [sigma | one_hot]) of EGNNScoreNetwork, one launch.
-    x [B, N, 3] relative coordinates, sigma [B] (or [B,1]), atom_types [B, N] int64."""
+    x [B, N, 3] relative coordinates, sigma [B] (or [B,1]), atom_types [B, N] int64.
+    second = (W2 [H2, F], b2 [H2]): a third output, the same input through that linear map (see mdx_egnn_node_inputs)."""
     B, N, d = x.shape
     assert d == 3 and k_vectors.shape[1] == 3
     n_nodes, n_k, (H, F) = B * N, k_vectors.shape[0], emb_weight.shape
     z = torch.empty(n_nodes, 2 * n_k, dtype=F32, device=x.device)
     h = torch.empty(n_nodes, H, dtype=F32, device=x.device)
+    w2, b2 = second if second is not None else (None, None)
+    assert second is None or (w2.shape[1] == F and b2.shape[0] == w2.shape[0])
+    H2 = w2.shape[0] if second is not None else 0
+    h2 = torch.empty(n_nodes, H2, dtype=F32, device=x.device) if second is not None else None
     rc = lib().mdx_egnn_node_inputs(ptr(x, F32, "x"), ptr(k_vectors, F32, "k_vectors"), n_k, ptr(sigma, F32, "sigma"), N,
                                     ptr(atom_types, I64, "atom_types"), ptr(emb_weight, F32, "emb_weight"),
                                     ptr(emb_bias, F32, "emb_bias"), F, H, n_nodes, ptr(z, F32, "z"), ptr(h, F32, "h"),
+                                    ptr(w2, F32, "second_weight"), ptr(b2, F32, "second_bias"), H2, ptr(h2, F32, "second_out"),
                                     stream_handle())
     check(rc, "mdx_egnn_node_inputs")
-    return z, h
+    return (z, h) if second is None else (z, h, h2)
 
 
 def egnn_scores(z, x_hat, k_vectors):

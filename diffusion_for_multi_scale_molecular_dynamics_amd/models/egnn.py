@@ -344,10 +344,12 @@ class EGNN(nn.Module):
                 act_fn=act_fn, residual=residual, attention=attention, normalize=normalize, coords_agg=coords_agg,
                 message_agg=message_agg, tanh=tanh))
 
-    def forward(self, h: torch.Tensor, edges: torch.Tensor, x: torch.Tensor, degree=None, embedded: bool = False) -> AXL:
+    def forward(self, h: torch.Tensor, edges: torch.Tensor, x: torch.Tensor, degree=None, embedded: bool = False,
+                first_proj: Optional[torch.Tensor] = None) -> AXL:
         """degree: None (a caller's own edge list, any order), the edge count per node [n_nodes] of a list sorted by source,
         or the triple (degree, offsets, n_edges) of a capacity-sized list (utils/neighbors.get_edges_static).
-        embedded: h is already embedding_in(node features) (kernels.egnn_node_inputs)."""
+        embedded: h is already embedding_in(node features) (kernels.egnn_node_inputs); first_proj: the first graph layer's
+        per-node projections [n_nodes, 2H] of that h, when the caller has them."""
         emb = self.embedding_in
         if embedded:
             assert h.shape[1] == emb.out_features
@@ -370,7 +372,7 @@ class EGNN(nn.Module):
             degree, offsets, n_edges = degree
         else:
             offsets = (torch.cumsum(degree, 0) - degree) if h.is_cuda else None
-        proj = None
+        proj = first_proj
         for k, layer in enumerate(self.graph_layers):
             following = self.graph_layers[k + 1] if k + 1 < len(self.graph_layers) else None
             h, x = layer(h, edges, x, degree, offsets, n_edges, node_proj=proj, next_layer=following)

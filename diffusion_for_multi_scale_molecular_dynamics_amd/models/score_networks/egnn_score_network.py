@@ -129,6 +129,27 @@ class EGNNScoreNetwork(ScoreNetwork):
             finally:
                 self.graph_status.zero_()
 
+    def _first_projection_of_inputs(self):
+        """(P W_emb, P b_emb) for the first graph layer's per-node projection matrix P = [W_src; W_dst]: the projections of
+        the embedded inputs are then a linear map of [sigma | one_hot] like the embedding itself (no [n_nodes, H] x [H, 2H]
+        product per forward).  None when the first layer does not run the fused edge chain.  Cached on the parameters'
+        versions."""
+        layers = self.egnn.graph_layers
+        if len(layers) == 0 or not layers[0].use_fused_ops:
+            return None
+        pack = layers[0]._edge_chain_pack()
+        emb = self.egnn.embedding_in
+        if pack is None or pack.proj_weight.shape[1] != emb.out_features:
+            return None
+        first = layers[0].message_mlp[0].weight
+        stamp = tuple((t.data_ptr(), t._version) for t in (first, emb.weight, emb.bias)) + (layers[0].edge_chain_precision,)
+        if getattr(self, "_first_projection", (None, None))[0] != stamp:
+            with torch.no_grad():
+                w2 = (pack.proj_weight.double() @ emb.weight.double()).float().contiguous()
+                b2 = (pack.proj_weight.double() @ emb.bias.double()).float().contiguous()
+            self._first_projection = (stamp, (w2, b2))
+        return self._first_projection[1]
+
     def _make_egnn(self, hp):
         return EGNN(
             input_size=self.number_of_features_per_node, num_classes=self.num_atom_types + 1,
@@ -194,11 +215,13 @@ class EGNNScoreNetwork(ScoreNetwork):
             # ~25 elementwise passes per forward; the same arithmetic (see include/mdx_hip.h)
             from ... import kernels
             k_vectors = self.bloch_wave_reciprocal_lattice_vectors.to(x)
-            z, h = kernels.egnn_node_inputs(x.contiguous(), k_vectors.contiguous(),
-                                            sigma_in.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous(),
-                                            comp.A.reshape(bsz, n).long().contiguous(), emb.weight.detach().contiguous(),
-                                            emb.bias.detach().contiguous())
-            out = self.egnn(h=h, edges=edges, x=z, degree=degree, embedded=True)
+            second = self._first_projection_of_inputs()
+            res = kernels.egnn_node_inputs(x.contiguous(), k_vectors.contiguous(),
+                                           sigma_in.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous(),
+                                           comp.A.reshape(bsz, n).long().contiguous(), emb.weight.detach().contiguous(),
+                                           emb.bias.detach().contiguous(), second=second)
+            z, h, first_proj = res if second is not None else (res[0], res[1], None)
+            out = self.egnn(h=h, edges=edges, x=z, degree=degree, embedded=True, first_proj=first_proj)
             scores = kernels.egnn_scores(z, out.X.contiguous(), k_vectors.contiguous())
             return AXL(A=out.A.reshape(bsz, n, -1), X=scores.reshape(bsz, n, d), L=torch.zeros_like(comp.L))
 

@@ -404,11 +404,15 @@ MDX_API int mdx_segment_combine(const float* pieces, const int64_t* offsets, con
  *                          EGNN.embedding_in([sigma | one_hot(atom type)]) = b + sigma W[:,0] + W[:,1 + a]
  *                          (emb_weight [H, n_features] row-major, n_features = 2 + number of atom types; sigma [B] per
  *                          structure, atoms_per_structure nodes each; the same binary32 operations as the reference's);
+ *                          second_out (nullable, [n_nodes, second_width]): a second linear map of the same input,
+ *                          b2 + sigma W2[:,0] + W2[:,1 + a] -- with W2 = P W, b2 = P b (formed by the caller) the first
+ *                          graph layer's per-node projections P h without an [n_nodes,H] x [H,2H] product;
  *   mdx_egnn_scores        S^alpha = z . Gamma^alpha . x_hat, Gamma^alpha = blockdiag_k(K_k[alpha] [[0,-1],[1,0]]):
  *                          scores [n_nodes,3] from the EGNN's coordinate output x_hat [n_nodes, 2 n_k]. */
 MDX_API int mdx_egnn_node_inputs(const float* x, const float* k_vectors, int n_k, const float* sigma, int atoms_per_structure,
                                  const int64_t* atom_types, const float* emb_weight, const float* emb_bias, int n_features,
-                                 int H, int64_t n_nodes, float* z_out, float* h_out, mdx_stream_t stream);
+                                 int H, int64_t n_nodes, float* z_out, float* h_out, const float* second_weight,
+                                 const float* second_bias, int second_width, float* second_out, mdx_stream_t stream);
 MDX_API int mdx_egnn_scores(const float* z, const float* x_hat, const float* k_vectors, int n_k, int64_t n_nodes,
                             float* scores_out, mdx_stream_t stream);
 

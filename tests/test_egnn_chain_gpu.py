@@ -468,6 +468,14 @@ def test_egnn_node_inputs_and_scores_against_torch(cuda):
     for k in range(1, C + 2):
         want_h = torch.addcmul(want_h, feats[:, k:k + 1], emb.weight[:, k].unsqueeze(0))
     assert torch.equal(h, want_h.detach())
+    # a second linear map of the same input in the same launch: P (W x + b) as (P W) x + P b
+    P = torch.randn(2 * H, H, generator=g).to(cuda) / H ** 0.5
+    w2 = (P.double() @ emb.weight.detach().double()).float().contiguous()
+    b2 = (P.double() @ emb.bias.detach().double()).float().contiguous()
+    z_b, h_b, proj = kernels.egnn_node_inputs(x, kv, sigma.reshape(-1).contiguous(), a, emb.weight.detach(), emb.bias.detach(),
+                                              second=(w2, b2))
+    assert torch.equal(z_b, z) and torch.equal(h_b, h)
+    assert _rel_l2(proj, want_h.detach().double() @ P.double().t()) < 1e-6
     flat = x.reshape(B * N, 3)
     kr = ((2.0 * math.pi * flat)[:, None, :] * kv[None, :, :]).sum(dim=-1)
     want_z = torch.stack([kr.cos(), kr.sin()], dim=2).reshape(B * N, -1)
