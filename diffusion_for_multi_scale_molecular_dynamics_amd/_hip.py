@@ -21,7 +21,7 @@ MAX_CLASSES = 8
 TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
     TAG_INIT_LATTICE, TAG_RESAMPLE_Z, TAG_RESAMPLE_U = range(11)
 
-ABI_VERSION = 7          # MDX_ABI_VERSION of include/mdx_hip.h
+ABI_VERSION = 8          # MDX_ABI_VERSION of include/mdx_hip.h
 ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
@@ -84,7 +84,7 @@ class EgnnChain(C.Structure):
     """mdx_egnn_chain_t"""
     _fields_ = [(n, C.c_int32) for n in ("hidden", "n_message_layers", "n_coord_layers", "precision", "message_mode",
                                          "reserved")] + \
-        [(n, C.c_void_p) for n in ("weight_image", "biases", "bias_in", "w_radial")]
+        [(n, C.c_void_p) for n in ("weight_image", "biases", "bias_in", "w_radial", "weight_exponents")]
 
 
 def build(force=False):
@@ -185,7 +185,7 @@ def _declare(L):
     L.mdx_egnn_chain_image_bytes.restype = i64
     L.mdx_egnn_chain_image_bytes.argtypes = [i32, i32]
     L.mdx_egnn_chain_pack.restype = i32
-    L.mdx_egnn_chain_pack.argtypes = [C.POINTER(vp), i32, vp, i32, i32, vp, vp]
+    L.mdx_egnn_chain_pack.argtypes = [C.POINTER(vp), i32, vp, i32, i32, C.c_uint32, vp, vp, vp]
     L.mdx_egnn_edge_chain.restype = i32
     L.mdx_egnn_edge_chain.argtypes = [C.POINTER(EgnnChain), vp, vp, i32, vp, i64, vp, vp, vp, vp, vp]
     L.mdx_node_mlp_rows.restype = i32

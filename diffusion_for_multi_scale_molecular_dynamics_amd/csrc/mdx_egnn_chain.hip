@@ -28,6 +28,13 @@
 //       PREC 1  split-f16: x = hi + lo, W = hi + lo (each an f16; hi + lo carries 22 significand bits); the product is
 //               hi.hi + (hi.lo + lo.hi) on v_mfma_f32_32x32x16_f16 with binary32 accumulation -- three MFMAs at 16x the
 //               f32 rate.  The dropped lo.lo term is 2^-22 relative: the same order as binary32 rounding itself.
+//               f16 has 5 exponent bits: unscaled, lo is a subnormal (quantum 2^-24) as soon as |v| < 2^-3, and the split no
+//               longer carries 22 bits.  So both operands are held SCALED BY EXACT POWERS OF TWO: the image of layer l is
+//               2^a_l W_l with a_l chosen at pack time so that the largest |W| sits in [2^13, 2^14) (every element down to
+//               2^-16 of the largest keeps its 22 bits), and the carried activations are 2^b u, b = kActExp (22 bits down to
+//               |u| = 2^-2-b; overflow beyond 65504 / 2^b).  The accumulator then holds 2^(a_l+b) z; the epilogue's first
+//               instruction brings the exponent back (Scale below).  Scaling by a power of two commutes with every
+//               rounding involved, so data of order one gives the same bits as without it.
 //               Magnitudes above the f16 range set MDX_STATUS_EGNN_F16_RANGE (the caller falls back to PREC 0).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -50,12 +57,14 @@ constexpr int kWave = 64;
 constexpr int kWaves = 4;                 // wavefronts per workgroup = SIMDs per CU
 constexpr int kTileEdges = 32 * kWaves;   // edges per workgroup tile
 constexpr int kRing = 4;                  // LDS ring slots for weight chunks: being read | readable next | two in flight
+constexpr int kScaleSlots = MDX_EGNN_CHAIN_MAX_LAYERS + 3;   // struct Scale per packed layer (+ the head / two projection layers)
 
 struct ChainArgs {
     const char* image;          // [layers][H/32 chunks][chunk bytes]
     const float* biases;        // [layers][H]
     const float* bias_in;       // [H]
     const float* w_radial;      // [H]
+    const int32_t* exps;        // [packed layers + 1] split-f16: the image holds 2^exps[l] W_l (last: the head row); else null
     const float* node_proj;     // [n_nodes][2H]
     const float* coord;         // [n_nodes][D]
     const int64_t* edges;       // [E][2]
@@ -84,6 +93,37 @@ constexpr float kLog2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f
 __device__ __forceinline__ float silu_scaled(float z)
 {
     return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z));
+}
+
+// Split-f16: the carried activations are 2^kActExp u (see the header comment).  2^6: full 22 bits for |u| >= 2^-8, an
+// absolute floor of 2^-31 below that; the f16 range is left at |u| > 1023 (|SiLU| > 709), which the status word reports.
+// (-DMDX_CHAIN_NO_SCALE: timing experiment only -- the round-2 arithmetic: no scaling, four-instruction epilogue)
+#ifdef MDX_CHAIN_NO_SCALE
+constexpr bool kScaled = false;
+#else
+constexpr bool kScaled = true;
+#endif
+template <int PREC>
+constexpr int kActExp = PREC == 1 && kScaled ? 6 : 0;
+constexpr float pow2_const(int e) { float v = 1.0f; for (int i = 0; i < (e < 0 ? -e : e); ++i) v = e < 0 ? v * 0.5f : v * 2.0f; return v; }
+__device__ __forceinline__ float pow2_bits(int e) { return __builtin_bit_cast(float, (uint32_t)(127 + e) << 23); }   // |e| <= 126
+
+// Exponent bookkeeping of one layer (wave-uniform; staged in LDS at kernel start, carried in scalar registers):
+// the accumulator of a tile of layer l holds A = 2^(a+b) z (a = the image's exponent, b = kActExp).
+//   neg_c = -2^-(a+b)   t = A neg_c = -z                         (the one instruction the scaling costs per value)
+//   k     =  2^a        u' = A / (k + k 2^t) = 2^b z / (1 + 2^-z)
+//   inv_a =  2^-a       a layer without activation: u' = A inv_a = 2^b z
+//   out   =  ln 2 2^-(a+b)   a tile stored as it is (the head, the projections behind the node MLP): y = A out
+struct Scale {
+    float neg_c, k, inv_a, out;
+};
+// u' = 2^b u for the first layer, computed on the vector ALU from z itself
+template <int PREC>
+__device__ __forceinline__ float silu_first(float z)
+{
+    if constexpr (PREC == 0) return silu_scaled(z);
+    constexpr float kb = pow2_const(-kActExp<PREC>);
+    return z * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(-z), kb, kb));
 }
 
 // Activations of a wavefront's 32 edges in MFMA B-operand registers.
@@ -398,16 +438,22 @@ struct Chain {
 // `linear` (wave-uniform): the tile belongs to a layer without activation (the last layer of a row chain): u = z, a select.
 template <int H, int PREC>
 __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const f32x16& pend, Act<H, PREC>& dst,
-                                                  bool linear = false)
+                                                  const Scale& sc, bool linear = false)
 {
+    // split-f16: the accumulator is 2^(a+b) z (struct Scale): -z, then 2^b z / (1 + 2^-z) with the divisor pre-scaled
+    auto act = [&](float A) -> float {
+        if constexpr (PREC == 0 || !kScaled) return silu_scaled(A);
+        else return A * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(A * sc.neg_c), sc.k, sc.k));
+    };
+    auto lin = [&](float A) -> float { return PREC == 0 || !kScaled ? A : A * sc.inv_a; };
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         if (r < r0 || r >= r1) continue;
         if constexpr (PREC == 0) {
             // (one value at a time: in pairs this instantiation nearly doubles its run time -- 7.25 -> 12.9 ms at H = 256)
-            put<H>(dst, tp, r, linear ? pend[r] : silu_scaled(pend[r]));
+            put<H>(dst, tp, r, linear ? lin(pend[r]) : act(pend[r]));
         } else if (!(r & 1)) {
-            const float y0 = linear ? pend[r] : silu_scaled(pend[r]), y1 = linear ? pend[r + 1] : silu_scaled(pend[r + 1]);
+            const float y0 = linear ? lin(pend[r]) : act(pend[r]), y1 = linear ? lin(pend[r + 1]) : act(pend[r + 1]);
             put_pair<H>(dst, tp, r, y0, y1);
         }
     }
@@ -490,8 +536,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     lds_f* par = (lds_f*)(lds_raw + kRing * C::CHUNK);      // [layers][H] biases | bias_in | w_radial
     lds_f* par_in = par + layers * H;
     lds_f* par_wr = par_in + H;
+    lds_f* par_sc = par_wr + H;                             // [kScaleSlots][4]: struct Scale of every packed layer
     // the source nodes of this wavefront's 32 edges (in-kernel message aggregation: where the pieces end)
-    __attribute__((address_space(3))) int* seg_src = (__attribute__((address_space(3))) int*)(par_wr + H) + wave * 32;
+    __attribute__((address_space(3))) int* seg_src = (__attribute__((address_space(3))) int*)(par_sc + 4 * kScaleSlots) + wave * 32;
+    constexpr int ACT = kActExp<PREC>;
+    constexpr float kIn = kLog2e * pow2_const(ACT);          // a caller's value x -> the carried 2^b log2(e) x
+    constexpr float kOut = kLn2 * pow2_const(-ACT);          // a carried value -> the caller's
 
     // (the device-side count arrives through a vector load: made scalar by hand, or every loop bound derived from it -- and
     // with them the whole ring state of the tile loop -- lives in vector registers and is updated by the vector ALU)
@@ -519,7 +569,19 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     const int64_t tile_lo = xcd * xcd_tiles, tile_hi = tile_lo + xcd_tiles < n_tiles ? tile_lo + xcd_tiles : n_tiles;
     if (tile_lo + xcd_slot >= tile_hi) return;              // uniform per workgroup
 
-    for (int i = threadIdx.x; i < layers * H; i += kWaves * kWave) par[i] = p.biases[i] * kLog2e;
+    // a layer's bias in its accumulator's units: log2(e) 2^(a_l + b) b_l (exact: a power of two)
+    for (int i = threadIdx.x; i < layers * H; i += kWaves * kWave) {
+        const int a = PREC == 1 && p.exps ? p.exps[i / H] : 0;
+        par[i] = p.biases[i] * kLog2e * pow2_bits(a + ACT);
+    }
+    if (threadIdx.x < kScaleSlots) {
+        const int packed = layers + (!ROWS ? 1 : (MODE == 3 && p.proj_out ? 2 : 0));
+        const int a = PREC == 1 && p.exps && (int)threadIdx.x < packed ? p.exps[threadIdx.x] : 0;
+        par_sc[4 * threadIdx.x + 0] = -pow2_bits(-(a + ACT));
+        par_sc[4 * threadIdx.x + 1] = pow2_bits(a);
+        par_sc[4 * threadIdx.x + 2] = pow2_bits(-a);
+        par_sc[4 * threadIdx.x + 3] = kLn2 * pow2_bits(-(a + ACT));
+    }
     if constexpr (!ROWS) {
         for (int i = threadIdx.x; i < H; i += kWaves * kWave) {
             par_in[i] = p.bias_in[i] * kLog2e;
@@ -568,6 +630,21 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             }
         }
         return acc;
+    };
+    // struct Scale of packed layer l, in scalar registers (one LDS read per layer; PREC 0 never uses it)
+    auto load_scale = [&](int l) -> Scale {
+        Scale sc{-1.0f, 1.0f, 1.0f, kLn2};
+        if constexpr (PREC == 1) {
+            // (four scalar reads ON PURPOSE: with one 16-byte read, hipcc 7.2 hands element 0 to all four v_readfirstlane --
+            // only ds_read_b32 of the first float is emitted; seen in the ISA, reproduced in a ten-line kernel)
+            const lds_f* q = par_sc + 4 * l;
+            const float v[4] = {q[0], q[1], q[2], q[3]};
+            sc.neg_c = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v[0])));
+            sc.k = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v[1])));
+            sc.inv_a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v[2])));
+            sc.out = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v[3])));
+        }
+        return sc;
     };
     const lds_c* w_cur = ch.prime();
     Frag pre[PFD];
@@ -630,7 +707,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     // z = log2(e) ((a + b) + b0 + radial wr): b0 and wr are staged pre-scaled, two fused multiply-adds per value
                     float y[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] = silu_scaled(__builtin_fmaf(a[i] + b[i], kLog2e, __builtin_fmaf(radial, wr[i], b0[i])));
+                    for (int i = 0; i < 4; ++i) y[i] = silu_first<PREC>(__builtin_fmaf(a[i] + b[i], kLog2e, __builtin_fmaf(radial, wr[i], b0[i])));
                     put_pair<H>(xa, q >> 2, 4 * (q & 3), y[0], y[1]);
                     put_pair<H>(xa, q >> 2, 4 * (q & 3) + 2, y[2], y[3]);
                 }
@@ -643,7 +720,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             for (int q = 0; q < H / 8; ++q) {
                 const f32x4 a = *(const f32x4*)(px + 8 * q);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) put<H>(xa, q >> 2, 4 * (q & 3) + i, a[i] * kLog2e);
+                for (int i = 0; i < 4; ++i) put<H>(xa, q >> 2, 4 * (q & 3) + i, a[i] * kIn);
                 if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -656,7 +733,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         // writes tile `tp` of `epi_dst`, (b) from the middle on, the reads of the NEXT tile's first fragments and bias
         // (next_bias == nullptr: that tile starts from zero -- the head).
         auto run_tile = [&](const Act<H, PREC>& in, bool have, int tp, Act<H, PREC>& epi_dst, const lds_f* next_bias,
-                            bool linear = false) -> f32x16 {
+                            const Scale& epi_sc, bool linear = false) -> f32x16 {
             MDX_STAMP(4);
             f32x16 acc = acc_next;
             Frag fr[STEPS + PFD];
@@ -674,7 +751,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #endif
                 if (s == STEPS - 1) acc_next = read_bias(next_bias);
 #if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 16))
-                if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, ROWS && linear);
+                if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, epi_sc, ROWS && linear);
 #else
                 if (have && s == 0) asm volatile("" ::"v"(pend));      // keep the MFMAs alive without their epilogue
 #endif
@@ -711,18 +788,21 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         // One layer: tiles t = 0 .. NT-1.  The epilogue beside tile t is that of the tile before it: tile t-1 of this layer
         // (-> out), or, at t = 0, the last tile of the previous layer (-> in: its features are the last k-steps of this
         // layer, produced before the MFMAs that read them).  FIRST: nothing is outstanding at t = 0.
+        Scale sc_prev = load_scale(0);                        // of the layer whose last tile's epilogue is outstanding
         auto layer = [&](auto first_tag, Act<H, PREC>& in, Act<H, PREC>& out, int l) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const lds_f* bias = par + l * H;
+            const Scale sc = load_scale(l);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 // the tile after this one: the next tile of this layer, the first of the next layer, or -- after the last
                 // layer -- the head (no bias; MODE 0) / layer 0 of the next rows (MODE 1)
                 const lds_f* next_bias = t + 1 < NT ? bias + 32 * (t + 1) : (l + 1 < layers ? bias + H : (!ROWS || (MODE == 3 && p.proj_out) ? nullptr : par));
                 // the epilogue beside tile 0 belongs to the previous layer (never the linear one); the others to this layer
-                if (t == 0) pend = run_tile(in, !FIRST, NT - 1, in, next_bias);
-                else pend = run_tile(in, true, t - 1, out, next_bias, l == layers - 1);
+                if (t == 0) pend = run_tile(in, !FIRST, NT - 1, in, next_bias, sc_prev);
+                else pend = run_tile(in, true, t - 1, out, next_bias, sc, l == layers - 1);
             }
+            sc_prev = sc;
         };
         // messages = the operand registers of the first coordinate layer, complete once its first tile has run
         auto store_messages = [&](const Act<H, PREC>& m) {
@@ -739,7 +819,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 const int t = q >> 2, r0 = 4 * (q & 3);
                 if constexpr (PREC == 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] = m.v[16 * t + r0 + i] * kLn2;
+                    for (int i = 0; i < 4; ++i) y[i] = m.v[16 * t + r0 + i] * kOut;
                 } else {
                     // hi + lo in one instruction per value: v_fma_mix_f32 with both addends taken from the packed halves
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -750,8 +830,8 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                         float y0, y1;
                         asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(ph), "v"(pl));
                         asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(y1) : "v"(ph), "v"(pl));
-                        y[2 * pr] = y0 * kLn2;
-                        y[2 * pr + 1] = y1 * kLn2;
+                        y[2 * pr] = y0 * kOut;
+                        y[2 * pr + 1] = y1 * kOut;
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) out_of_range = out_of_range || !(__builtin_fabsf(y[i]) <= 3.0e38f);
@@ -789,7 +869,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 for (int g = 0; g < 4; ++g) {
                     if constexpr (PREC == 0) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) x[4 * g + i] = m.v[16 * t + 4 * g + i] * kLn2;
+                        for (int i = 0; i < 4; ++i) x[4 * g + i] = m.v[16 * t + 4 * g + i] * kOut;
                     } else {
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         const int r0 = 4 * g;
@@ -800,8 +880,8 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                             float y0, y1;
                             asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(ph), "v"(pl));
                             asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(y1) : "v"(ph), "v"(pl));
-                            x[4 * g + 2 * pr] = y0 * kLn2;
-                            x[4 * g + 2 * pr + 1] = y1 * kLn2;
+                            x[4 * g + 2 * pr] = y0 * kOut;
+                            x[4 * g + 2 * pr + 1] = y1 * kOut;
                         }
                     }
                 }
@@ -835,14 +915,15 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         // the head: one more tile whose image row 0 is w_out (no bias, no activation): s_e = row 0 of the accumulator
         auto head_tile = [&](Act<H, PREC>& in) {
             Act<H, PREC> unused;
-            const f32x16 acc = run_tile(in, true, NT - 1, in, par);      // after the head: layer 0, tile 0 of the next edges
+            const f32x16 acc = run_tile(in, true, NT - 1, in, par, sc_prev);      // after the head: layer 0, tile 0 of the next edges
             (void)unused;
-            if constexpr (PREC == 1) out_of_range = out_of_range || (live && !(__builtin_fabsf(acc[0]) <= 3.0e38f));
-            if (live && h == 0) p.edge_scalar[e] = acc[0];
+            const float s_e = acc[0] * load_scale(layers).out;            // (the head row is packed as it is: ln 2 comes here)
+            if constexpr (PREC == 1) out_of_range = out_of_range || (live && !(__builtin_fabsf(s_e) <= 3.0e38f));
+            if (live && h == 0) p.edge_scalar[e] = s_e;
         };
         // MODE 1: the last tile of the last (linear) layer has no tile after it to run beside; then out = residual + y
         auto finish_rows = [&](Act<H, PREC>& y, Act<H, PREC>& u) {
-            epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, y, true);
+            epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, y, sc_prev, true);
             const bool project = MODE == 3 && p.proj_out != nullptr;       // out is also the operand of two more linear layers
             const float* res = p.residual ? p.residual + e * p.ld_in + 4 * h : nullptr;
             float* row = p.rows_out + e * H + 4 * h;
@@ -853,7 +934,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     const int t = q >> 2, r0 = 4 * (q & 3);
                     if constexpr (PREC == 0) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = y.v[16 * t + r0 + i] * kLn2;
+                        for (int i = 0; i < 4; ++i) v[i] = y.v[16 * t + r0 + i] * kOut;
                     } else {
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         const u32x4 vh = __builtin_bit_cast(u32x4, y.hi[2 * t + (r0 >> 3)]), vl = __builtin_bit_cast(u32x4, y.lo[2 * t + (r0 >> 3)]);
@@ -863,8 +944,8 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                             float y0, y1;
                             asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(ph), "v"(pl));
                             asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(y1) : "v"(ph), "v"(pl));
-                            v[2 * pr] = y0 * kLn2;
-                            v[2 * pr + 1] = y1 * kLn2;
+                            v[2 * pr] = y0 * kOut;
+                            v[2 * pr + 1] = y1 * kOut;
                         }
 #pragma unroll
                         for (int i = 0; i < 4; ++i) out_of_range = out_of_range || !(__builtin_fabsf(v[i]) <= 3.0e38f);
@@ -890,8 +971,8 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #pragma unroll
                         for (int q = 0; q < H / 8; ++q) {
                             const f32x4 a = *(const f32x4*)(pr + 8 * q);
-                            put_pair<H>(u, q >> 2, 4 * (q & 3), a[0] * kLog2e, a[1] * kLog2e);
-                            put_pair<H>(u, q >> 2, 4 * (q & 3) + 2, a[2] * kLog2e, a[3] * kLog2e);
+                            put_pair<H>(u, q >> 2, 4 * (q & 3), a[0] * kIn, a[1] * kIn);
+                            put_pair<H>(u, q >> 2, 4 * (q & 3) + 2, a[2] * kIn, a[3] * kIn);
                             if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -899,11 +980,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #pragma unroll 1
                     for (int t2 = 0; t2 < 2 * NT; ++t2) {
                         if constexpr (C::SPREAD) ch.scalar_addresses();    // (loop-carried: see scalar_addresses)
-                        const f32x16 acc = run_tile(u, false, 0, u, t2 + 1 < 2 * NT ? nullptr : par);
+                        const f32x16 acc = run_tile(u, false, 0, u, t2 + 1 < 2 * NT ? nullptr : par, sc_prev);
+                        const float to_out = load_scale(layers + t2 / NT).out;
                         if (live) {
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
-                                const f32x4 v = {acc[4 * g] * kLn2, acc[4 * g + 1] * kLn2, acc[4 * g + 2] * kLn2, acc[4 * g + 3] * kLn2};
+                                const f32x4 v = {acc[4 * g] * to_out, acc[4 * g + 1] * to_out, acc[4 * g + 2] * to_out, acc[4 * g + 3] * to_out};
                                 if constexpr (PREC == 1) {
 #pragma unroll
                                     for (int i = 0; i < 4; ++i) out_of_range = out_of_range || !(__builtin_fabsf(v[i]) <= 3.0e38f);
@@ -921,7 +1003,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             // pass A: layer 0 = the first half of the wide weight on h; no epilogue, the accumulators are parked in xb
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const f32x16 acc = run_tile(xa, false, 0, xa, t + 1 < NT ? par + 32 * (t + 1) : nullptr);
+                const f32x16 acc = run_tile(xa, false, 0, xa, t + 1 < NT ? par + 32 * (t + 1) : nullptr, sc_prev);
                 park(xb, t, acc);
             }
             // the operand registers again, with agg (columns H .. 2H-1 of the row)
@@ -931,7 +1013,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 for (int q = 0; q < H / 8; ++q) {
                     const f32x4 a = *(const f32x4*)(px + 8 * q);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) put<H>(xa, q >> 2, 4 * (q & 3) + i, a[i] * kLog2e);
+                    for (int i = 0; i < 4; ++i) put<H>(xa, q >> 2, 4 * (q & 3) + i, a[i] * kIn);
                     if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -940,7 +1022,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const lds_f* after = t + 1 < NT ? nullptr : par + 2 * H;          // layer 2, tile 0 (there always is one)
-                pend = run_tile(xa, t > 0, t - 1, xb, after);
+                pend = run_tile(xa, t > 0, t - 1, xb, after, sc_prev);      // (layers 0 and 1 share one exponent: sc_prev = layer 0's)
                 if (t + 1 < NT) acc_next = unpark(xb, t + 1);
             }
             l_first = 2;
@@ -1011,8 +1093,54 @@ struct PackArgs {
     const float* w[MDX_EGNN_CHAIN_MAX_LAYERS];      // [H][H] nn.Linear weights (out, in), device
     const float* w_out;                             // [H] the coordinate head: row 0 of one more 32-row chunk (rest zero)
     int layers, H, precision;
+    uint32_t tied;                                  // bit l: layer l shares its exponent with layer l - 1
+    int32_t* exps;                                  // [layers + 1] (split-f16): the image holds 2^exps[l] W_l
     void* image;
 };
+
+// Split-f16 exponents, pass 1: exps[l] (as unsigned) = the bits of max |W_l| (non-negative floats order like their bits).
+__global__ __launch_bounds__(256) void egnn_chain_maxabs_kernel(PackArgs p)
+{
+    const int l = blockIdx.y;                       // == p.layers: the head row
+    const bool head = l == p.layers;
+    const float* w = head ? p.w_out : p.w[l];
+    const int64_t n = head ? p.H : (int64_t)p.H * p.H;
+    uint32_t m = 0;
+    if (w)
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const uint32_t b = __builtin_bit_cast(uint32_t, w[i]) & 0x7fffffffu;
+            if (b < 0x7f800000u && b > m) m = b;    // (infinities and NaNs are not magnitudes to scale for)
+        }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)m, d);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax((uint32_t*)p.exps + l, m);
+}
+// pass 2 (one thread): bits of the maximum -> a_l with 2^a_l max|W_l| in [2^13, 2^14) (0 for an all-zero layer); tied layers
+// (the two halves of a wide first layer, whose accumulators continue one another) take the smaller exponent of their run.
+__global__ void egnn_chain_exponents_kernel(PackArgs p)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    for (int l = 0; l <= p.layers; ++l) {
+        const uint32_t b = ((const uint32_t*)p.exps)[l];
+        int a = 0;
+        if (b && kScaled) {
+            const int e = (int)(b >> 23) - 127;     // floor(log2 m) for a normal m; subnormal maxima: treated as 2^-126
+            a = 13 - (e < -126 ? -126 : e);
+            a = a > 40 ? 40 : (a < -40 ? -40 : a);
+        }
+        p.exps[l] = a;
+    }
+    for (int l = 1; l < p.layers; ++l)
+        if (p.tied >> l & 1u) {
+            int lo = l - 1;
+            while (lo > 0 && (p.tied >> lo & 1u)) --lo;
+            int a = p.exps[lo];
+            for (int k = lo + 1; k <= l; ++k) a = p.exps[k] < a ? p.exps[k] : a;
+            for (int k = lo; k <= l; ++k) p.exps[k] = a;
+        }
+}
 
 __global__ __launch_bounds__(256) void egnn_chain_pack_kernel(PackArgs p)
 {
@@ -1027,7 +1155,7 @@ __global__ __launch_bounds__(256) void egnn_chain_pack_kernel(PackArgs p)
         (void)NT;
         const bool head = l == p.layers;
         auto weight = [&](int n, int k) -> float {
-            if (head) return (n == 0 && p.w_out) ? p.w_out[k] * kLn2 : 0.0f;       // the chain carries log2(e) x activation
+            if (head) return (n == 0 && p.w_out) ? p.w_out[k] : 0.0f;       // (the kernel multiplies the head's sum by ln 2)
             return p.w[l][(int64_t)n * H + k];
         };
         if (p.precision == 0) {
@@ -1039,7 +1167,7 @@ __global__ __launch_bounds__(256) void egnn_chain_pack_kernel(PackArgs p)
             // chunk: [s = H/16][hi: lane 64 x 8 halfs | lo: lane 64 x 8 halfs]; element j: k = 16 s + 8 (j >> 2) + 4 h + (j & 3)
             const int s = (int)(r / 512), lane = (int)(r % 512) / 8, j = (int)(r % 8);
             const int n = 32 * t + (lane & 31), k = 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-            const float v = weight(n, k);
+            const float v = weight(n, k) * pow2_bits(p.exps[l]);      // exact (a power of two; |v| < 2^14)
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)(v - (float)hi);
             _Float16* chunk = (_Float16*)((char*)p.image + ((int64_t)l * (H / 32) + t) * ((int64_t)H * 32 * 4));
@@ -1104,7 +1232,7 @@ int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
 {
     using C = Chain<H, PREC>;
     // ring | biases + first-layer vectors | per-wavefront source ids of the in-kernel aggregation
-    const size_t lds = (size_t)kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H) +
+    const size_t lds = (size_t)kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H + 4 * kScaleSlots) +
                        (MODE == 2 ? sizeof(int) * kWaves * 32 : 0);
     static bool granted[64] = {};       // (one flag per instantiation: function-local static of a template)
     int dev = 0;
@@ -1138,9 +1266,10 @@ int64_t mdx_egnn_chain_image_bytes(int hidden, int n_layers)
 }
 
 int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, const float* w_out, int hidden, int precision,
-                        void* image_out, mdx_stream_t stream)
+                        uint32_t tied_layers, void* image_out, int32_t* exponents_out, mdx_stream_t stream)
 {
     if (!weights_host || !image_out || n_layers < 1 || (precision != 0 && precision != 1)) return MDX_ERR_INVALID_ARG;
+    if (precision == 1 && !exponents_out) return MDX_ERR_INVALID_ARG;
     if (n_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     if (hidden != 32 && hidden != 64 && hidden != 128 && hidden != 256) return MDX_ERR_UNSUPPORTED;
     PackArgs a{};
@@ -1150,10 +1279,19 @@ int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, const fl
     }
     a.w_out = w_out;
     a.layers = n_layers; a.H = hidden; a.precision = precision; a.image = image_out;
+    a.tied = tied_layers; a.exps = exponents_out;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (exponents_out) {
+        if (hipMemsetAsync(exponents_out, 0, sizeof(int32_t) * (n_layers + 1), st) != hipSuccess) return MDX_ERR_HIP;
+        if (precision == 1) {
+            hipLaunchKernelGGL(egnn_chain_maxabs_kernel, dim3(32, (unsigned)n_layers + 1), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(egnn_chain_exponents_kernel, dim3(1), dim3(64), 0, st, a);
+        }
+    }
     const int64_t total = (int64_t)n_layers * hidden * hidden + 32 * hidden;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(egnn_chain_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(egnn_chain_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 
@@ -1169,10 +1307,11 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
     if (c->hidden != 32 && c->hidden != 64 && c->hidden != 128 && c->hidden != 256) return MDX_ERR_UNSUPPORTED;
     if (n_edges == 0) return MDX_OK;
     if (!c->weight_image || !c->biases || !c->bias_in || !c->w_radial || !node_proj || !coord || !edges ||
-        !messages_out || !edge_scalar_out)
+        !messages_out || !edge_scalar_out || (c->precision == 1 && !c->weight_exponents))
         return MDX_ERR_INVALID_ARG;
     ChainArgs a{};
     a.image = (const char*)c->weight_image; a.biases = c->biases; a.bias_in = c->bias_in; a.w_radial = c->w_radial;
+    a.exps = c->weight_exponents;
     a.node_proj = node_proj; a.coord = coord; a.edges = edges; a.n_edges_dev = n_edges_dev;
     a.n_edges = n_edges; a.n_message = c->n_message_layers; a.n_coord = c->n_coord_layers; a.D = coord_dimension;
     a.messages = messages_out; a.edge_scalar = edge_scalar_out; a.status = status;
@@ -1223,9 +1362,9 @@ int mdx_mlp_chain_rows(const mdx_egnn_chain_t* c, const float* x, const float* r
     if (c->n_message_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     if (c->hidden != 32 && c->hidden != 64 && c->hidden != 128 && c->hidden != 256) return MDX_ERR_UNSUPPORTED;
     if (n_rows == 0) return MDX_OK;
-    if (!c->weight_image || !c->biases || !x || !out) return MDX_ERR_INVALID_ARG;
+    if (!c->weight_image || !c->biases || !x || !out || (c->precision == 1 && !c->weight_exponents)) return MDX_ERR_INVALID_ARG;
     ChainArgs a{};
-    a.image = (const char*)c->weight_image; a.biases = c->biases;
+    a.image = (const char*)c->weight_image; a.biases = c->biases; a.exps = c->weight_exponents;
     a.n_edges_dev = n_rows_dev; a.n_edges = n_rows; a.n_message = c->n_message_layers; a.n_coord = 0; a.D = 0;
     a.rows_in = x; a.residual = residual; a.rows_out = out; a.status = status; a.ld_in = c->hidden;
     const int layers = a.n_message;
@@ -1250,9 +1389,9 @@ int mdx_node_mlp_rows(const mdx_egnn_chain_t* c, const float* node_in, int add_r
     if (c->n_message_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     if (c->hidden != 32 && c->hidden != 64 && c->hidden != 128 && c->hidden != 256) return MDX_ERR_UNSUPPORTED;
     if (n_rows == 0) return MDX_OK;
-    if (!c->weight_image || !c->biases || !node_in || !out) return MDX_ERR_INVALID_ARG;
+    if (!c->weight_image || !c->biases || !node_in || !out || (c->precision == 1 && !c->weight_exponents)) return MDX_ERR_INVALID_ARG;
     ChainArgs a{};
-    a.image = (const char*)c->weight_image; a.biases = c->biases;
+    a.image = (const char*)c->weight_image; a.biases = c->biases; a.exps = c->weight_exponents;
     a.n_edges_dev = n_rows_dev; a.n_edges = n_rows; a.n_message = c->n_message_layers; a.n_coord = 0; a.D = 0;
     a.rows_in = node_in; a.residual = add_residual ? node_in : nullptr; a.rows_out = out; a.status = status;
     a.ld_in = 2 * (int64_t)c->hidden;

@@ -573,6 +573,23 @@ def segment_rows(data, offsets, degree, mean: bool) -> torch.Tensor:
 EDGE_CHAIN_PRECISIONS = {"f32": 0, "f16x3": 1}
 
 
+def _pack_chain_image(weights, w_out, H: int, precision: str, tied_layers: int = 0):
+    """(image, exponents) of mdx_egnn_chain_pack for device matrices `weights` ([H, H] each, nn.Linear layout) and the
+    optional head row w_out [H].  exponents: int32 [len(weights) + 1] on the device -- the per-layer powers of two the
+    split-f16 image is scaled by (zeros for "f32"), chosen and written by the library without a host read."""
+    dev = weights[0].device
+    keep = [w.detach().to(F32).contiguous() for w in weights]
+    image = torch.empty(lib().mdx_egnn_chain_image_bytes(H, len(keep)), dtype=torch.uint8, device=dev)
+    exponents = torch.empty(len(keep) + 1, dtype=I32, device=dev)
+    array = (C.c_void_p * len(keep))(*[w.data_ptr() for w in keep])
+    head = None if w_out is None else w_out.detach().reshape(-1).to(F32).contiguous()
+    with torch.cuda.device(dev):
+        check(lib().mdx_egnn_chain_pack(array, len(keep), None if head is None else C.c_void_p(head.data_ptr()), H,
+                                        EDGE_CHAIN_PRECISIONS[precision], tied_layers, C.c_void_p(image.data_ptr()),
+                                        C.c_void_p(exponents.data_ptr()), stream_handle()), "mdx_egnn_chain_pack")
+    return image, exponents      # (the temporaries are freed in stream order: the image holds its own copy)
+
+
 class EdgeChainPack:
     """Device image of one E_GCL layer's per-edge MLP chain for mdx_egnn_edge_chain: the H -> H weight matrices of the
     message MLP (after its first layer) and of the coordinate MLP, re-laid out by mdx_egnn_chain_pack for `precision`,
@@ -587,15 +604,7 @@ class EdgeChainPack:
         if not self.supported(first_message_layer, message_layers, coord_layers, coord_out_layer):
             raise _hip.MdxError("this E_GCL shape is not covered by the fused edge chain (see mdx_egnn_edge_chain)")
         self.precision, self.hidden = precision, H
-        self._keep = [layer.weight.detach().to(F32).contiguous() for layer in layers]
-        n_bytes = lib().mdx_egnn_chain_image_bytes(H, len(layers))
-        self.image = torch.empty(n_bytes, dtype=torch.uint8, device=dev)
-        array = (C.c_void_p * len(layers))(*[w.data_ptr() for w in self._keep])
-        self.w_out = coord_out_layer.weight.detach().reshape(-1).to(F32).contiguous()
-        with torch.cuda.device(dev):
-            check(lib().mdx_egnn_chain_pack(array, len(layers), C.c_void_p(self.w_out.data_ptr()), H,
-                                            EDGE_CHAIN_PRECISIONS[precision], C.c_void_p(self.image.data_ptr()),
-                                            stream_handle()), "mdx_egnn_chain_pack")
+        self.image, self.exponents = _pack_chain_image([layer.weight for layer in layers], coord_out_layer.weight, H, precision)
         self.biases = torch.stack([layer.bias.detach().to(F32) for layer in layers]).contiguous()
         self.bias_in = first_message_layer.bias.detach().to(F32).contiguous()
         self.w_radial = first_message_layer.weight.detach()[:, 2 * input_size].to(F32).contiguous()
@@ -604,11 +613,11 @@ class EdgeChainPack:
         self.proj_weight = torch.cat([w0[:, :input_size], w0[:, input_size:2 * input_size]], dim=0).contiguous()
         self.c_struct = _hip.EgnnChain(H, len(list(message_layers)), len(list(coord_layers)),
                                        EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
-                                       self.biases.data_ptr(), self.bias_in.data_ptr(), self.w_radial.data_ptr())
-        # the kernel's LDS: weight ring + small vectors + the source ids of the in-kernel aggregation
-        lds = 4 * 32 * H * 4 + 4 * (len(layers) * H + 2 * H) + 4 * 4 * 32
+                                       self.biases.data_ptr(), self.bias_in.data_ptr(), self.w_radial.data_ptr(),
+                                       self.exponents.data_ptr())
+        # the kernel's LDS: weight ring + small vectors + per-layer scale table + the source ids of the in-kernel aggregation
+        lds = 4 * 32 * H * 4 + 4 * (len(layers) * H + 2 * H) + 16 * (_hip.EGNN_CHAIN_MAX_LAYERS + 3) + 4 * 4 * 32
         self.piece_sums_ok = lds <= 160 * 1024
-        self._keep = []                    # the image holds its own copy (temporaries are freed in stream order)
         self.device = dev
 
     @staticmethod
@@ -635,15 +644,10 @@ class RowChainPack:
             raise _hip.MdxError("this layer stack is not covered by mdx_mlp_chain_rows")
         dev = layers[0].weight.device
         self.precision, self.hidden = precision, H
-        keep = [layer.weight.detach().to(F32).contiguous() for layer in layers]
-        self.image = torch.empty(lib().mdx_egnn_chain_image_bytes(H, len(layers)), dtype=torch.uint8, device=dev)
-        array = (C.c_void_p * len(layers))(*[w.data_ptr() for w in keep])
-        with torch.cuda.device(dev):
-            check(lib().mdx_egnn_chain_pack(array, len(layers), None, H, EDGE_CHAIN_PRECISIONS[precision],
-                                            C.c_void_p(self.image.data_ptr()), stream_handle()), "mdx_egnn_chain_pack")
+        self.image, self.exponents = _pack_chain_image([layer.weight for layer in layers], None, H, precision)
         self.biases = torch.stack([layer.bias.detach().to(F32) for layer in layers]).contiguous()
         self.c_struct = _hip.EgnnChain(H, len(layers), 0, EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
-                                       self.biases.data_ptr(), None, None)
+                                       self.biases.data_ptr(), None, None, self.exponents.data_ptr())
 
     @staticmethod
     def supported(layers) -> bool:
@@ -677,16 +681,15 @@ class NodeMlpPack:
         if self.projects:
             assert tuple(next_projection.shape) == (2 * H, H)
             keep += [next_projection[:H].detach().to(F32).contiguous(), next_projection[H:].detach().to(F32).contiguous()]
-        self.image = torch.empty(lib().mdx_egnn_chain_image_bytes(H, len(keep)), dtype=torch.uint8, device=dev)
-        array = (C.c_void_p * len(keep))(*[w.data_ptr() for w in keep])
-        with torch.cuda.device(dev):
-            check(lib().mdx_egnn_chain_pack(array, len(keep), None, H, EDGE_CHAIN_PRECISIONS[precision],
-                                            C.c_void_p(self.image.data_ptr()), stream_handle()), "mdx_egnn_chain_pack")
+        # tied: the two halves of the wide first layer (their accumulators continue one another) and the two halves of the
+        # projection share a power of two each
+        tied = (1 << 1) | ((1 << (n + 1)) if self.projects else 0)
+        self.image, self.exponents = _pack_chain_image(keep, None, H, precision, tied_layers=tied)
         zeros = torch.zeros(H, dtype=F32, device=dev)
         self.biases = torch.stack([layers[0].bias.detach().to(F32), zeros] +
                                   [l.bias.detach().to(F32) for l in layers[1:]]).contiguous()
         self.c_struct = _hip.EgnnChain(H, n, 0, EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
-                                       self.biases.data_ptr(), None, None)
+                                       self.biases.data_ptr(), None, None, self.exponents.data_ptr())
 
     @staticmethod
     def supported(layers) -> bool:

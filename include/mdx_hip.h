@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 7
+#define MDX_ABI_VERSION 8
 
 /* status codes */
 #define MDX_OK 0
@@ -361,7 +361,11 @@ MDX_API int mdx_segment_rows(const float* data, const int64_t* offsets, const in
  * normalize (callers keep the per-layer library path for those).
  * precision 0: v_mfma_f32_32x32x2_f32, exact binary32 (== fmaf chains in a fixed order).
  * precision 1: split-f16, three v_mfma_f32_32x32x16_f16 per product (hi.hi + hi.lo + lo.hi), binary32 accumulation:
- *              ~2^-22 relative per product; sets MDX_STATUS_EGNN_F16_RANGE when an activation exceeds 6e4 in magnitude.
+ *              ~2^-22 relative per product.  Both operands are held scaled by exact powers of two so that the f16 halves
+ *              keep their 22 bits at small magnitudes: the image of layer l is 2^a_l W_l with the layer's largest |W| in
+ *              [2^13, 2^14) (a_l chosen by mdx_egnn_chain_pack and written to weight_exponents), the activations carried
+ *              between layers are 2^MDX_EGNN_F16_ACTIVATION_EXPONENT times their value; the kernel undoes both (exact).
+ *              Sets MDX_STATUS_EGNN_F16_RANGE when an activation leaves the f16 range: |SiLU output| > ~709.
  * weight_image: the n_message_layers + n_coord_layers matrices [H,H] (nn.Linear layout; weights_host = host array of
  * device pointers) and the head's weight w_out [H], re-laid out by mdx_egnn_chain_pack for the chosen precision
  * (mdx_egnn_chain_image_bytes bytes, caller-owned, 16-byte aligned); the head rides the same pipeline as one more
@@ -371,6 +375,7 @@ MDX_API int mdx_segment_rows(const float* data, const int64_t* offsets, const in
 #define MDX_EGNN_CHAIN_MAX_LAYERS 16
 #define MDX_EGNN_MESSAGES_ROWS 0        /* messages_out [E,H] = the messages                                            */
 #define MDX_EGNN_MESSAGES_PIECE_SUMS 1  /* messages_out [E,H] = per-node piece sums (see mdx_segment_combine)           */
+#define MDX_EGNN_F16_ACTIVATION_EXPONENT 6
 typedef struct mdx_egnn_chain {
     int32_t hidden, n_message_layers, n_coord_layers, precision;
     int32_t message_mode, reserved;     /* MDX_EGNN_MESSAGES_*; reserved = 0 */
@@ -378,10 +383,16 @@ typedef struct mdx_egnn_chain {
     const float* biases;       /* [n_message_layers + n_coord_layers, H] */
     const float* bias_in;      /* [H]  bias of the first message layer                       */
     const float* w_radial;     /* [H]  its weight column for the squared distance            */
+    const int32_t* weight_exponents;   /* device, [packed layers + 1]: as written by mdx_egnn_chain_pack; required for
+                                          precision 1, ignored (may be NULL) for precision 0 */
 } mdx_egnn_chain_t;
 MDX_API int64_t mdx_egnn_chain_image_bytes(int hidden, int n_layers);
+/* tied_layers: bit l set = layer l uses the same power of two as layer l - 1 (the two H x H halves of a Linear(2H, H), whose
+ * accumulators continue one another: mdx_node_mlp_rows).  exponents_out: device, [n_layers + 1] (last: the head row's);
+ * required for precision 1; with precision 0 it is zero-filled when given.  No host synchronisation. */
 MDX_API int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, const float* w_out, int hidden,
-                                int precision, void* image_out, mdx_stream_t stream);
+                                int precision, uint32_t tied_layers, void* image_out, int32_t* exponents_out,
+                                mdx_stream_t stream);
 MDX_API int mdx_egnn_edge_chain(const mdx_egnn_chain_t* chain_host, const float* node_proj, const float* coord,
                                 int coord_dimension, const int64_t* edges, int64_t n_edges, const int64_t* n_edges_dev,
                                 float* messages_out, float* edge_scalar_out, uint32_t* status, mdx_stream_t stream);

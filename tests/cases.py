@@ -56,3 +56,9 @@ ADAPTIVE = {
 
 # BASELINE configs[0] at its exact settings (tests/golden/traj_c1_exact.npz): T = 100, batch 16, MLP template
 C1_EXACT = (noise_ns(100, sigma_min=1e-4, sigma_max=0.25), sampling_ns(8, 1), lambda eb: nets.mlp_net(8, 1))
+
+
+# BASELINE configs[2]'s network shape and sampler settings (tests/golden/traj_egnn_c3_{top,bottom}.npz: two indices of the
+# T = 1000 schedule at the top and at the bottom, B = 4, the production EGNN with formula weights)
+C3_SHAPE = (noise_ns(1000, **LIN), sampling_ns(64, 1, M=2, one=False, greedy=False, cell=[10.86] * 3),
+            lambda eb: nets.egnn_c3_net(1, edge_builder=eb))

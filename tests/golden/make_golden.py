@@ -715,6 +715,60 @@ def golden_c1_exact():
     save("traj_c1_exact.npz", **out)
 
 
+def _egnn_c3(num_atom_types=1):
+    """The reference's production EGNN (experiments/.../Si_2x2x2/config_diffusion_egnn.yaml:44-60): 4 graph layers, 256 wide,
+    4 hidden layers per MLP, radial cutoff 7.5 -- with every trainable parameter filled from tests/formula_weights.py
+    (the fixture then needs no 19 MB state_dict: the tests evaluate the same formula)."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from formula_weights import fill_with_formula
+    p = EGNNScoreNetworkParameters(num_atom_types=num_atom_types, n_layers=4,
+                                   coordinate_hidden_dimensions_size=256, coordinate_n_hidden_dimensions=4,
+                                   message_hidden_dimensions_size=256, message_n_hidden_dimensions=4,
+                                   node_hidden_dimensions_size=256, node_n_hidden_dimensions=4,
+                                   coords_agg="mean", message_agg="mean", attention=False, normalize=False, residual=True,
+                                   tanh=False, edges="radial_cutoff", radial_cutoff=7.5)
+    return fill_with_formula(EGNNScoreNetwork(p).eval())
+
+
+def golden_c3_shape():
+    """The network shape and sampler settings BASELINE configs[2] is quoted on (the benchmarked kernels'
+    instantiation), on the reference's CPU path:
+      net_egnn_c3.npz          EGNNScoreNetwork forward (models/score_networks/egnn_score_network.py:226-303), B = 8, N = 64
+      traj_egnn_c3_top.npz     LangevinGenerator.sample_from_noisy_composition(1000 -> 998)  (generators/langevin_generator.py:536-805)
+      traj_egnn_c3_bottom.npz  the same 2 -> 0 (index 0: the corrector's sigma_min special case, :719-725)
+    with T = 1000, sigma 1e-4 .. 0.2 linear, corrector_step_epsilon 2.5e-8, M = 2, no greedy / one-transition
+    (config_diffusion_egnn.yaml:84-103).  Draws and per-step compositions recorded; weights by formula."""
+    net = _egnn_c3(1)
+    g = torch.Generator().manual_seed(909)
+    B, N, cell = 8, 64, 10.86
+    batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.randint(0, 2, (B, N), generator=g), X=torch.rand(B, N, 3, generator=g),
+                                        L=torch.tensor([cell, cell, cell, 0, 0, 0.0]).repeat(B, 1)),
+             TIME: torch.rand(B, 1, generator=g), NOISE: torch.rand(B, 1, generator=g) * 0.2,
+             CARTESIAN_FORCES: torch.zeros(B, N, 3)}
+    with torch.no_grad():
+        o = net(batch, conditional=False)
+    save("net_egnn_c3.npz", A=_np(batch[NOISY_AXL_COMPOSITION].A), X=_np(batch[NOISY_AXL_COMPOSITION].X),
+         L=_np(batch[NOISY_AXL_COMPOSITION].L), time=_np(batch[TIME]), noise=_np(batch[NOISE]),
+         out_A=_np(o.A), out_X=_np(o.X), out_L=_np(o.L))
+
+    kw = dict(T=1000, N=64, num_atom_types=1, M=2, one=False, greedy=False, cell=[10.86] * 3,
+              noise_kw=dict(sigma_min=1e-4, sigma_max=0.2, schedule_type="linear", corrector_step_epsilon=2.5e-8))
+    B = 4
+    for name, start, end, masked_fraction in (("traj_egnn_c3_top", 1000, 998, 1.0), ("traj_egnn_c3_bottom", 2, 0, 0.1)):
+        gen, npar, spar = make_generator(record=True, net=net, **kw)
+        X0 = torch.rand(B, N, 3, generator=g)
+        A0 = (torch.rand(B, N, generator=g) < masked_fraction).long()          # MASK = num_atom_types = 1
+        L0 = torch.tensor([cell, cell, cell, 0, 0, 0.0]).repeat(B, 1)
+        torch.manual_seed(910 + start)
+        with torch.no_grad(), DrawRecorder() as rec:
+            axl = gen.sample_from_noisy_composition(AXL(A=A0, X=X0, L=L0), start, end)
+        out = dict(final_A=_np(axl.A), final_X=_np(axl.X), final_L=_np(axl.L), batch=np.array(B),
+                   start_A=_np(A0), start_X=_np(X0), start_L=_np(L0), start_index=np.array(start), end_index=np.array(end))
+        out.update(rec.pack())
+        out.update(_pack_records(gen))
+        save(name + ".npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -732,3 +786,5 @@ if __name__ == "__main__":
         golden_distances()
     if which in ("all", "c1"):
         golden_c1_exact()
+    if which in ("all", "c3"):
+        golden_c3_shape()

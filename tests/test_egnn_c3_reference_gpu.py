@@ -1,0 +1,116 @@
+"""GPU parity of the BENCHMARKED network shape against the REFERENCE's own outputs.
+
+bench.py's C3 / C4 / C5 lines run the reference's production EGNN -- 4 graph layers, 256 wide, 4 hidden layers per MLP,
+radius graph at rc = 7.5 (experiments/.../Si_2x2x2/config_diffusion_egnn.yaml:44-60) -- through
+egnn_edge_chain_kernel<256, PREC, 2> and <256, PREC, 3>.  The fixtures net_egnn_c3 / traj_egnn_c3_{top,bottom} hold what the
+reference computed at that shape (tests/golden/make_golden.py::golden_c3_shape; weights from tests/formula_weights.py), so
+these tests hold the fused HIP forward, in BOTH arithmetic modes of the MFMA kernels, and the sampler steps built on it
+against the reference itself -- not against the product's own module:
+
+  * network forward: scores within 1e-5 rel-L2 (north_star's tolerance), logits close, MASK logit -inf;
+  * every predictor / corrector step of the T = 1000 schedule's first two and last two indices, started from the
+    composition the reference recorded and fed the reference's draws: atom types exact, coordinates within 1e-5 (torus);
+  * the same four indices in free run.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import nets
+from conftest import load_golden, torus_rel_l2
+from oracle import reference_sampler as RS
+from test_generator_gpu import _pkg, _replayed
+
+pytestmark = pytest.mark.gpu
+
+MODES = ["f32", "f16x3", None]          # exact-f32 MFMA | split-f16 MFMA (the default) | per-layer library GEMMs
+
+
+def _batch(g, device):
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
+                                                                              NOISY_AXL_COMPOSITION, TIME)
+    t = lambda k: torch.from_numpy(g[k]).to(device)      # noqa: E731
+    return {NOISY_AXL_COMPOSITION: AXL(A=t("A"), X=t("X"), L=t("L")), TIME: t("time"), NOISE: t("noise"),
+            CARTESIAN_FORCES: torch.zeros(g["X"].shape, device=device)}
+
+
+@pytest.mark.parametrize("precision", MODES)
+def test_c3_network_forward_against_reference(cuda, precision):
+    g = load_golden("net_egnn_c3.npz")
+    net = nets.egnn_c3_net(1).to(cuda)
+    net.edge_chain_precision = precision
+    with torch.no_grad():
+        out = net(_batch(g, cuda), conditional=False)
+    net.check_status()
+    assert torch.isinf(out.A[..., -1]).all() and (out.A[..., -1] < 0).all()
+    ref = g["out_X"].astype(np.float64)
+    err = np.linalg.norm(out.X.cpu().numpy() - ref) / np.linalg.norm(ref)
+    assert err < 1e-5, f"{precision}: scores rel-L2 {err:.2e} against the reference"
+    np.testing.assert_allclose(out.A.cpu().numpy()[..., :-1], g["out_A"][..., :-1], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out.L.cpu().numpy(), g["out_L"], rtol=1e-5, atol=1e-7)
+    if precision is not None:        # the fused chain really ran: every graph layer holds a packed image for this mode
+        assert all(layer._chain[1] is not None and layer._chain[1].precision == precision
+                   for layer in net.egnn.graph_layers)
+
+
+def _generator(cuda, precision, **extra):
+    import warnings
+    P = _pkg()
+    noise_kw, sampling_kw, netf = cases.C3_SHAPE
+    skw = dict(sampling_kw)
+    skw.update(extra)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar, spar = P["Noise"](**noise_kw), P["Sampling"](**skw)
+    net = netf(None).to(cuda)
+    net.edge_chain_precision = precision
+    return P["Langevin"](npar, spar, net), spar
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("name", ["traj_egnn_c3_top", "traj_egnn_c3_bottom"])
+def test_c3_teacher_forced_steps(cuda, name, precision):
+    g = load_golden(name + ".npz")
+    gen, spar = _generator(cuda, precision)
+    gen.noise_source = _replayed(g)
+    B, M = int(g["batch"]), spar.number_of_corrector_steps
+
+    def axl(prefix, k):
+        return RS.AXL(A=torch.from_numpy(g[prefix + "_A"][k]).to(cuda), X=torch.from_numpy(g[prefix + "_X"][k]).to(cuda),
+                      L=torch.from_numpy(g[prefix + "_L"][k]).to(cuda))
+
+    worst = 0.0
+    with torch.no_grad():
+        gen._prepare(cuda)
+        gen._begin_call(cuda)
+        forces = torch.zeros(B, spar.number_of_atoms, 3, device=cuda)
+        for k, index in enumerate(g["pred_index"]):
+            out = gen.predictor_step(axl("pred_composition_i", k), int(index), forces)
+            assert np.array_equal(out.A.cpu().numpy(), g["pred_composition_im1_A"][k]), (name, "pred", k)
+            worst = max(worst, torus_rel_l2(out.X.cpu().numpy(), g["pred_composition_im1_X"][k]))
+            for m in range(M):
+                kk = k * M + m
+                out = gen.corrector_step(axl("corr_composition_i", kk), int(index) - 1, forces, m)
+                assert np.array_equal(out.A.cpu().numpy(), g["corr_corrected_composition_i_A"][kk]), (name, "corr", kk)
+                worst = max(worst, torus_rel_l2(out.X.cpu().numpy(), g["corr_corrected_composition_i_X"][kk]))
+    gen.check_status()
+    assert gen.noise_source.inner.exhausted()
+    assert worst < 1e-5, f"{name} / {precision}: worst per-step rel-L2 {worst:.2e}"
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("name", ["traj_egnn_c3_top", "traj_egnn_c3_bottom"])
+def test_c3_free_run_against_reference(cuda, name, precision):
+    g = load_golden(name + ".npz")
+    gen, spar = _generator(cuda, precision)
+    gen.noise_source = _replayed(g)
+    start = RS.AXL(A=torch.from_numpy(g["start_A"]).to(cuda), X=torch.from_numpy(g["start_X"]).to(cuda),
+                   L=torch.from_numpy(g["start_L"]).to(cuda))
+    with torch.no_grad():
+        out = gen.sample_from_noisy_composition(start, int(g["start_index"]), int(g["end_index"]))
+    gen.check_status()
+    assert gen.noise_source.inner.exhausted()
+    assert np.array_equal(out.A.cpu().numpy(), g["final_A"])
+    err = torus_rel_l2(out.X.cpu().numpy(), g["final_X"])
+    assert err < 1e-5, f"{name} / {precision}: final rel-L2 {err:.2e}"

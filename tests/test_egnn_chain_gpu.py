@@ -100,6 +100,64 @@ def test_edge_chain_against_fp64(cuda, precision, H, n_msg, n_crd, n_nodes, deg)
         assert (m2[E - 5:] == -7.0).all() and (s2[E - 5:] == -7.0).all()
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("case", ["small_activations", "tiny_activations", "small_weights", "mixed_weights"])
+def test_edge_chain_small_magnitudes_against_fp64(cuda, precision, case):
+    """The UNDERFLOW side of the split-f16 mode.  f16's subnormal step is 2^-24, so an unscaled split v = hi + lo stops
+    carrying 22 bits once |v| < 2^-3: default-initialised 256-wide layers (|W| <= 1/16) and activations of order 1e-3 are
+    already there.  The kernel therefore keeps the weight image scaled by an exact per-layer power of two (largest
+    |W| just under 2^14) and the carried activations by a fixed one (mdx_egnn_chain_t.activation_exponent), and undoes both
+    in the epilogue -- exact, so O(1) data sees no change.  Held here: the 9-layer chain at H = 256 against fp64 with
+      small_activations  default-init weights (order 1/16), biases scaled so that every layer's activations are of order 1e-3
+      tiny_activations   the same at order 1e-4
+      small_weights      weights x 0.05 (order 3e-3), O(1) biases and inputs
+      mixed_weights      a different factor per layer (0.02 .. 300): every layer gets its own power of two
+    at the same 1e-5 (f16x3) / 2e-6 (f32) as the O(1) cases.  (An unscaled split: 2e-5 and 2e-4 on the first two.)"""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    H, n_msg, n_crd, n_nodes, deg, n_in, D = 256, 4, 5, 400, 12, 24, 6
+    g = torch.Generator().manual_seed(77)
+    torch.manual_seed(78)
+    lin0 = torch.nn.Linear(2 * n_in + 1, H)
+    msg = [torch.nn.Linear(H, H) for _ in range(n_msg)]
+    crd = [torch.nn.Linear(H, H) for _ in range(n_crd)]
+    out = torch.nn.Linear(H, 1, bias=False)
+    w_scale, b_scale, in_scale = {"small_activations": (1.0, 0.03, 0.01), "tiny_activations": (1.0, 0.003, 0.001),
+                                  "small_weights": (0.05, 1.0, 1.0), "mixed_weights": (None, 1.0, 1.0)}[case]
+    mixed = [0.05, 3.0, 0.3, 300.0, 0.02, 2.0, 0.004, 40.0, 1.0]          # (gain 0.3 per unit: the product stays tame)
+    with torch.no_grad():
+        lin0.weight.mul_(in_scale)
+        lin0.bias.mul_(in_scale)
+        for k, layer in enumerate(msg + crd):
+            layer.weight.mul_(mixed[k] if w_scale is None else w_scale)
+            layer.bias.mul_(b_scale)
+    degree = torch.randint(1, 2 * deg, (n_nodes,), generator=g)
+    src = torch.repeat_interleave(torch.arange(n_nodes), degree)
+    E = int(src.numel())
+    edges = torch.stack([src, torch.randint(0, n_nodes, (E,), generator=g)], 1)
+    h = torch.randn(n_nodes, n_in, generator=g)
+    coord = torch.rand(n_nodes, D, generator=g) * 2 - 1
+    want_m, want_s = _chain_reference(lin0, msg, crd, out, n_in, h, coord, edges)
+    if case.endswith("activations"):      # the regime the case is about
+        assert float(want_m.abs().mean()) < (3e-3 if case == "small_activations" else 3e-4)
+    mods = [m.to(cuda) for m in [lin0] + msg + crd + [out]]
+    pack = kernels.EdgeChainPack(mods[0], mods[1:1 + n_msg], mods[1 + n_msg:-1], mods[-1], input_size=n_in, precision=precision)
+    w = mods[0].weight.detach()
+    proj = torch.nn.functional.linear(h.to(cuda), torch.cat([w[:, :n_in], w[:, n_in:2 * n_in]], 0)).contiguous()
+    status = torch.zeros(1, dtype=torch.int32, device=cuda)
+    got_m, got_s = kernels.egnn_edge_chain(pack, proj, coord.to(cuda).contiguous(), edges.to(cuda), status=status)
+    pieces, got_s2 = kernels.egnn_edge_chain(pack, proj, coord.to(cuda).contiguous(), edges.to(cuda), status=status, piece_sums=True)
+    offsets = (torch.cumsum(degree, 0) - degree).to(cuda)
+    got_sum = kernels.segment_combine(pieces, offsets, degree.to(cuda), False)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    want_sum = torch.zeros(n_nodes, H, dtype=torch.float64).index_add_(0, src, want_m.detach())
+    tol = TOLERANCE[precision]
+    errs = (_rel_l2(got_m, want_m), _rel_l2(got_s, want_s), _rel_l2(got_sum, want_sum))
+    print(f"{case} / {precision}: messages {errs[0]:.2e}, head {errs[1]:.2e}, node sums {errs[2]:.2e}")
+    assert max(errs) < tol, (case, precision, errs)
+    assert torch.equal(got_s, got_s2)
+
+
 def test_edge_chain_f16_range_is_reported(cuda):
     """Split-f16 mode: an activation beyond the f16 range sets MDX_STATUS_EGNN_F16_RANGE; binary32 mode does not care."""
     from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels

@@ -353,3 +353,51 @@ def test_c1_exact_configuration(oracle):
         comp = RS.AXL(A=g["corr_out_A"][k].astype(np.int64), X=g["corr_out_X"][k], L=lattice)
     assert replay.exhausted()
     assert worst < 1e-5, worst
+
+
+def _c3_batch(g):
+    import torch
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
+                                                                              NOISY_AXL_COMPOSITION, TIME)
+    return {NOISY_AXL_COMPOSITION: AXL(A=torch.from_numpy(g["A"]), X=torch.from_numpy(g["X"]), L=torch.from_numpy(g["L"])),
+            TIME: torch.from_numpy(g["time"]), NOISE: torch.from_numpy(g["noise"]),
+            CARTESIAN_FORCES: torch.zeros(g["X"].shape)}
+
+
+def test_c3_shape_network_against_reference_forward(oracle):
+    """The production-size EGNN (4 x 256 x 4, radial cutoff 7.5, N = 64) -- the shape BASELINE configs[2..4] benchmark --
+    as the product's torch module on the CPU (oracle edge list) against the REFERENCE's forward on the same formula
+    weights: scores within 1e-5 rel-L2 (north_star's tolerance), logits close, MASK logit -inf."""
+    import torch
+    g = load_golden("net_egnn_c3.npz")
+    net = nets.egnn_c3_net(1, edge_builder=nets.oracle_edge_builder)
+    with torch.no_grad():
+        out = net(_c3_batch(g), conditional=False)
+    assert torch.isinf(out.A[..., -1]).all() and (out.A[..., -1] < 0).all()
+    ref = g["out_X"].astype(np.float64)
+    assert np.linalg.norm(out.X.numpy() - ref) / np.linalg.norm(ref) < 1e-5
+    np.testing.assert_allclose(out.A.numpy()[..., :-1], g["out_A"][..., :-1], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out.L.numpy(), g["out_L"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["traj_egnn_c3_top", "traj_egnn_c3_bottom"])
+def test_c3_shape_trajectories(oracle, name):
+    """The oracle sampler on the reference's draws at BASELINE configs[2]'s settings (T = 1000 linear schedule, M = 2,
+    production EGNN): two indices from the top (1000 -> 998) and the last two (2 -> 0, index 0 = the corrector's sigma_min
+    special case): atom types exact, coordinates within 1e-5 at every step and at the end."""
+    g = load_golden(name + ".npz")
+    noise_kw, sampling_kw, netf = cases.C3_SHAPE
+    npar, spar = cases.as_objects(noise_kw, sampling_kw)
+    replay = RS.ReplayNoise(g)
+    gen = RS.OracleLangevinGenerator(npar, spar, netf(nets.oracle_edge_builder), noise=replay)
+    gen.record = True
+    start = RS.AXL(A=g["start_A"].copy(), X=g["start_X"].copy(), L=g["start_L"].copy())
+    out = gen.sample_from_noisy_composition(start, int(g["start_index"]), int(g["end_index"]))
+    assert replay.exhausted()
+    assert np.array_equal(out.A, g["final_A"])
+    assert torus_rel_l2(out.X, g["final_X"]) < 1e-5
+    preds = [r for r in gen.records if r[0] == "predictor"]
+    assert [r[1] for r in preds] == list(g["pred_index"])
+    for k, r in enumerate(preds):
+        assert np.array_equal(r[3].A, g["pred_composition_im1_A"][k])
+        assert torus_rel_l2(r[3].X, g["pred_composition_im1_X"][k]) < 1e-5
