@@ -81,6 +81,7 @@ struct ChainArgs {
     int64_t ld_in;              // row stride of rows_in and residual, in floats
     float* proj_out;            // MODE 3, nullable: [M][2H] = out W_p^T for the 2 H x H layers that follow the MLP in the image
     float* rows_out;            // [M][H]
+    void* stamp_buf;            // -DMDX_CHAIN_STAMPS builds only (else null): see MDX_STAMP_WRITE
 };
 
 constexpr float kLog2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f;
@@ -163,11 +164,18 @@ template <int H>
 __device__ __forceinline__ void put_pair(Act<H, 1>& a, int t, int r, float y0, float y1)
 {
     uint32_t hi, lo;
-    float l0, l1;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(y0), "v"(y1));
+#ifdef MDX_CHAIN_MIXLO
+    // lo = f16(y - hi), each half written by one instruction: the difference is formed exactly (f16 operand x -1 + f32 operand)
+    // and rounded to f16 once -- the same value as rounding the exact binary32 difference -- three instructions per pair
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(y0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(y1));
+#else
+    float l0, l1;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(y0));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(y1));
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(l0), "v"(l1));
+#endif
     const int s = 2 * t + (r >> 3), j = (r & 7) >> 1;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 vh = __builtin_bit_cast(u32x4, a.hi[s]), vl = __builtin_bit_cast(u32x4, a.lo[s]);
@@ -181,26 +189,27 @@ __device__ __forceinline__ void put_pair(Act<H, 1>& a, int t, int r, float y0, f
 // marked points into the buffer passed as `status` (uint64 [4096]); tools/chain_bench.py --stamps prints the intervals.
 // -DMDX_CHAIN_STAMPS=2: only the two ends of the kernel, with s_memtime (shader clock) AND s_memrealtime (100 MHz): the
 // clock the chip held during the launch (tools/chain_bench.py --clocks).
+// The stamp list is the caller's buffer (uint64 [4096], passed where the status word goes): entries [0, 4000), the entry
+// count in element 4095 (zeroed on the launch stream by the entry point).  `stamp_buf_` must be in scope: the kernel's
+// copy of ChainArgs::stamp_buf, or Chain's member.  (No __device__ globals, no host-side symbol copies: the first version
+// set two globals with hipMemcpyToSymbolAsync from stack variables -- read by the copy after the entry point had
+// returned; those builds died at process exit.)
 #ifdef MDX_CHAIN_STAMPS
-#define MDX_STAMP_ALWAYS(id)                                                                                       \
+#define MDX_STAMP_WRITE(id, clock)                                                                                 \
     do {                                                                                                           \
-        if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 4000) {                                               \
-            ((unsigned long long*)stamp_buf)[stamp_n++] = ((unsigned long long)(id) << 48) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffull); \
+        unsigned long long* sb_ = (unsigned long long*)stamp_buf_;                                                 \
+        if (sb_ && blockIdx.x == 0 && threadIdx.x == 0 && sb_[4095] < 4000) {                                      \
+            sb_[sb_[4095]] = ((unsigned long long)(id) << 48) | ((clock) & 0xffffffffffffull);                     \
+            sb_[4095] += 1;                                                                                        \
         }                                                                                                          \
     } while (0)
-#define MDX_STAMP_REALTIME(id)                                                                                     \
-    do {                                                                                                           \
-        if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 4000) {                                               \
-            ((unsigned long long*)stamp_buf)[stamp_n++] = ((unsigned long long)(id) << 48) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffffffull); \
-        }                                                                                                          \
-    } while (0)
+#define MDX_STAMP_ALWAYS(id) MDX_STAMP_WRITE(id, __builtin_amdgcn_s_memtime())
+#define MDX_STAMP_REALTIME(id) MDX_STAMP_WRITE(id, __builtin_amdgcn_s_memrealtime())
 #if MDX_CHAIN_STAMPS >= 2
 #define MDX_STAMP(id)
 #else
 #define MDX_STAMP(id) MDX_STAMP_ALWAYS(id)
 #endif
-__device__ void* stamp_buf;
-__device__ int stamp_n;
 #else
 #define MDX_STAMP(id)
 #define MDX_STAMP_ALWAYS(id)
@@ -237,12 +246,24 @@ struct Chain {
 #ifdef MDX_CHAIN_VERIFY
     uint32_t* verify_status = nullptr;
 #endif
+#ifdef MDX_CHAIN_STAMPS
+    void* stamp_buf_ = nullptr;
+#endif
     uint32_t issue_src;     // byte offset of (chunk, share) in the image   (SGPR; the image is a few megabytes)
     uint32_t issue_dst;     // LDS byte address of slot + share           (SGPR)
 #if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
     unsigned long long dma_cycles = 0, dma_count = 0;
 #endif
 
+    // A request is ordered against the compiler's own memory instructions ("memory"): the counted vmcnt waits of acquire_next
+    // assume the message / piece-row stores and the requests are issued in program order.  (m0 is written and read inside
+    // one statement: the compiler reserves it and keeps nothing in it across statements; naming it as a clobber only draws
+    // "clobber list contains reserved registers".)  -DMDX_CHAIN_NO_REQUEST_CLOBBER: the round-2 form, for timing.
+#ifdef MDX_CHAIN_NO_REQUEST_CLOBBER
+#define MDX_REQUEST_CLOBBER
+#else
+#define MDX_REQUEST_CLOBBER : "memory"
+#endif
     __device__ __forceinline__ void issue_piece(int i)
     {
 #if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 4))
@@ -280,15 +301,15 @@ struct Chain {
             // it enforces for its own instructions only.)
             if constexpr (GUARD)
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane16), "s"(src), "s"(dst),
-                             "n"((i & 3) * 1024));
+                             "n"((i & 3) * 1024) MDX_REQUEST_CLOBBER);
             else
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane16), "s"(src), "s"(dst),
-                             "n"((i & 3) * 1024));
+                             "n"((i & 3) * 1024) MDX_REQUEST_CLOBBER);
         } else {
             // (the burst form of the exact-f32 chain: the per-lane address as a vector-register pair -- with eight scalar-base
             // requests in a row the row-chain instantiation at H = 256 spills 3.6 KB per lane)
             const uint64_t lane_src = src + lane16;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" ::"v"(lane_src), "s"(dst), "n"((i & 3) * 1024));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" ::"v"(lane_src), "s"(dst), "n"((i & 3) * 1024) MDX_REQUEST_CLOBBER);
         }
 #endif
 #if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
@@ -459,6 +480,43 @@ __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const 
     }
 }
 
+// The same epilogue as a three-stage software pipeline over the k-steps of the tile beside which it runs (split-f16, H = 256:
+// 16 k-steps, 8 pairs of values).  Pair j enters at step kPairStart[j]:
+//   stage A (that step)   A from the accumulator, t = -z, e = 2^t          2 (moves) + 2 + 2 instructions
+//   stage B (the next)    y = A / (k + k e)                                2 + 2 + 2
+//   stage C (the one after) split y into f16 halves -> operand registers   3 (4)
+// so every step carries about ten vector instructions beside its three MFMAs, instead of none beside the first half of the
+// tile's MFMAs and twenty beside each step of the second half -- which is what the scheduler makes of the plain form
+// (tools/tile_stats.py) -- and no step waits on a chain of nine dependent instructions.  The last pair is complete at the
+// end of step 14: the tile that follows a layer's last tile reads these values as its k-steps 14 and 15.
+constexpr int kPairStart[8] = {0, 1, 3, 5, 6, 8, 10, 12};
+template <int H>
+struct EpiloguePipe {
+    float a[8][2], e[8][2];
+    template <int PREC>
+    __device__ __forceinline__ void step(int s, int tp, const f32x16& pend, Act<H, PREC>& dst, const Scale& sc, bool linear)
+    {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (s == kPairStart[j]) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[j][i] = pend[2 * j + i];
+                    e[j][i] = __builtin_amdgcn_exp2f(a[j][i] * sc.neg_c);
+                }
+            } else if (s == kPairStart[j] + 1) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float y = a[j][i] * __builtin_amdgcn_rcpf(__builtin_fmaf(e[j][i], sc.k, sc.k));
+                    e[j][i] = linear ? a[j][i] * sc.inv_a : y;
+                }
+            } else if (s == kPairStart[j] + 2) {
+                put_pair<H>(dst, tp, 2 * j, e[j][0], e[j][1]);
+            }
+        }
+    }
+};
+
 // One step of the segmented scan over a DPP row of 16 lanes: x[r] += (the value D lanes down the row; 0 beyond the row's
 // first lane) * gate, gate = 1.0 where that lane belongs to this lane's piece, else 0.0.
 template <int D>
@@ -514,9 +572,15 @@ template <int H, int PREC, int MODE>
 __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(ChainArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    // (GUARD: see issue_piece.  The piece-sums instantiations have no scalar-register spills -- checked in the build's
-    // resource listing -- and skip the three wait states: 1 % of the launch.)
+    // (GUARD: see issue_piece.  The piece-sums instantiations skip the three extra wait states in front of their requests --
+    // 2.2 % of the launch, A/B in profiles/r03_chain_ablation.md -- which is safe only while they restore no scalar register
+    // from a vector register: the BUILD checks that (csrc/Makefile feeds the compiler's resource remarks of this unit to
+    // check_chain_resources.py and fails on a scalar-register spill in any <H, PREC, 2> kernel).  -DMDX_CHAIN_GUARD_ALL: all guarded.)
+#ifdef MDX_CHAIN_GUARD_ALL
+    using C = Chain<H, PREC, true>;
+#else
     using C = Chain<H, PREC, MODE != 2>;
+#endif
     // MODE 3 = MODE 1 whose first layer is 2 H -> H: the rows are [h | agg]; chain "layers" 0 and 1 are the two H x H halves of
     // that layer's weight.  Pass A multiplies h by the first half and PARKS the raw accumulators (bias included) in the
     // registers of the other operand set; pass B reloads the operand registers with agg, starts every tile from its parked
@@ -590,6 +654,9 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     }
     __syncthreads();
 
+#ifdef MDX_CHAIN_STAMPS
+    void* stamp_buf_ = p.stamp_buf;
+#endif
     MDX_STAMP_ALWAYS(20);
     MDX_STAMP_REALTIME(21);
     C ch;
@@ -601,6 +668,9 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     ch.lane16 = (uint32_t)lane * 16u;
 #ifdef MDX_CHAIN_VERIFY
     ch.verify_status = p.status;
+#endif
+#ifdef MDX_CHAIN_STAMPS
+    ch.stamp_buf_ = p.stamp_buf;
 #endif
 
     // Weight fragments of a k-step, and the state that flows from one tile to the next: the LDS address of the tile's
@@ -736,6 +806,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                             const Scale& epi_sc, bool linear = false) -> f32x16 {
             MDX_STAMP(4);
             f32x16 acc = acc_next;
+#ifndef MDX_CHAIN_NO_STAGED      // (-DMDX_CHAIN_NO_STAGED: the plain per-step epilogue everywhere, for A/B timing)
+            constexpr bool STAGED = PREC == 1 && kScaled && STEPS == 16;
+#else
+            constexpr bool STAGED = false;
+#endif
+            EpiloguePipe<H> pipe;
             Frag fr[STEPS + PFD];
 #pragma unroll
             for (int s = 0; s < PFD; ++s) fr[s] = pre[s];
@@ -751,7 +827,11 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #endif
                 if (s == STEPS - 1) acc_next = read_bias(next_bias);
 #if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 16))
-                if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, epi_sc, ROWS && linear);
+                if constexpr (STAGED) {
+                    if (have) pipe.template step<PREC>(s, tp, pend, epi_dst, epi_sc, ROWS && linear);
+                } else {
+                    if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, epi_sc, ROWS && linear);
+                }
 #else
                 if (have && s == 0) asm volatile("" ::"v"(pend));      // keep the MFMAs alive without their epilogue
 #endif
@@ -768,21 +848,43 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].hi, in.hi[s], acc, 0, 0, 0);
                     if (C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].hi, in.lo[s], acc, 0, 0, 0);
+#ifdef MDX_CHAIN_DUMMY_VALU      // (calibration experiment: what one more independent vector instruction per k-step costs)
+                    { float dummy_; asm volatile("v_mov_b32 %0, 0" : "=v"(dummy_)); }
+#endif
+#ifdef MDX_CHAIN_DUMMY_SNOP      // (the same for an instruction that only takes an issue slot)
+                    asm volatile("s_nop 0");
+#endif
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].lo, in.hi[s], acc, 0, 0, 0);
                 }
 #ifdef MDX_CHAIN_PIN_STEPS
                 __builtin_amdgcn_sched_barrier(0);      // keep each k-step's share of vector work beside ITS MFMAs
+#else
+                if constexpr (STAGED) __builtin_amdgcn_sched_barrier(0);
 #endif
             }
 #pragma unroll
             for (int s = 0; s < PFD; ++s) pre[s] = fr[STEPS + s];
             w_cur = w_next;
+#ifdef MDX_CHAIN_GROUPS
+            // The interleave of the tile's scheduling region, stated: per MFMA, MDX_CHAIN_GROUPS vector instructions (and a
+            // fragment read behind two MFMAs of three).  Left to itself the scheduler issues the first half of a tile's
+            // MFMAs bare and packs the whole epilogue beside the second half, which is then bound by vector issue.
+            if constexpr (PREC == 1) {
+#pragma unroll
+                for (int i = 0; i < 3 * STEPS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, MDX_CHAIN_GROUPS, 0);
+                    if (i % 3 != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+#endif
 #ifndef MDX_CHAIN_NO_TILE_PIN
             // keep every tile's share of vector work beside ITS MFMAs: left free, the scheduler sinks the epilogues of the
             // first tiles of a layer into its last ones (their results are not needed before the next layer), which then
             // carry twice the vector work and are bound by instruction issue
             __builtin_amdgcn_sched_barrier(0);
 #endif
+            asm volatile("; MDX_TILE_END" ::);          // (a comment in the assembly: what tools/tile_stats.py cuts the listing at)
             return acc;
         };
         // One layer: tiles t = 0 .. NT-1.  The epilogue beside tile t is that of the tile before it: tile t-1 of this layer
@@ -1078,10 +1180,8 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     MDX_STAMP_ALWAYS(22);
     MDX_STAMP_REALTIME(23);
 #if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ((unsigned long long*)stamp_buf)[stamp_n++] = (24ull << 48) | (ch.dma_cycles & 0xffffffffffffull);
-        ((unsigned long long*)stamp_buf)[stamp_n++] = (25ull << 48) | (ch.dma_count & 0xffffffffffffull);
-    }
+    MDX_STAMP_WRITE(24, ch.dma_cycles);
+    MDX_STAMP_WRITE(25, ch.dma_count);
 #endif
     if constexpr (PREC == 1) {
         if (p.status && out_of_range) atomicOr(p.status, MDX_STATUS_EGNN_F16_RANGE);
@@ -1317,12 +1417,10 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
     a.messages = messages_out; a.edge_scalar = edge_scalar_out; a.status = status;
     a.piece_sums = c->message_mode == MDX_EGNN_MESSAGES_PIECE_SUMS;
 #ifdef MDX_CHAIN_STAMPS
-    {
-        int zero = 0;
-        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(stamp_buf), &status, sizeof(void*), 0, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream));
-        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(stamp_n), &zero, sizeof(int), 0, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream));
-        a.status = nullptr;
-    }
+    // (diagnostic builds: `status` is the caller's stamp list, uint64 [4096]; its entry count restarts with every launch)
+    if (status && hipMemsetAsync((char*)status + 4095 * 8, 0, 8, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return MDX_ERR_HIP;
+    a.stamp_buf = status;
+    a.status = nullptr;
 #endif
     const int layers = a.n_message + a.n_coord;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -26,7 +26,7 @@ from ..namespace import AXL, CARTESIAN_FORCES, NOISE, NOISY_AXL_COMPOSITION, TIM
 from ..noise_schedulers.noise_parameters import NoiseParameters
 from ..noise_schedulers.noise_scheduler import NoiseScheduler
 from ..utils.sample_trajectory import PinnedStaging, SampleTrajectory
-from .noise_sources import DevicePhiloxNoise, ReferenceOrderNoise
+from .noise_sources import DevicePhiloxNoise, RecordingNoise, ReferenceOrderNoise
 from .predictor_corrector_axl_generator import PredictorCorrectorAXLGenerator, PredictorCorrectorSamplingParameters
 from .trajectory_initializer import TrajectoryInitializer
 
@@ -72,6 +72,9 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         self._seed = getattr(sp, "seed", None)
         self._call_counter = 0
         self.noise_source = ReferenceOrderNoise() if rng_mode == "reference" else None
+        # calls recomputed with the exact-f32 MFMA kernels because the split-f16 ones met a value beyond the f16 range
+        # (_guarded); logged by sample_diffusion, printed by bench.py
+        self.f16_range_fallbacks = 0
         self.resampling_steps = 0     # set by ConstrainedLangevinGenerator (repaint_resampling_steps)
         self._visit = 0               # which of the 1 + resampling_steps passes through the current time index
 
@@ -286,10 +289,74 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
 
     def sample_from_noisy_composition(self, starting_noisy_composition: AXL, starting_step_index: int,
                                       ending_step_index: int) -> AXL:
+        """The entry point both sample() and callers with their own starting composition go through; ends with the call's one
+        host read of the status words (the reference's asserts; the score network's f16-range report)."""
         self._check_index_range(starting_step_index, ending_step_index)
         self._prepare(starting_noisy_composition.X.device)
         if self.noise_source is None:
             self._begin_call(starting_noisy_composition.X.device)
+        return self._guarded(lambda: self._run_loop(starting_noisy_composition, starting_step_index, ending_step_index))
+
+    def _guarded(self, run):
+        """run() + check_status(); if the score network's split-f16 MFMA kernels report a value beyond the f16 range, THIS
+        call -- and nothing else -- is recomputed with the exact-f32 kernels on the same draws: the network's precision is
+        put back afterwards, what the discarded attempt recorded is dropped, the event is counted in
+        `f16_range_fallbacks` and warned about.  Device RNG: a draw is a function of (seed, call, index), the same call
+        index gives the same numbers.  Reference-order RNG: the call's draws are kept while it runs and handed out again."""
+        from .._hip import EdgeChainRangeError
+        net = self.axl_network
+        switchable = getattr(net, "edge_chain_precision", None) == "f16x3"
+        source = self.noise_source
+        keeps = switchable and not getattr(source, "device_rng", False)
+        if keeps:
+            self.noise_source = RecordingNoise(source)
+            self._share_noise_source()
+        marks = self._recorder_marks() if self.record else None
+        try:
+            try:
+                out = run()
+                self.check_status()
+                return out
+            except EdgeChainRangeError:
+                if not switchable:
+                    raise
+                import warnings
+                self.f16_range_fallbacks += 1
+                warnings.warn("EGNN edge chain: a value beyond the f16 range; this call is recomputed with "
+                              "edge_chain_precision='f32' (the network's setting is restored afterwards)")
+                if marks is not None:
+                    self._recorder_truncate(marks)
+                self._buffers.pop("graph_loop", None)
+                if keeps:
+                    self.noise_source = self.noise_source.replay()
+                    self._share_noise_source()
+                net.edge_chain_precision = "f32"
+                try:
+                    out = run()
+                    self.check_status()
+                finally:
+                    net.edge_chain_precision = "f16x3"
+                return out
+        finally:
+            if keeps:
+                self.noise_source = source
+                self._share_noise_source()
+
+    def _share_noise_source(self):
+        if hasattr(self.trajectory_initializer, "noise_source"):
+            self.trajectory_initializer.noise_source = self.noise_source
+
+    def _recorder_marks(self):
+        data = self.sample_trajectory_recorder._internal_data
+        return {key: len(data[key]) for key in ("predictor_step", "corrector_step", "atom_type_update") if key in data}
+
+    def _recorder_truncate(self, marks):
+        data = self.sample_trajectory_recorder._internal_data
+        for key in ("predictor_step", "corrector_step", "atom_type_update"):
+            if key in data:
+                del data[key][marks.get(key, 0):]
+
+    def _run_loop(self, starting_noisy_composition: AXL, starting_step_index: int, ending_step_index: int) -> AXL:
         if self.fused_score_network:
             return self._sample_fused(starting_noisy_composition, starting_step_index, ending_step_index)
         if self.use_hip_graph and getattr(self.noise_source, "device_rng", False) and not self.record:
@@ -379,26 +446,9 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
                 net_status.zero_()
 
     def sample(self, number_of_samples: int, device: torch.device) -> AXL:
-        from .._hip import EdgeChainRangeError
         self._prepare(device)
         self._begin_call(torch.device(device))
-        try:
-            composition = super().sample(number_of_samples, device)
-            self.check_status()
-        except EdgeChainRangeError:
-            # The score network's split-f16 edge chain met a value beyond the f16 range: recompute this call with the exact
-            # binary32 MFMA kernel (device RNG: the same call index gives the same draws; reference-order RNG cannot be
-            # rewound, so there the error stands).
-            if self.rng_mode != "device" or not hasattr(self.axl_network, "edge_chain_precision"):
-                raise
-            import warnings
-            warnings.warn("EGNN edge chain: value beyond the f16 range; recomputing the call with edge_chain_precision='f32'")
-            self.axl_network.edge_chain_precision = "f32"
-            self._buffers.pop("graph_loop", None)
-            self._call_counter -= 1
-            self._begin_call(torch.device(device))
-            composition = super().sample(number_of_samples, device)
-            self.check_status()
+        composition = super().sample(number_of_samples, device)      # -> sample_from_noisy_composition (status read there)
         if self.rng_mode == "device":
             self.noise_source = None
         return composition

@@ -42,3 +42,46 @@ class DevicePhiloxNoise:
 
     def initial_lattice(self, b, nl, device):
         return kernels.rng_fill(kernels.RNG_NORMAL, self.seed, self.call, 0, TAG_INIT_LATTICE, b, nl, device)
+
+
+class RecordingNoise(ReferenceOrderNoise):
+    """Reference-order draws passed through and KEPT, so that a call which has to be recomputed (the score network's
+    split-f16 kernels met a value beyond the f16 range: LangevinGenerator._guarded) sees the very same numbers again:
+    a CPU generator cannot be rewound, a list can.  replay() returns a source that hands the kept draws out again, in
+    order, and continues with `inner` once they are used up."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.kept = []
+
+    def rand(self, *shape):
+        out = self.inner.rand(*shape)
+        self.kept.append(("rand", out))
+        return out
+
+    def randn(self, *shape):
+        out = self.inner.randn(*shape)
+        self.kept.append(("randn", out))
+        return out
+
+    def replay(self):
+        return _ReplayNoise(self.kept, self.inner)
+
+
+class _ReplayNoise(ReferenceOrderNoise):
+    def __init__(self, kept, inner):
+        self.kept, self.inner, self.position = kept, inner, 0
+
+    def _next(self, kind, shape):
+        if self.position < len(self.kept):
+            want, out = self.kept[self.position]
+            self.position += 1
+            assert want == kind, "the recomputed call draws in a different order"
+            return out
+        return getattr(self.inner, kind)(*shape)
+
+    def rand(self, *shape):
+        return self._next("rand", shape)
+
+    def randn(self, *shape):
+        return self._next("randn", shape)

@@ -116,6 +116,8 @@ class E_GCL(nn.Module):
         state = dict(self.__dict__)
         state["_chain"], state["_node_chain"], state["status_word"] = (None, None), (None, None), None
         state["_node_mlp"] = (None, None)
+        state.pop("_chain_kept", None)
+        state.pop("_node_mlp_kept", None)
         return state
 
     def _messages(self, h: torch.Tensor, edge_index: torch.Tensor, radial: torch.Tensor, fused: bool) -> torch.Tensor:
@@ -170,8 +172,12 @@ class E_GCL(nn.Module):
         stamp = (self.edge_chain_precision,) + tuple((t.data_ptr(), t._version) for lin in linears
                                                       for t in (lin.weight, lin.bias) if t is not None)
         if self._chain[0] != stamp:
-            self._chain = (stamp, kernels.EdgeChainPack(*modules, input_size=self.input_size,
-                                                        precision=self.edge_chain_precision))
+            # (one image per precision is kept: the generator's one-call switch to "f32" and back repacks nothing)
+            kept = self.__dict__.setdefault("_chain_kept", {})
+            if kept.get(self.edge_chain_precision, (None, None))[0] != stamp:
+                kept[self.edge_chain_precision] = (stamp, kernels.EdgeChainPack(*modules, input_size=self.input_size,
+                                                                                precision=self.edge_chain_precision))
+            self._chain = kept[self.edge_chain_precision]
         return self._chain[1]
 
     def _node_chain_pack(self):
@@ -217,7 +223,11 @@ class E_GCL(nn.Module):
         stamp = (self.edge_chain_precision,) + tuple((t.data_ptr(), t._version) for lin in linears for t in (lin.weight, lin.bias)) + \
             ((first_next.data_ptr(), first_next._version) if first_next is not None else (None,))
         if self._node_mlp[0] != stamp:
-            self._node_mlp = (stamp, kernels.NodeMlpPack(linears, self.edge_chain_precision, next_projection=projection))
+            kept = self.__dict__.setdefault("_node_mlp_kept", {})
+            if kept.get(self.edge_chain_precision, (None, None))[0] != stamp:
+                kept[self.edge_chain_precision] = (stamp, kernels.NodeMlpPack(linears, self.edge_chain_precision,
+                                                                              next_projection=projection))
+            self._node_mlp = kept[self.edge_chain_precision]
         return self._node_mlp[1]
 
     def _coord_head_is_plain(self) -> bool:

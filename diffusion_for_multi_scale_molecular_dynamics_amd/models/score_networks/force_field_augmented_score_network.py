@@ -32,6 +32,21 @@ class ForceFieldAugmentedScoreNetwork(torch.nn.Module):
         self._score_network = score_network
         self._force_field_parameters = force_field_parameters
 
+    # what the generators look for on a score network, passed through to the wrapped one (build-only attributes: the status
+    # word of its HIP kernels and the arithmetic of its fused MFMA kernels)
+    @property
+    def graph_status(self):
+        return getattr(self._score_network, "graph_status", None)
+
+    @property
+    def edge_chain_precision(self):
+        return getattr(self._score_network, "edge_chain_precision", None)
+
+    @edge_chain_precision.setter
+    def edge_chain_precision(self, value):
+        if hasattr(self._score_network, "edge_chain_precision"):
+            self._score_network.edge_chain_precision = value
+
     def forward(self, batch: Dict[AnyStr, torch.Tensor], conditional: Optional[bool] = None) -> AXL:
         raw = self._score_network(batch, conditional)
         return AXL(A=raw.A, X=raw.X + self.get_relative_coordinates_pseudo_force(batch), L=raw.L)

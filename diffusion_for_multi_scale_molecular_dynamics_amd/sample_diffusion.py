@@ -128,6 +128,11 @@ def create_samples_and_write_to_disk(generator, sampling_parameters, device, out
         samples_batch = create_batch_of_samples_sharded(generator=generator, sampling_parameters=sampling_parameters,
                                                         device=device)
     logger.info("Done Generating Samples.")
+    fallbacks = getattr(generator, "f16_range_fallbacks", 0)
+    if fallbacks:
+        logger.warning("%d sampling call(s) were recomputed with the exact-f32 MFMA kernels: the split-f16 edge chain met "
+                       "values beyond the f16 range (set edge_chain_precision='f32' on the network to avoid the retries)",
+                       fallbacks)
     if rank != 0:
         return
     output_directory = Path(output_path)

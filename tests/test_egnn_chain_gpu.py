@@ -178,6 +178,47 @@ def test_edge_chain_f16_range_is_reported(cuda):
         assert int(status.item()) == want
 
 
+@pytest.mark.parametrize("H", [64, 256])
+def test_weight_stream_addresses_verified(cuda, H):
+    """Regression guard for the round-2 device fault (a weight-stream request issued with a stale scalar base read unmapped
+    memory): csrc/libmdx_hip_verify.so is the same library with the edge chain compiled -DMDX_CHAIN_VERIFY -- every request
+    of every wavefront compares the global and LDS addresses it is about to use with the plain formula and reports a
+    mismatch in bits 30 / 31 of the status word.  The split-f16 chain (rows and piece-sums instantiations, several tiles per
+    workgroup, a ragged tail) runs once through it: no bit set, and the same outputs, bit for bit, as the shipped library."""
+    import os
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
+    verify_path = os.path.join(os.path.dirname(_hip.LIB_PATH), "libmdx_hip_verify.so")
+    assert os.path.exists(verify_path), "build it with `make -C csrc verify` (part of `make all` and of __graft_entry__.build())"
+    shipped_path, shipped = _hip.LIB_PATH, _hip.lib()
+    n_msg, n_crd, n_in, D, n_nodes = 2, 3, 16, 6, 3000
+    g = torch.Generator().manual_seed(H)
+    torch.manual_seed(H + 1)
+    mods = [m.to(cuda) for m in [torch.nn.Linear(2 * n_in + 1, H)] + [torch.nn.Linear(H, H) for _ in range(n_msg + n_crd)] +
+            [torch.nn.Linear(H, 1, bias=False)]]
+    degree = torch.randint(0, 40, (n_nodes,), generator=g)
+    src = torch.repeat_interleave(torch.arange(n_nodes), degree)
+    edges = torch.stack([src, torch.randint(0, n_nodes, (src.numel(),), generator=g)], 1).to(cuda)
+    proj = torch.randn(n_nodes, 2 * H, generator=g).to(cuda)
+    coord = torch.rand(n_nodes, D, generator=g).to(cuda)
+    outs = {}
+    try:
+        for name, path in (("shipped", shipped_path), ("verify", verify_path)):
+            _hip._lib, _hip.LIB_PATH = (shipped, path) if name == "shipped" else (None, path)
+            _hip.lib()
+            pack = kernels.EdgeChainPack(mods[0], mods[1:1 + n_msg], mods[1 + n_msg:-1], mods[-1], input_size=n_in, precision="f16x3")
+            status = torch.zeros(1, dtype=torch.int32, device=cuda)
+            rows = kernels.egnn_edge_chain(pack, proj, coord, edges, status=status, piece_sums=False)
+            pieces = kernels.egnn_edge_chain(pack, proj, coord, edges, status=status, piece_sums=True)
+            torch.cuda.synchronize()
+            word = int(status.item()) & 0xFFFFFFFF
+            assert word == 0, f"{name}: status {word:#x} (bit 30: source address, bit 31: LDS address of a request)"
+            outs[name] = (rows[0], rows[1], pieces[1])
+    finally:
+        _hip._lib, _hip.LIB_PATH = shipped, shipped_path
+    for a, b in zip(outs["shipped"], outs["verify"]):
+        assert torch.equal(a, b)
+
+
 def test_coord_aggregate_against_torch(cuda):
     from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
     g = torch.Generator().manual_seed(5)
@@ -345,41 +386,63 @@ def test_egnn_sampler_graph_replay_equals_eager(cuda, precision):
     assert (outs["eager"][0] != 1).all()
 
 
-def test_sampler_recomputes_in_f32_when_the_f16_range_is_left(cuda):
-    """A network whose activations leave the f16 range: the split-f16 chain reports it, LangevinGenerator.sample recomputes
-    the call with the exact binary32 kernel (same Philox call index => same draws) and warns; the result equals a run that
-    used 'f32' from the start."""
+@pytest.mark.parametrize("rng_mode", ["device", "reference"])
+def test_sampler_recomputes_in_f32_when_the_f16_range_is_left(cuda, rng_mode):
+    """A network whose activations leave the f16 range: the split-f16 kernels report it and THAT sample() call is recomputed
+    with the exact-f32 kernels on the same draws (device RNG: same Philox call index; reference-order RNG: the call's draws
+    are kept and handed out again), with a warning and a count -- the result equals a run that used 'f32' from the start.
+    The switch is local: the network's setting is 'f16x3' again afterwards, a recorded trajectory holds the recomputed
+    steps only, and the next call -- whose activations stay in range -- runs the split-f16 kernels with no retry."""
     from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
     from diffusion_for_multi_scale_molecular_dynamics_amd.generators.predictor_corrector_axl_generator import \
         PredictorCorrectorSamplingParameters
     from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters
     import cases
     import warnings
-    outs = {}
+    T, B = 3, 6
+    outs, gens = {}, {}
     for mode in ("f16x3", "f32"):
         torch.manual_seed(21)
         net = nets.egnn_net(1, "radial_cutoff", 7.5, hidden=32, n_layers=2, n_hidden=2).to(cuda)
+        first_bias = net.egnn.graph_layers[0].message_mlp[0].bias
+        normal_bias = first_bias.detach().clone()
         with torch.no_grad():
-            net.egnn.graph_layers[0].message_mlp[0].bias.fill_(7.0e4)          # SiLU(7e4) = 7e4 > 65504
+            first_bias.fill_(7.0e4)                                            # SiLU(7e4) = 7e4: beyond the carried f16 range
             for lin in net.egnn.graph_layers[0].message_mlp[2::2]:
                 lin.weight.mul_(1e-4)                                          # keep everything downstream finite in f32
         net.edge_chain_precision = mode
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            npar = NoiseParameters(**cases.noise_ns(3, **cases.LIN))
+            npar = NoiseParameters(**cases.noise_ns(T, **cases.LIN))
             spar = PredictorCorrectorSamplingParameters(**cases.sampling_ns(64, 1, M=1, greedy=False, one=False,
-                                                                            cell=[10.86] * 3), rng_mode="device", seed=5)
-        gen = LangevinGenerator(npar, spar, net)
+                                                                            cell=[10.86] * 3), rng_mode=rng_mode, seed=5,
+                                                        record_samples=True)
+        gen = gens[mode] = LangevinGenerator(npar, spar, net)
+        torch.manual_seed(99)                                                  # (the reference-order draws)
         with torch.no_grad():
             if mode == "f16x3":
                 with pytest.warns(UserWarning, match="f16 range"):
-                    out = gen.sample(6, cuda)
-                assert net.edge_chain_precision == "f32"
+                    first = gen.sample(B, cuda)
+                assert net.edge_chain_precision == "f16x3" and gen.f16_range_fallbacks == 1
             else:
-                out = gen.sample(6, cuda)
-        outs[mode] = out
-    assert torch.equal(outs["f16x3"].A, outs["f32"].A) and torch.equal(outs["f16x3"].X, outs["f32"].X)
-    assert torch.isfinite(outs["f32"].X).all()
+                first = gen.sample(B, cuda)
+                assert gen.f16_range_fallbacks == 0
+            # the discarded attempt left nothing in the recorder: T predictor steps, not 2 T
+            assert len(gen.sample_trajectory_recorder._internal_data["predictor_step"]) == T
+            # second call, activations in range: no retry, split-f16 kernels
+            first_bias.copy_(normal_bias)
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                second = gen.sample(B, cuda)
+        outs[mode] = (first, second)
+        assert gen.f16_range_fallbacks == (1 if mode == "f16x3" else 0) and net.edge_chain_precision == mode
+        assert all(layer._chain[1].precision == mode for layer in net.egnn.graph_layers)      # what the last forward ran
+    assert torch.equal(outs["f16x3"][0].A, outs["f32"][0].A) and torch.equal(outs["f16x3"][0].X, outs["f32"][0].X)
+    assert torch.isfinite(outs["f32"][0].X).all()
+    # the second calls ran different arithmetic on the same draws: equal atom types, coordinates within the tolerance
+    assert torch.equal(outs["f16x3"][1].A, outs["f32"][1].A)
+    diff = (outs["f16x3"][1].X - outs["f32"][1].X + 0.5) % 1.0 - 0.5
+    assert float(diff.norm() / outs["f32"][1].X.norm()) < 1e-5
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
