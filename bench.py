@@ -211,9 +211,15 @@ def time_launches(launch, device, launches):
         launch()
     torch.cuda.synchronize(device)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):           # (torch collects garbage on entry; nothing of ours frees device objects in a finaliser)
-        for _ in range(launches):
-            launch()
+    import gc
+    gc.collect()                            # (torch >= 2.9 no longer does this on entry; no finaliser may call HIP in a capture)
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            for _ in range(launches):
+                launch()
+    finally:
+        gc.enable()
     graph.replay()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)

@@ -71,8 +71,8 @@ struct ChainArgs {
     const int64_t* n_edges_dev; // nullable: device-resident edge count (<= n_edges)
     int64_t n_edges;
     int n_message, n_coord, D;
-    int piece_sums;             // MODE 0: messages_out receives per-node PIECE SUMS instead of the messages (see aggregate_pieces)
-    float* messages;            // [E][H]
+    int piece_sums;             // the caller asked for MODE 2: `messages` receives per-node PIECE SUMS (see aggregate_pieces)
+    float* messages;            // [E][H]; piece sums: [ceil(E / 16) + n_nodes][H]
     float* edge_scalar;         // [E]
     uint32_t* status;
     // MODE 1 (a chain of H -> H layers over the ROWS of a matrix, last layer linear, optional residual): n_edges rows
@@ -963,7 +963,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 gate[k] = (c16 >= d && seg_src[c16 >= d ? col - d : col] == my_src) ? 1.0f : 0.0f;
             }
             const bool ends = col < n_live && (c16 == 15 || col + 1 >= n_live || seg_src[col + 1 < 32 ? col + 1 : col] != my_src);
-            float* row = p.messages + (wave_base + col) * H + 4 * h;
+            // Compact piece rows (no [E, H] buffer): a piece that ends on a 16-edge boundary goes to row e / 16; any other piece
+            // end is the LAST edge of its node (the next edge has another source, and it is inside this wavefront's 32 edges
+            // because its position is not 15 mod 16) and goes to the node's own row behind the ceil(capacity / 16) boundary rows.
+            const int64_t e_mine = wave_base + col;
+            const int64_t piece_row = c16 == 15 ? (e_mine >> 4) : ((p.n_edges + 15) >> 4) + (int64_t)my_src;
+            float* row = p.messages + piece_row * H + 4 * h;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 float x[16];                                // features 32 t + 8 g + 4 h + i of this lane's edge, x[4 g + i]
@@ -1297,13 +1302,15 @@ __global__ __launch_bounds__(256) void egnn_coord_aggregate_kernel(const float* 
     }
 }
 
-// out[i,:] = (1/degree_i if mean) x sum of node i's pieces: rows e with e in [offset_i, offset_i + degree_i) and
-// (e % 16 == 15 or e == offset_i + degree_i - 1), in increasing e.  One wavefront per node, 16 bytes per lane.
+// out[i,:] = (1/degree_i if mean) x sum of node i's pieces, in increasing edge order: the boundary rows e / 16 of its edges
+// e = 15 mod 16 and, when its last edge is not one of those, its own row boundary_rows + i (the compact layout the edge
+// chain writes, aggregate_pieces).  One wavefront per node, 16 bytes per lane.
 // `left` (nullable): out rows are [left[i,:] | sum_i] of width 2 H -- the input of the node MLP's first layer (h | agg), written
 // in the one pass over the nodes instead of a concatenation afterwards.
 __global__ __launch_bounds__(256) void segment_combine_kernel(const float* __restrict__ pieces, const int64_t* __restrict__ offsets,
                                                               const int64_t* __restrict__ degree, int64_t n_nodes, int H,
-                                                              int mean, float* __restrict__ out, const float* __restrict__ left)
+                                                              int mean, float* __restrict__ out, const float* __restrict__ left,
+                                                              int64_t boundary_rows)
 {
     const int lane = threadIdx.x % kWave;
     const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / kWave;
@@ -1312,10 +1319,12 @@ __global__ __launch_bounds__(256) void segment_combine_kernel(const float* __res
     for (int64_t node = wave; node < n_nodes; node += n_waves) {
         const int64_t e0 = offsets[node], deg = degree[node], e1 = e0 + deg;
         const float scale = (mean && deg > 0) ? 1.0f / (float)deg : 1.0f;
+        // the node's last piece: a boundary row if its last edge is 15 mod 16, else the node's own row
+        const int64_t last_row = ((e1 - 1) & 15) == 15 ? ((e1 - 1) >> 4) : boundary_rows + node;
         for (int q = lane; q < quads; q += kWave) {
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            for (int64_t e = e0 | 15; e < e1 - 1; e += 16) acc += reinterpret_cast<const f32x4*>(pieces + e * H)[q];
-            if (deg > 0) acc += reinterpret_cast<const f32x4*>(pieces + (e1 - 1) * H)[q];
+            for (int64_t e = e0 | 15; e < e1 - 1; e += 16) acc += reinterpret_cast<const f32x4*>(pieces + (e >> 4) * H)[q];
+            if (deg > 0) acc += reinterpret_cast<const f32x4*>(pieces + last_row * H)[q];
             if (mean) acc *= scale;
             if (left) {
                 reinterpret_cast<f32x4*>(out + node * 2 * H)[q] = reinterpret_cast<const f32x4*>(left + node * H)[q];
@@ -1438,17 +1447,23 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
     return MDX_ERR_UNSUPPORTED;
 }
 
-int mdx_segment_combine(const float* pieces, const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int H, int mean,
-                        const float* left, float* out, mdx_stream_t stream)
+int64_t mdx_egnn_piece_rows(int64_t n_edges, int64_t n_nodes)
 {
-    if (n_nodes < 0 || H < 4) return MDX_ERR_INVALID_ARG;
+    if (n_edges < 0 || n_nodes < 0) return -1;
+    return ((n_edges + 15) >> 4) + n_nodes;
+}
+
+int mdx_segment_combine(const float* pieces, int64_t n_edges, const int64_t* offsets, const int64_t* degree, int64_t n_nodes,
+                        int H, int mean, const float* left, float* out, mdx_stream_t stream)
+{
+    if (n_nodes < 0 || H < 4 || n_edges < 0) return MDX_ERR_INVALID_ARG;
     if (H & 3) return MDX_ERR_UNSUPPORTED;
     if (n_nodes == 0) return MDX_OK;
     if (!pieces || !offsets || !degree || !out) return MDX_ERR_INVALID_ARG;
     int64_t blocks = (n_nodes * kWave + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(segment_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       pieces, offsets, degree, n_nodes, H, mean, out, left);
+                       pieces, offsets, degree, n_nodes, H, mean, out, left, (n_edges + 15) >> 4);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 

@@ -461,7 +461,12 @@ class IterationLoop:
     capture-safe (no host synchronisation).  Used by LangevinGenerator.sample and by bench.py."""
 
     def __init__(self, generator: LangevinGenerator, start: AXL, starting_step_index: int, use_graph: bool):
-        gen = self.generator = generator
+        import weakref
+        gen = generator
+        # (a weak reference: the generator keeps its last loop alive in _buffers; a strong reference back would make the pair
+        # cyclic garbage, and the collector -- not the last reference going away -- would decide WHEN the loop's hipGraph is
+        # destroyed: possibly in the middle of another generator's capture, where hipGraphExecDestroy aborts the process)
+        self.generator = weakref.proxy(generator)
         device = start.X.device
         gen._prepare(device)
         assert getattr(gen.noise_source, "device_rng", False), "the device-resident loop needs rng_mode='device'"
@@ -488,15 +493,27 @@ class IterationLoop:
             self.graph = torch.cuda.CUDAGraph()
             # Objects whose finaliser calls HIP must not be collected while the stream is capturing: an older loop's
             # torch.cuda.CUDAGraph (hipGraphExecDestroy) and kernels.BlasContext (hipblasLtDestroy).  The first kind is
-            # released deterministically here, before the capture starts (the previous loop of this generator is dropped
-            # and torch.cuda.graph() itself runs gc.collect() on entry); the second lives for the whole process in
-            # BlasContext._by_device and refuses to destroy its handle during a capture.
+            # released deterministically: the previous loop of this generator is dropped here, loops of other generators
+            # die with their generator (no reference cycle: see __init__), and the collector runs right before the capture
+            # and not during it; the second lives for the whole process in BlasContext._by_device and refuses to destroy
+            # its handle during a capture.
             previous = gen._buffers.pop("graph_loop", None)
             if previous is not None:
                 previous.graph = None
             del previous
-            with torch.cuda.graph(self.graph):
-                gen._iteration_on_device_index(comp, self.forces, self.d_index)
+            # torch.cuda.graph() no longer collects garbage on entry (torch >= 2.9: only with
+            # torch.compiler.config.force_cudagraph_gc): collect here, before the capture, and keep the collector off while
+            # the stream is capturing -- nothing may run a finaliser that calls HIP in there.
+            import gc
+            gc.collect()
+            was_enabled = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(self.graph):
+                    gen._iteration_on_device_index(comp, self.forces, self.d_index)
+            finally:
+                if was_enabled:
+                    gc.enable()
         kernels.index_set(self.d_index, starting_step_index - 1)
 
     def advance(self, iterations: int):

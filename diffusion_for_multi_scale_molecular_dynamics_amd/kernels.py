@@ -728,11 +728,14 @@ def mlp_chain_rows(pack: RowChainPack, x, residual=None, status=None) -> torch.T
 def egnn_edge_chain(pack: EdgeChainPack, node_proj, coord, edges, status=None, n_edges_dev=None, piece_sums: bool = False):
     """messages [E,H], edge_scalar [E] of the fused per-edge chain (mdx_egnn_edge_chain); edges sorted by source.
     n_edges_dev (int64 [1], device): the actual number of edge rows when `edges` is a capacity-sized list.
-    piece_sums: the first output holds per-node piece sums instead of the messages (feed it to segment_combine)."""
+    piece_sums: the first output holds per-node piece sums instead of the messages, in the compact layout of
+    mdx_egnn_piece_rows(E, n_nodes) = ceil(E / 16) + n_nodes rows (feed it to segment_combine with n_edges=E): no [E, H]
+    buffer exists in that mode."""
     E, H = edges.shape[0], pack.hidden
     pack.c_struct.message_mode = 1 if piece_sums else 0
     assert node_proj.shape[1] == 2 * H and coord.shape[0] == node_proj.shape[0]
-    messages = torch.empty(E, H, dtype=F32, device=edges.device)
+    rows = lib().mdx_egnn_piece_rows(E, node_proj.shape[0]) if piece_sums else E
+    messages = torch.empty(rows, H, dtype=F32, device=edges.device)
     scalar = torch.empty(E, dtype=F32, device=edges.device)
     rc = lib().mdx_egnn_edge_chain(C.byref(pack.c_struct), ptr(node_proj, F32, "node_proj"), ptr(coord, F32, "coord"),
                                    coord.shape[1], ptr(edges, I64, "edges"), E, ptr(n_edges_dev, I64, "n_edges_dev"),
@@ -742,13 +745,15 @@ def egnn_edge_chain(pack: EdgeChainPack, node_proj, coord, edges, status=None, n
     return messages, scalar
 
 
-def segment_combine(pieces, offsets, degree, mean: bool, left=None) -> torch.Tensor:
-    """Sum (or mean) over each node's edges from the piece sums of egnn_edge_chain(..., piece_sums=True) -> [n_nodes, H];
-    with `left` [n_nodes, H]: [left | sums], [n_nodes, 2H] (the node MLP's input, without a separate concatenation)."""
+def segment_combine(pieces, n_edges: int, offsets, degree, mean: bool, left=None) -> torch.Tensor:
+    """Sum (or mean) over each node's edges from the piece sums of egnn_edge_chain(..., piece_sums=True) over `n_edges` edge
+    rows (the capacity that call was given) -> [n_nodes, H]; with `left` [n_nodes, H]: [left | sums], [n_nodes, 2H] (the
+    node MLP's input, without a separate concatenation)."""
     n_nodes, H = degree.shape[0], pieces.shape[1]
     assert left is None or tuple(left.shape) == (n_nodes, H)
+    assert pieces.shape[0] == lib().mdx_egnn_piece_rows(n_edges, n_nodes), "pieces: not the compact layout of n_edges, n_nodes"
     out = torch.empty(n_nodes, H if left is None else 2 * H, dtype=F32, device=pieces.device)
-    rc = lib().mdx_segment_combine(ptr(pieces, F32, "pieces"), ptr(offsets, I64, "offsets"), ptr(degree, I64, "degree"),
+    rc = lib().mdx_segment_combine(ptr(pieces, F32, "pieces"), n_edges, ptr(offsets, I64, "offsets"), ptr(degree, I64, "degree"),
                                    n_nodes, H, int(bool(mean)), ptr(left, F32, "left"), ptr(out, F32, "out"), stream_handle())
     check(rc, "mdx_segment_combine")
     return out

@@ -301,7 +301,8 @@ class E_GCL(nn.Module):
                                                         n_edges_dev=n_edges, piece_sums=in_kernel)
         coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean)
         if in_kernel and h.shape[1] == messages.shape[1]:
-            node_in = kernels.segment_combine(messages, offsets, degree, self.message_mean, left=h.contiguous())     # [h | agg]
+            node_in = kernels.segment_combine(messages, edge_index.shape[0], offsets, degree, self.message_mean,
+                                              left=h.contiguous())                                       # [h | agg]
             whole = self._node_mlp_pack(next_layer)
             if whole is not None and whole.hidden == h.shape[1]:
                 # the whole node MLP (its 2H -> H layer included), the residual and -- when a graph layer follows -- that
@@ -311,7 +312,7 @@ class E_GCL(nn.Module):
                     out, self._next_proj = out
                 return out, coord_out
         else:
-            agg = (kernels.segment_combine(messages, offsets, degree, self.message_mean) if in_kernel
+            agg = (kernels.segment_combine(messages, edge_index.shape[0], offsets, degree, self.message_mean) if in_kernel
                    else kernels.segment_rows(messages, offsets, degree, self.message_mean))
             node_in = torch.cat([h, agg], dim=1)
         node_pack = self._node_chain_pack()

@@ -104,10 +104,14 @@ class EGNNScoreNetwork(ScoreNetwork):
         self.edge_builder = edge_builder
         self.graph_status = None      # device word that collects MDX_STATUS_* bits of the forward without a sync
         # Radius graph without a host read between count and fill (so that a whole sampler iteration can be captured into a
-        # hipGraph): the edge list is sized for the worst case B N (N - 1) -- it cannot overflow -- as long as the [E, H]
-        # message buffer of that size stays below this many bytes; above it, the two-call protocol with its one host read
-        # is used.  Applies when every graph layer runs the fused edge chain (nothing else then needs E on the host).
-        self.static_edge_list_max_bytes = 24 << 30
+        # hipGraph): the edge list is sized for the worst case B N (N - 1) -- it cannot overflow.  What that capacity costs:
+        # 20 bytes per edge row (the int64 pair + the head's scalar) and the compact piece rows of the in-kernel message
+        # sums (H floats per 16 edge rows) -- 0.3 GB at C3, 0.9 GB at C5 with 256 structures per GPU; no [E, H] buffer
+        # exists on this path.  It is taken while that stays below this fraction of the device's FREE memory; above it the
+        # two-call protocol (one host read per forward, lists sized to the real edge count) is used and the switch is
+        # logged.  Applies when every graph layer runs the fused edge chain (nothing else then needs E on the host).
+        self.static_edge_list_max_fraction = 0.5
+        self._logged_two_call_switch = False
         self.egnn = self._make_egnn(hp)
 
     @property
@@ -187,13 +191,31 @@ class EGNNScoreNetwork(ScoreNetwork):
             self.graph_status = torch.zeros(1, dtype=torch.int32, device=relative_coordinates.device)
         capacity = bsz * n * (n - 1)
         width = max((layer.message_mlp[0].out_features for layer in self.egnn.graph_layers), default=0)
-        if relative_coordinates.is_cuda and not torch.is_grad_enabled() and 0 < capacity * width * 4 <= \
-                self.static_edge_list_max_bytes and all(layer.use_fused_ops and layer._edge_chain_pack() is not None
-                                                        for layer in self.egnn.graph_layers):
-            edges, degree, offsets, n_edges = neighbors.get_edges_static(relative_coordinates, unit_cell,
-                                                                         self.radial_cutoff, capacity,
-                                                                         status=self.graph_status)
-            return edges, (degree, offsets, n_edges)
+        if relative_coordinates.is_cuda and not torch.is_grad_enabled() and capacity > 0 and \
+                all(layer.use_fused_ops and layer._edge_chain_pack() is not None for layer in self.egnn.graph_layers):
+            needed = capacity * 20 + (capacity // 16 + bsz * n) * width * 4
+            # (hipMemGetInfo is not allowed while a stream is capturing: the answer of the eager warm-up iterations that
+            # precede every capture of this shape is kept)
+            key = (str(relative_coordinates.device), capacity, width, self.static_edge_list_max_fraction)
+            decisions = self.__dict__.setdefault("_static_decisions", {})
+            if key not in decisions and not torch.cuda.is_current_stream_capturing():
+                # free = what the driver reports + what torch's caching allocator holds but has not handed out
+                free = torch.cuda.mem_get_info(relative_coordinates.device)[0] + torch.cuda.memory_reserved(
+                    relative_coordinates.device) - torch.cuda.memory_allocated(relative_coordinates.device)
+                decisions[key] = (needed <= self.static_edge_list_max_fraction * free, free)
+            fits, free = decisions.get(key, (True, 0))
+            if fits:
+                edges, degree, offsets, n_edges = neighbors.get_edges_static(relative_coordinates, unit_cell,
+                                                                             self.radial_cutoff, capacity,
+                                                                             status=self.graph_status)
+                return edges, (degree, offsets, n_edges)
+            if not self._logged_two_call_switch:
+                import logging
+                logging.getLogger(__name__).warning(
+                    "EGNN radius graph: a capacity-sized edge list would take %.1f GB of the %.1f GB free on the device; using "
+                    "the two-call protocol (one host read per forward, the sampler iteration is not captured in a hipGraph)",
+                    needed / 2 ** 30, free / 2 ** 30)
+                self._logged_two_call_switch = True
         return neighbors.get_edges_with_radial_cutoff(relative_coordinates, unit_cell, self.radial_cutoff,
                                                       status=self.graph_status, return_degree=True)
 

@@ -92,8 +92,14 @@ def create_batch_of_samples_sharded(generator: AXLGenerator, sampling_parameters
     rows = pack_compositions(local)
     padded = torch.zeros((width, rows.shape[1]), dtype=torch.uint8, device=rows.device)
     padded[: rows.shape[0]] = rows
-    out = torch.empty((world * width, rows.shape[1]), dtype=torch.uint8, device=rows.device)
-    dist.all_gather_into_tensor(out, padded, group=group)          # the job's single collective
+    if dist.get_backend(group) == "gloo" and padded.is_cuda:
+        # (rehearsals of the multi-rank flow on one GPU, and the per-shard parity test: gloo moves host memory)
+        host = torch.empty((world * width, rows.shape[1]), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, padded.cpu(), group=group)
+        out = host.to(rows.device)
+    else:
+        out = torch.empty((world * width, rows.shape[1]), dtype=torch.uint8, device=rows.device)
+        dist.all_gather_into_tensor(out, padded, group=group)          # the job's single collective
     gathered = unpack_compositions(out.view(world, width, -1), n_atoms, d)
     # restore sub-batch order
     pieces = {}

@@ -374,7 +374,7 @@ MDX_API int mdx_segment_rows(const float* data, const int64_t* offsets, const in
  * count (<= n_edges), for callers that size the edge list without reading it back. */
 #define MDX_EGNN_CHAIN_MAX_LAYERS 16
 #define MDX_EGNN_MESSAGES_ROWS 0        /* messages_out [E,H] = the messages                                            */
-#define MDX_EGNN_MESSAGES_PIECE_SUMS 1  /* messages_out [E,H] = per-node piece sums (see mdx_segment_combine)           */
+#define MDX_EGNN_MESSAGES_PIECE_SUMS 1  /* messages_out [mdx_egnn_piece_rows(E, n_nodes), H] = per-node piece sums      */
 #define MDX_EGNN_F16_ACTIVATION_EXPONENT 6
 typedef struct mdx_egnn_chain {
     int32_t hidden, n_message_layers, n_coord_layers, precision;
@@ -398,15 +398,20 @@ MDX_API int mdx_egnn_edge_chain(const mdx_egnn_chain_t* chain_host, const float*
                                 float* messages_out, float* edge_scalar_out, uint32_t* status, mdx_stream_t stream);
 /* Message aggregation without the [E,H] round trip: with message_mode = MDX_EGNN_MESSAGES_PIECE_SUMS the edge chain adds
  * the messages of a node's edges up INSIDE the kernel, per group of 16 consecutive edge rows (the list is sorted by source),
- * and writes only those sums: the sum over the edges of node i inside group [16 k, 16 k + 16) lands in the row of the last
- * such edge; every other row of messages_out is left untouched.  mdx_segment_combine then gives
- * out[i,:] = (1/degree_i if mean) sum of node i's pieces, read in row order -- unsorted_segment_sum / _mean of the messages
- * (models/egnn_utils.py:11-70) with a fixed summation order and no atomics; it replaces mdx_segment_rows, reads ~2 rows
- * per node instead of degree_i, and the messages themselves never reach memory.  Node indices must be < 2^31.
+ * and writes only those sums, into a COMPACT buffer of mdx_egnn_piece_rows(n_edges, n_nodes) = ceil(n_edges / 16) + n_nodes
+ * rows (n_edges = the capacity passed to mdx_egnn_edge_chain): the sum over the edges of node i inside group
+ * [16 k, 16 k + 16) lands in row k when the group's last edge belongs to node i, otherwise -- the node's last edge is then
+ * inside the group -- in the node's own row ceil(n_edges / 16) + i; every other row is left untouched.  No [E,H] buffer
+ * exists in this mode (C3: 165 MB instead of 2.1 GB; C5 at 256 structures per GPU: 0.8 GB instead of 12.2 GB).
+ * mdx_segment_combine (same n_edges) then gives out[i,:] = (1/degree_i if mean) sum of node i's pieces, read in edge order --
+ * unsorted_segment_sum / _mean of the messages (models/egnn_utils.py:11-70) with a fixed summation order and no atomics; it
+ * replaces mdx_segment_rows, reads ~2 rows per node instead of degree_i, and the messages themselves never reach memory.
+ * Node indices must be < 2^31.
  * left (nullable, [n_nodes,H]): out is [n_nodes, 2H] = [left | sums] -- torch.cat([h, agg], dim=1), the input of the node
  * MLP (models/egnn.py:202-230), written in the same pass. */
-MDX_API int mdx_segment_combine(const float* pieces, const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int H,
-                                int mean, const float* left, float* out, mdx_stream_t stream);
+MDX_API int64_t mdx_egnn_piece_rows(int64_t n_edges, int64_t n_nodes);
+MDX_API int mdx_segment_combine(const float* pieces, int64_t n_edges, const int64_t* offsets, const int64_t* degree,
+                                int64_t n_nodes, int H, int mean, const float* left, float* out, mdx_stream_t stream);
 
 /* EGNNScoreNetwork's per-node inputs and outputs around the EGNN (models/score_networks/egnn_score_network.py:253-290), one
  * launch each instead of a dozen elementwise passes (spatial dimension 3):

@@ -147,7 +147,7 @@ def test_edge_chain_small_magnitudes_against_fp64(cuda, precision, case):
     got_m, got_s = kernels.egnn_edge_chain(pack, proj, coord.to(cuda).contiguous(), edges.to(cuda), status=status)
     pieces, got_s2 = kernels.egnn_edge_chain(pack, proj, coord.to(cuda).contiguous(), edges.to(cuda), status=status, piece_sums=True)
     offsets = (torch.cumsum(degree, 0) - degree).to(cuda)
-    got_sum = kernels.segment_combine(pieces, offsets, degree.to(cuda), False)
+    got_sum = kernels.segment_combine(pieces, E, offsets, degree.to(cuda), False)
     torch.cuda.synchronize()
     assert int(status.item()) == 0
     want_sum = torch.zeros(n_nodes, H, dtype=torch.float64).index_add_(0, src, want_m.detach())
@@ -369,7 +369,7 @@ def test_egnn_sampler_graph_replay_equals_eager(cuda, precision):
         net = nets.egnn_net(1, "radial_cutoff", 7.5, hidden=32, n_layers=2, n_hidden=2).to(cuda)
         net.edge_chain_precision = precision
         if mode == "two_call":
-            net.static_edge_list_max_bytes = 0
+            net.static_edge_list_max_fraction = 0.0      # force the two-call protocol
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             npar = NoiseParameters(**cases.noise_ns(5, **cases.LIN))
@@ -515,8 +515,8 @@ def test_edge_chain_piece_sums_against_fp64(cuda, precision, H, n_nodes, deg):
     offsets = (torch.cumsum(degree, 0) - degree).to(cuda)
     status = torch.zeros(1, dtype=torch.int32, device=cuda)
     pieces, scalar = kernels.egnn_edge_chain(pack, proj, coord_d, edges_d, status=status, piece_sums=True)
-    got_mean = kernels.segment_combine(pieces, offsets, degree.to(cuda), True)
-    got_sum = kernels.segment_combine(pieces, offsets, degree.to(cuda), False)
+    got_mean = kernels.segment_combine(pieces, E, offsets, degree.to(cuda), True)
+    got_sum = kernels.segment_combine(pieces, E, offsets, degree.to(cuda), False)
     messages, scalar2 = kernels.egnn_edge_chain(pack, proj, coord_d, edges_d, status=status, piece_sums=False)
     rows_mean = kernels.segment_rows(messages, offsets, degree.to(cuda), True)
     torch.cuda.synchronize()
@@ -528,7 +528,7 @@ def test_edge_chain_piece_sums_against_fp64(cuda, precision, H, n_nodes, deg):
     assert (got_sum[degree == 0] == 0).all()
     # [left | sums] in one pass: torch.cat([left, sums], 1), bit for bit
     left = torch.randn(n_nodes, H, generator=g).to(cuda)
-    both = kernels.segment_combine(pieces, offsets, degree.to(cuda), True, left=left)
+    both = kernels.segment_combine(pieces, E, offsets, degree.to(cuda), True, left=left)
     assert both.shape == (n_nodes, 2 * H) and torch.equal(both, torch.cat([left, got_mean], dim=1))
     node_err = ((got_mean.double().cpu() - want_mean).norm(dim=1) / want_mean.norm(dim=1).clamp(min=1e-30))[degree > 0].max()
     assert float(node_err) < 20 * tol, float(node_err)

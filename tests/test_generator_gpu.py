@@ -1166,3 +1166,94 @@ def test_fused_sampler_register_resident_family(cuda, num_atom_types, n_hidden):
         assert np.array_equal(a.A, b.A), n_iterations
         assert torus_rel_l2(a.X, b.X) < tol, (n_iterations, torus_rel_l2(a.X, b.X))
     assert (results["family", 40].A != num_atom_types).all()
+
+
+_SHARD_WORKER = '''
+import os, sys, warnings
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch
+import torch.distributed as dist
+import cases, nets
+from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+from diffusion_for_multi_scale_molecular_dynamics_amd.generators.predictor_corrector_axl_generator import \\
+    PredictorCorrectorSamplingParameters
+from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters
+from diffusion_for_multi_scale_molecular_dynamics_amd.sampling.diffusion_sampling import create_batch_of_samples_sharded
+dist.init_process_group(backend="gloo")
+rank = dist.get_rank()
+device = torch.device("cuda:0")
+out = {{}}
+for name in {names!r}:
+    noise_kw, sampling_kw, netf = cases.TRAJECTORIES[name]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        spar = PredictorCorrectorSamplingParameters(**dict(sampling_kw, number_of_samples={total}, sample_batchsize={batch}),
+                                                    rng_mode="device", seed={seed})
+    if netf is None:
+        net = nets.fake_net(spar.num_atom_types)
+    else:
+        torch.manual_seed(1234)
+        net = netf(None)
+    gen = LangevinGenerator(NoiseParameters(**noise_kw), spar, net.to(device))
+    with torch.no_grad():
+        res = create_batch_of_samples_sharded(gen, spar, device)
+    out[name] = {{k: (v if torch.is_tensor(v) else tuple(v)) for k, v in res.items()}}
+torch.save({{n: dict(A=o["original_axl"][0].cpu(), X=o["original_axl"][1].cpu(), L=o["original_axl"][2].cpu(),
+                    C=o["cartesian_positions"].cpu()) for n, o in out.items()}}, os.path.join({out!r}, f"rank{{rank}}.pt"))
+dist.barrier()
+dist.destroy_process_group()
+print(f"rank {{rank}} ok")
+'''
+
+
+def test_sharded_driver_per_shard_parity_on_the_hip_path(cuda, tmp_path):
+    """SURVEY 8(e), 'Seeds / parity under sharding': each rank seeds base + rank, and its shard must equal a single-process
+    run with number_of_samples = its share and that seed.  Two fresh child processes (gloo, both on cuda:0) run
+    create_batch_of_samples_sharded with the REAL LangevinGenerator (device RNG; the echo network and the small MLP) over
+    7 samples in sub-batches of 2 -- rank 0 owns sub-batches 0 and 2 (4 samples), rank 1 owns 1 and 3 (3 samples: uneven);
+    the batch both ranks hold after the job's one gather equals, bit for bit, the sub-batches of two single-process
+    generators with seeds base + 0 and base + 1, put in sub-batch order (reference loop:
+    sampling/diffusion_sampling.py:44-50)."""
+    import os
+    import subprocess
+    import sys
+    import warnings
+    from conftest import ROOT
+    from diffusion_for_multi_scale_molecular_dynamics_amd.sampling.diffusion_sampling import (shard_of_rank, split_sizes)
+    names, total, batch, seed = ["traj_fake_c3_m2", "traj_mlp_c3"], 7, 2, 4242
+    script = tmp_path / "shard_worker.py"
+    script.write_text(_SHARD_WORKER.format(root=ROOT, names=names, total=total, batch=batch, seed=seed, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, f"rank {r} failed:\n{o[-3000:]}"
+    got = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
+    P = _pkg()
+    sizes = split_sizes(total, batch)
+    assert sizes == [2, 2, 2, 1]
+    for name in names:
+        noise_kw, sampling_kw, netf = cases.TRAJECTORIES[name]
+        pieces = {}
+        for r in range(2):                      # the single-process run of rank r's share with seed base + r
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                spar = P["Sampling"](**dict(sampling_kw, number_of_samples=total, sample_batchsize=batch),
+                                     rng_mode="device", seed=seed + r)
+            if netf is None:
+                net = nets.fake_net(spar.num_atom_types)
+            else:
+                torch.manual_seed(1234)
+                net = netf(None)
+            gen = P["Langevin"](P["Noise"](**noise_kw), spar, net.to(cuda))
+            with torch.no_grad():
+                for k, n in shard_of_rank(sizes, r, 2):
+                    pieces[k] = gen.sample(n, cuda)
+        want_A = torch.cat([pieces[k].A for k in range(len(sizes))]).cpu()
+        want_X = torch.cat([pieces[k].X for k in range(len(sizes))]).cpu()
+        for r in range(2):                      # every rank holds the whole batch
+            g = got[r][name]
+            assert torch.equal(g["A"], want_A), (name, r)
+            assert torch.equal(g["X"].view(torch.int32), want_X.view(torch.int32)), (name, r)
+            assert g["X"].shape[0] == total and torch.equal(g["C"], g["X"] * g["L"][:, None, :3])

@@ -50,6 +50,7 @@ def timed_runs(gen, sampling_parameters, batch, repeats):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--port", action="store_true", help="also time bench.py's cpu_baseline (the oracle port) on this host")
     args = ap.parse_args()
     result = {"host": {"cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "torch": torch.__version__},
               "protocol": "create_batch_of_samples wall time, first run excluded, %d repeats" % args.repeats, "configs": {}}
@@ -73,6 +74,17 @@ def main():
             "structures_per_s_min_max": [round(batch / max(job), 5), round(batch / min(job), 5)],
             "extrapolated": c["T"] != full_T}
         print(name, result["configs"][name], flush=True)
+    if args.port:
+        # the build's own CPU restatement -- the `cpu_baseline` leg of bench.py, same bounded sample of C3 -- on
+        # THIS host, so that the `cpu_baseline` bench.py reports from the GPU box's cores can be read against the reference
+        # figure above (same machine, same day): calibration = port / reference.
+        sys.path.insert(0, ROOT)
+        import bench
+        for name in ("C3", "C2"):
+            port = bench.cpu_baseline(bench.WORKLOADS[name], name)
+            ref = result["configs"]["C3_cpu_B16" if name == "C3" else "C2_cpu"]["structures_per_s"]
+            result.setdefault("port", {})[name] = dict(port, port_over_reference=round(port["value"] / ref, 3))
+            print(name, result["port"][name], flush=True)
     print(json.dumps(result))
 
 
