@@ -105,7 +105,7 @@ constexpr bool kScaled = false;
 constexpr bool kScaled = true;
 #endif
 template <int PREC>
-constexpr int kActExp = PREC == 1 && kScaled ? 6 : 0;
+constexpr int kActExp = PREC >= 1 && kScaled ? 6 : 0;
 constexpr float pow2_const(int e) { float v = 1.0f; for (int i = 0; i < (e < 0 ? -e : e); ++i) v = e < 0 ? v * 0.5f : v * 2.0f; return v; }
 __device__ __forceinline__ float pow2_bits(int e) { return __builtin_bit_cast(float, (uint32_t)(127 + e) << 23); }   // |e| <= 126
 
@@ -138,6 +138,24 @@ template <int H>
 struct Act<H, 1> {
     half8 hi[H / 16], lo[H / 16];         // k-step s, element j: feature 16 s + 8 (j >> 2) + 4 h + (j & 3)
 };
+// PREC 2: split-f16 on v_mfma_f32_16x16x32_f16.  A lane holds TWO edges (column groups cg = 0, 1: edges 16 cg + (lane & 15) of
+// the wavefront's 32) and a quarter of their features (g = lane >> 4).  A 32-row chunk is two row tiles rho of 16; its sixteen
+// accumulator registers are r = 8 rho + 4 cg + i  <->  feature 32 t + 16 rho + 4 g + i of edge cg: exactly element j = 4 rho + i
+// of the B fragment of k-step t (32 features deep) of column group cg, so the hand-over to the next layer stays in registers.
+template <int H>
+struct Act<H, 2> {
+    half8 hi[2][H / 32], lo[2][H / 32];   // [cg][k-step s], element j: feature 32 s + 16 (j >> 2) + 4 g + (j & 3)
+};
+
+// Which of the lane's edges a float4 group q (registers 4 q .. 4 q + 3 of a tile) belongs to, and its first feature within the
+// 32-row chunk (sub = lane >> 5 for the 32x32 shapes, lane >> 4 for the 16x16 shape).
+template <int PREC>
+struct Lay {
+    static constexpr bool W16 = PREC == 2;
+    static constexpr int NS = W16 ? 2 : 1;                   // edges (or rows) per lane
+    static __device__ __forceinline__ constexpr int es(int q) { return W16 ? (q & 1) : 0; }
+    static __device__ __forceinline__ int fb(int q, int sub) { return W16 ? 16 * (q >> 1) + 4 * sub : 8 * q + 4 * sub; }
+};
 
 template <int H>
 __device__ __forceinline__ void put(Act<H, 0>& a, int t, int r, float y)
@@ -160,10 +178,8 @@ __device__ __forceinline__ void put_pair(Act<H, 0>& a, int t, int r, float y0, f
     a.v[16 * t + r] = y0;
     a.v[16 * t + r + 1] = y1;
 }
-template <int H>
-__device__ __forceinline__ void put_pair(Act<H, 1>& a, int t, int r, float y0, float y1)
+__device__ __forceinline__ void split_f16_pair(float y0, float y1, uint32_t& hi, uint32_t& lo)
 {
-    uint32_t hi, lo;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(y0), "v"(y1));
 #ifdef MDX_CHAIN_MIXLO
     // lo = f16(y - hi), each half written by one instruction: the difference is formed exactly (f16 operand x -1 + f32 operand)
@@ -176,13 +192,78 @@ __device__ __forceinline__ void put_pair(Act<H, 1>& a, int t, int r, float y0, f
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(y1));
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(l0), "v"(l1));
 #endif
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int H>
+__device__ __forceinline__ void put_pair(Act<H, 1>& a, int t, int r, float y0, float y1)
+{
+    uint32_t hi, lo;
+    split_f16_pair(y0, y1, hi, lo);
     const int s = 2 * t + (r >> 3), j = (r & 7) >> 1;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 vh = __builtin_bit_cast(u32x4, a.hi[s]), vl = __builtin_bit_cast(u32x4, a.lo[s]);
     vh[j] = hi;
     vl[j] = lo;
     a.hi[s] = __builtin_bit_cast(half8, vh);
     a.lo[s] = __builtin_bit_cast(half8, vl);
+}
+template <int H>
+__device__ __forceinline__ void put_pair(Act<H, 2>& a, int t, int r, float y0, float y1)
+{
+    uint32_t hi, lo;
+    split_f16_pair(y0, y1, hi, lo);
+    const int cg = (r >> 2) & 1, j = 2 * (r >> 3) + ((r & 3) >> 1);      // register r = 8 rho + 4 cg + i  ->  element 4 rho + i
+    u32x4 vh = __builtin_bit_cast(u32x4, a.hi[cg][t]), vl = __builtin_bit_cast(u32x4, a.lo[cg][t]);
+    vh[j] = hi;
+    vl[j] = lo;
+    a.hi[cg][t] = __builtin_bit_cast(half8, vh);
+    a.lo[cg][t] = __builtin_bit_cast(half8, vl);
+}
+template <int H>
+__device__ __forceinline__ void put(Act<H, 2>& a, int t, int r, float y)
+{
+    const _Float16 hi = (_Float16)y;
+    const int cg = (r >> 2) & 1, j = 4 * (r >> 3) + (r & 3);
+    a.hi[cg][t][j] = hi;
+    a.lo[cg][t][j] = (_Float16)(y - (float)hi);
+}
+
+// The four carried values of float4 group q of tile t (registers 4 q .. 4 q + 3), as binary32: hi + lo in one instruction per
+// value for the split forms (v_fma_mix_f32 with both addends taken from the packed halves).
+template <int H>
+__device__ __forceinline__ f32x4 get4(const Act<H, 0>& a, int t, int q)
+{
+    return f32x4{a.v[16 * t + 4 * q], a.v[16 * t + 4 * q + 1], a.v[16 * t + 4 * q + 2], a.v[16 * t + 4 * q + 3]};
+}
+__device__ __forceinline__ void join_f16_pair(uint32_t ph, uint32_t pl, float& y0, float& y1)
+{
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(ph), "v"(pl));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(y1) : "v"(ph), "v"(pl));
+}
+template <int H>
+__device__ __forceinline__ f32x4 get4(const Act<H, 1>& a, int t, int q)
+{
+    const int r0 = 4 * q;
+    const u32x4 vh = __builtin_bit_cast(u32x4, a.hi[2 * t + (r0 >> 3)]), vl = __builtin_bit_cast(u32x4, a.lo[2 * t + (r0 >> 3)]);
+    f32x4 y;
+    float y0, y1;
+    join_f16_pair(vh[(r0 & 7) >> 1], vl[(r0 & 7) >> 1], y0, y1);
+    y[0] = y0; y[1] = y1;
+    join_f16_pair(vh[((r0 & 7) >> 1) + 1], vl[((r0 & 7) >> 1) + 1], y0, y1);
+    y[2] = y0; y[3] = y1;
+    return y;
+}
+template <int H>
+__device__ __forceinline__ f32x4 get4(const Act<H, 2>& a, int t, int q)
+{
+    const int cg = q & 1, rho = q >> 1;                                   // registers 8 rho + 4 cg + (0..3): elements 4 rho + (0..3)
+    const u32x4 vh = __builtin_bit_cast(u32x4, a.hi[cg][t]), vl = __builtin_bit_cast(u32x4, a.lo[cg][t]);
+    f32x4 y;
+    float y0, y1;
+    join_f16_pair(vh[2 * rho], vl[2 * rho], y0, y1);
+    y[0] = y0; y[1] = y1;
+    join_f16_pair(vh[2 * rho + 1], vl[2 * rho + 1], y0, y1);
+    y[2] = y0; y[3] = y1;
+    return y;
 }
 
 // Timing diagnostics (never in the shipped build): -DMDX_CHAIN_STAMPS makes wavefront 0 of workgroup 0 write s_memtime at
@@ -359,7 +440,7 @@ struct Chain {
     // pieces requested in the SAME tile as the chunk's begin_chunk() (behind the acquire in the middle of the tile); the
     // others follow in the first half of the next tile
     // (split-f16 only: the exact-f32 chain, whose MFMAs are twice as long, measured 2 % faster with the burst)
-    static constexpr bool SPREAD = PREC == 1;
+    static constexpr bool SPREAD = PREC >= 1;
     static constexpr int FIRST_HALF = !SPREAD ? LPW : (LPW >= 2 ? LPW / 2 : 1);
 
     // Called in the MIDDLE of a tile's MFMA stream: makes the NEXT chunk readable (so that its first fragments can be read
@@ -488,8 +569,9 @@ __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const 
 // so every step carries about ten vector instructions beside its three MFMAs, instead of none beside the first half of the
 // tile's MFMAs and twenty beside each step of the second half -- which is what the scheduler makes of the plain form
 // (tools/tile_stats.py) -- and no step waits on a chain of nine dependent instructions.  The last pair is complete at the
-// end of step 14: the tile that follows a layer's last tile reads these values as its k-steps 14 and 15.
-constexpr int kPairStart[8] = {0, 1, 3, 5, 6, 8, 10, 12};
+// end of step 13: the tile that follows a layer's last tile reads these values in its steps 14 and 15 (the 16x16 shape: all
+// sixteen as one k-step of 32 in both; the 32x32 shape: eight in each).
+constexpr int kPairStart[8] = {0, 1, 3, 4, 6, 8, 9, 11};
 template <int H>
 struct EpiloguePipe {
     float a[8][2], e[8][2];
@@ -529,6 +611,17 @@ __device__ __forceinline__ void segmented_step(float (&x)[16], float gate)
     }
 }
 
+// The same with a gate per register (16x16 shape: the sixteen registers of a tile belong to two different edges).
+template <int D>
+__device__ __forceinline__ void segmented_step_gates(float (&x)[16], const float (&gate)[16])
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float below = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[r]), 0x110 + D, 0xf, 0xf, true));
+        x[r] = __builtin_fmaf(below, gate[r], x[r]);
+    }
+}
+
 // Raw accumulators of tile t parked in / taken from the sixteen registers that tile occupies in an operand set (MODE 3).
 template <int H>
 __device__ __forceinline__ void park(Act<H, 0>& a, int t, const f32x16& acc)
@@ -556,6 +649,27 @@ __device__ __forceinline__ void park(Act<H, 1>& a, int t, const f32x16& acc)
     a.lo[2 * t + 1] = __builtin_bit_cast(half8, q[3]);
 }
 template <int H>
+__device__ __forceinline__ void park(Act<H, 2>& a, int t, const f32x16& acc)
+{
+    f32x4 q[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) q[r >> 2][r & 3] = acc[r];
+    a.hi[0][t] = __builtin_bit_cast(half8, q[0]);
+    a.hi[1][t] = __builtin_bit_cast(half8, q[1]);
+    a.lo[0][t] = __builtin_bit_cast(half8, q[2]);
+    a.lo[1][t] = __builtin_bit_cast(half8, q[3]);
+}
+template <int H>
+__device__ __forceinline__ f32x16 unpark(const Act<H, 2>& a, int t)
+{
+    const f32x4 q[4] = {__builtin_bit_cast(f32x4, a.hi[0][t]), __builtin_bit_cast(f32x4, a.hi[1][t]),
+                        __builtin_bit_cast(f32x4, a.lo[0][t]), __builtin_bit_cast(f32x4, a.lo[1][t])};
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = q[r >> 2][r & 3];
+    return acc;
+}
+template <int H>
 __device__ __forceinline__ f32x16 unpark(const Act<H, 1>& a, int t)
 {
     const f32x4 q[4] = {__builtin_bit_cast(f32x4, a.hi[2 * t]), __builtin_bit_cast(f32x4, a.hi[2 * t + 1]),
@@ -572,14 +686,15 @@ template <int H, int PREC, int MODE>
 __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(ChainArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    // (GUARD: see issue_piece.  The piece-sums instantiations skip the three extra wait states in front of their requests --
-    // 2.2 % of the launch, A/B in profiles/r03_chain_ablation.md -- which is safe only while they restore no scalar register
-    // from a vector register: the BUILD checks that (csrc/Makefile feeds the compiler's resource remarks of this unit to
-    // check_chain_resources.py and fails on a scalar-register spill in any <H, PREC, 2> kernel).  -DMDX_CHAIN_GUARD_ALL: all guarded.)
+    // (GUARD: see issue_piece.  The production-size piece-sums instantiations <256, PREC, 2> skip the three extra wait states
+    // in front of their requests -- 2.2 % of the launch, A/B in profiles/r03_chain_ablation.md -- which is safe only while they
+    // restore no scalar register from a vector register: the BUILD checks that (csrc/Makefile feeds the compiler's resource
+    // remarks of this unit to check_chain_resources.py and fails on a scalar-register spill in any of them).  Every other
+    // instantiation is guarded.  -DMDX_CHAIN_GUARD_ALL: all guarded.)
 #ifdef MDX_CHAIN_GUARD_ALL
     using C = Chain<H, PREC, true>;
 #else
-    using C = Chain<H, PREC, MODE != 2>;
+    using C = Chain<H, PREC, !(MODE == 2 && H == 256)>;
 #endif
     // MODE 3 = MODE 1 whose first layer is 2 H -> H: the rows are [h | agg]; chain "layers" 0 and 1 are the two H x H halves of
     // that layer's weight.  Pass A multiplies h by the first half and PARKS the raw accumulators (bias included) in the
@@ -587,13 +702,19 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     // accumulator, multiplies by the second half and runs the usual epilogue into the slot the parked tile has left.
     constexpr bool ROWS = MODE == 1 || MODE == 3;
     constexpr int NT = C::NT;
-    constexpr int STEPS = PREC == 0 ? H / 8 : H / 16;        // k-steps of a tile: 4 f32 MFMAs | 3 f16 MFMAs each
+    constexpr int STEPS = PREC == 0 ? H / 8 : H / 16;        // k-steps of a tile: 4 f32 MFMAs | 3 f16 MFMAs (32x32x16) | 6 (16x16x32) each
+    constexpr bool SPLIT = PREC >= 1;                        // split-f16 arithmetic (either MFMA shape)
+    using L = Lay<PREC>;
+    constexpr bool W16 = L::W16;
+    constexpr int NS = L::NS;                                // edges (rows) per lane: 1 | 2 (16x16 shape)
 #ifndef MDX_CHAIN_PFD
 #define MDX_CHAIN_PFD 2
 #endif
     constexpr int PFD = STEPS >= 2 * MDX_CHAIN_PFD ? MDX_CHAIN_PFD : 1;     // weight fragments are read from LDS this many steps ahead
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
-    const int h = lane >> 5, col = lane & 31;
+    // 32x32 shapes: the lane's edge is column lane & 31 and it holds the feature quads of half h = lane >> 5;
+    // 16x16 shape: edges 16 cg + (lane & 15), cg = 0, 1, and the feature quads of quarter g = lane >> 4
+    const int h = W16 ? lane >> 4 : lane >> 5, col = W16 ? lane & 15 : lane & 31;
     const int layers = p.n_message + p.n_coord;
 
     lds_c* ring = (lds_c*)lds_raw;
@@ -635,12 +756,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 
     // a layer's bias in its accumulator's units: log2(e) 2^(a_l + b) b_l (exact: a power of two)
     for (int i = threadIdx.x; i < layers * H; i += kWaves * kWave) {
-        const int a = PREC == 1 && p.exps ? p.exps[i / H] : 0;
+        const int a = SPLIT && p.exps ? p.exps[i / H] : 0;
         par[i] = p.biases[i] * kLog2e * pow2_bits(a + ACT);
     }
     if (threadIdx.x < kScaleSlots) {
         const int packed = layers + (!ROWS ? 1 : (MODE == 3 && p.proj_out ? 2 : 0));
-        const int a = PREC == 1 && p.exps && (int)threadIdx.x < packed ? p.exps[threadIdx.x] : 0;
+        const int a = SPLIT && p.exps && (int)threadIdx.x < packed ? p.exps[threadIdx.x] : 0;
         par_sc[4 * threadIdx.x + 0] = -pow2_bits(-(a + ACT));
         par_sc[4 * threadIdx.x + 1] = pow2_bits(a);
         par_sc[4 * threadIdx.x + 2] = pow2_bits(-a);
@@ -693,10 +814,10 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (bias_row) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *(const __attribute__((address_space(3))) f32x4*)(bias_row + 8 * g + 4 * h);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *(const __attribute__((address_space(3))) f32x4*)(bias_row + L::fb(q, h));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[4 * g + i] = b4[i];
+                for (int i = 0; i < 4; ++i) acc[4 * q + i] = b4[i];
             }
         }
         return acc;
@@ -704,7 +825,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     // struct Scale of packed layer l, in scalar registers (one LDS read per layer; PREC 0 never uses it)
     auto load_scale = [&](int l) -> Scale {
         Scale sc{-1.0f, 1.0f, 1.0f, kLn2};
-        if constexpr (PREC == 1) {
+        if constexpr (SPLIT) {
             // (four scalar reads ON PURPOSE: with one 16-byte read, hipcc 7.2 hands element 0 to all four v_readfirstlane --
             // only ds_read_b32 of the first float is emitted; seen in the ISA, reproduced in a ten-line kernel)
             const lds_f* q = par_sc + 4 * l;
@@ -725,22 +846,36 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     bool out_of_range = false;       // split-f16: a non-finite output (see epilogue_elements)
     for (int64_t tile = tile_lo + xcd_slot; tile < tile_hi; tile += xcd_wgs) {
         MDX_STAMP_ALWAYS(9);
-        // ---- this lane's edge (or row) -----------------------------------------------------------------------------
-        const int64_t e_raw = tile * kTileEdges + wave * 32 + col;
-        const bool live = e_raw < n_edges;
-        const int64_t e = live ? e_raw : n_edges - 1;
+        // ---- this lane's edges (or rows): one (32x32 shapes) or two (16x16 shape: column groups 0 and 1) ---------------------
+        int64_t e_raw[NS], e[NS];
+#pragma unroll
+        for (int es = 0; es < NS; ++es) {
+            e_raw[es] = tile * kTileEdges + wave * 32 + (W16 ? 16 * es : 0) + col;
+            e[es] = e_raw[es] < n_edges ? e_raw[es] : n_edges - 1;
+        }
+        // (evaluated where it is needed, not carried through the tile as a pair of scalar registers per edge: the 16x16-shape
+        // kernels are short of those)
+        auto is_live = [&](int es) -> bool { return e_raw[es] < n_edges; };
         Act<H, PREC> xa, xb;
+        // float4 group q8 = 4 t + q of the lane's H / 2 values: registers 4 q .. 4 q + 3 of tile t = features
+        // 32 t + fb(q) .. + 3 of edge es(q)  (struct Lay)
         if constexpr (!ROWS) {
-            const int64_t src = p.edges[2 * e], dst = p.edges[2 * e + 1];
-            if (MODE == 2 && h == 0) seg_src[col] = (int)src;      // (node indices fit 31 bits: checked on the host)
-            float radial = 0.0f;
-            for (int k = 0; k < p.D; ++k) {
-                const float dlt = p.coord[src * p.D + k] - p.coord[dst * p.D + k];
-                radial += dlt * dlt;
+            float radial[NS];
+            const float *ps[NS], *pd[NS];
+#pragma unroll
+            for (int es = 0; es < NS; ++es) {
+                const int64_t src = p.edges[2 * e[es]], dst = p.edges[2 * e[es] + 1];
+                if (MODE == 2 && h == 0) seg_src[(W16 ? 16 * es : 0) + col] = (int)src;      // (node indices fit 31 bits: checked on the host)
+                float r2 = 0.0f;
+                for (int k = 0; k < p.D; ++k) {
+                    const float dlt = p.coord[src * p.D + k] - p.coord[dst * p.D + k];
+                    r2 += dlt * dlt;
+                }
+                radial[es] = r2;
+                ps[es] = p.node_proj + src * 2 * H;
+                pd[es] = p.node_proj + dst * 2 * H + H;
             }
-            // first message layer, straight into B-operand registers
-            const float* ps = p.node_proj + src * 2 * H + 4 * h;
-            const float* pd = p.node_proj + dst * 2 * H + H + 4 * h;
+            // first message layer, straight into B-operand registers.
             // The gathers are software-pipelined by hand: batches of QB float4 pairs, requested DEPTH batches before they are
             // used, with scheduling pins between "request" and "compute" (left to itself the compiler keeps six to ten of
             // the 64 loads in flight -- the operand sets fill the register file -- and the phase is a chain of L2 latencies:
@@ -750,14 +885,14 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             auto request = [&](int batch) {
 #pragma unroll
                 for (int k = 0; k < QB; ++k) {
-                    const int q = batch * QB + k;           // features 8 q + 4 h + (0..3)
+                    const int q8 = batch * QB + k, es = L::es(q8 & 3), off = 32 * (q8 >> 2) + L::fb(q8 & 3, h);
 #if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 2)
-                    ga[batch][k] = f32x4{radial, 1.0f, 2.0f, radial};
-                    gb[batch][k] = f32x4{0.5f, radial, 0.25f, 1.0f};
-                    (void)q;
+                    ga[batch][k] = f32x4{radial[es], 1.0f, 2.0f, radial[es]};
+                    gb[batch][k] = f32x4{0.5f, radial[es], 0.25f, 1.0f};
+                    (void)off;
 #else
-                    ga[batch][k] = *(const f32x4*)(ps + 8 * q);
-                    gb[batch][k] = *(const f32x4*)(pd + 8 * q);
+                    ga[batch][k] = *(const f32x4*)(ps[es] + off);
+                    gb[batch][k] = *(const f32x4*)(pd[es] + off);
 #endif
                 }
             };
@@ -770,28 +905,33 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < QB; ++k) {
-                    const int q = batch * QB + k;
+                    const int q8 = batch * QB + k, es = L::es(q8 & 3), off = 32 * (q8 >> 2) + L::fb(q8 & 3, h);
                     const f32x4 a = ga[batch][k], b = gb[batch][k];
-                    const f32x4 b0 = *(const __attribute__((address_space(3))) f32x4*)(par_in + 8 * q + 4 * h);
-                    const f32x4 wr = *(const __attribute__((address_space(3))) f32x4*)(par_wr + 8 * q + 4 * h);
+                    const f32x4 b0 = *(const __attribute__((address_space(3))) f32x4*)(par_in + off);
+                    const f32x4 wr = *(const __attribute__((address_space(3))) f32x4*)(par_wr + off);
                     // z = log2(e) ((a + b) + b0 + radial wr): b0 and wr are staged pre-scaled, two fused multiply-adds per value
                     float y[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] = silu_first<PREC>(__builtin_fmaf(a[i] + b[i], kLog2e, __builtin_fmaf(radial, wr[i], b0[i])));
-                    put_pair<H>(xa, q >> 2, 4 * (q & 3), y[0], y[1]);
-                    put_pair<H>(xa, q >> 2, 4 * (q & 3) + 2, y[2], y[3]);
+                    for (int i = 0; i < 4; ++i) y[i] = silu_first<PREC>(__builtin_fmaf(a[i] + b[i], kLog2e, __builtin_fmaf(radial[es], wr[i], b0[i])));
+                    put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3), y[0], y[1]);
+                    put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3) + 2, y[2], y[3]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            // the row itself (the caller's activations, carried as log2(e) x inside the chain)
-            const float* px = p.rows_in + e * p.ld_in + 4 * h;
+            // the rows themselves (the caller's activations, carried as 2^b log2(e) x inside the chain)
 #pragma unroll
-            for (int q = 0; q < H / 8; ++q) {
-                const f32x4 a = *(const f32x4*)(px + 8 * q);
+            for (int q8 = 0; q8 < H / 8; ++q8) {
+                const int es = L::es(q8 & 3), off = 32 * (q8 >> 2) + L::fb(q8 & 3, h);
+                const f32x4 a = *(const f32x4*)(p.rows_in + e[es] * p.ld_in + off);
+                if constexpr (SPLIT) {
+                    put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3), a[0] * kIn, a[1] * kIn);
+                    put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3) + 2, a[2] * kIn, a[3] * kIn);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) put<H>(xa, q >> 2, 4 * (q & 3) + i, a[i] * kIn);
-                if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < 4; ++i) put<H>(xa, q8 >> 2, 4 * (q8 & 3) + i, a[i] * kIn);
+                }
+                if ((q8 & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
         }
         MDX_STAMP_ALWAYS(10);
@@ -807,7 +947,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             MDX_STAMP(4);
             f32x16 acc = acc_next;
 #ifndef MDX_CHAIN_NO_STAGED      // (-DMDX_CHAIN_NO_STAGED: the plain per-step epilogue everywhere, for A/B timing)
-            constexpr bool STAGED = PREC == 1 && kScaled && STEPS == 16;
+            constexpr bool STAGED = SPLIT && kScaled && STEPS == 16;
 #else
             constexpr bool STAGED = false;
 #endif
@@ -829,6 +969,11 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 16))
                 if constexpr (STAGED) {
                     if (have) pipe.template step<PREC>(s, tp, pend, epi_dst, epi_sc, ROWS && linear);
+                } else if constexpr (W16) {
+                    // (16x16 shape: ALL sixteen values of the pending tile are elements of ONE k-step of the next layer, the one
+                    // this tile reads in its last two steps when it is that layer's first tile: complete before those steps)
+                    constexpr int D = STEPS > 2 ? STEPS - 2 : 1;
+                    if (have && s < D) epilogue_elements<H, PREC>(tp, 16 * s / D, 16 * (s + 1) / D, pend, epi_dst, epi_sc, ROWS && linear);
                 } else {
                     if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, epi_sc, ROWS && linear);
                 }
@@ -843,6 +988,24 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     for (int i = 0; i < 4; ++i) {
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s].f[i], in.v[4 * s + i], acc, 0, 0, 0);
                         if (C::SPREAD && i == 0 && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
+                    }
+                } else if constexpr (W16) {
+                    // step s = 2 ks + rho: the fragment of row tile rho (16 rows x 32 k) against k-step ks of both column groups;
+                    // the same A operand four times in a row, the two accumulators alternating
+                    const int ks = s >> 1, rho = s & 1;
+                    f32x4 a0 = {acc[8 * rho], acc[8 * rho + 1], acc[8 * rho + 2], acc[8 * rho + 3]};
+                    f32x4 a1 = {acc[8 * rho + 4], acc[8 * rho + 5], acc[8 * rho + 6], acc[8 * rho + 7]};
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.hi[0][ks], a0, 0, 0, 0);
+                    if (C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.hi[1][ks], a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.lo[0][ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.lo[1][ks], a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].lo, in.hi[0][ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].lo, in.hi[1][ks], a1, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[8 * rho + i] = a0[i];
+                        acc[8 * rho + 4 + i] = a1[i];
                     }
                 } else {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].hi, in.hi[s], acc, 0, 0, 0);
@@ -909,108 +1072,103 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         // messages = the operand registers of the first coordinate layer, complete once its first tile has run
         auto store_messages = [&](const Act<H, PREC>& m) {
 #if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 1)
-            if (e_raw >= 0) return;
+            if (e_raw[0] >= 0) return;
 #endif
             // every wavefront issues exactly H / 8 store instructions (lanes beyond the edge count masked off, the address
             // clamped): the next chunk wait counts on them (Chain::stores_behind)
-            float* row = p.messages + e * H + 4 * h;
-            if (live) {
 #pragma unroll
-            for (int q = 0; q < H / 8; ++q) {
-                f32x4 y;
-                const int t = q >> 2, r0 = 4 * (q & 3);
-                if constexpr (PREC == 0) {
+            for (int q8 = 0; q8 < H / 8; ++q8) {
+                const int t = q8 >> 2, q = q8 & 3, es = L::es(q);
+                f32x4 y = get4<H>(m, t, q);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] = m.v[16 * t + r0 + i] * kOut;
-                } else {
-                    // hi + lo in one instruction per value: v_fma_mix_f32 with both addends taken from the packed halves
-                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 vh = __builtin_bit_cast(u32x4, m.hi[2 * t + (r0 >> 3)]), vl = __builtin_bit_cast(u32x4, m.lo[2 * t + (r0 >> 3)]);
+                for (int i = 0; i < 4; ++i) y[i] *= kOut;
+                if constexpr (SPLIT) {
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const uint32_t ph = vh[((r0 & 7) >> 1) + pr], pl = vl[((r0 & 7) >> 1) + pr];
-                        float y0, y1;
-                        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(ph), "v"(pl));
-                        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(y1) : "v"(ph), "v"(pl));
-                        y[2 * pr] = y0 * kOut;
-                        y[2 * pr + 1] = y1 * kOut;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) out_of_range = out_of_range || !(__builtin_fabsf(y[i]) <= 3.0e38f);
+                    for (int i = 0; i < 4; ++i) out_of_range = out_of_range || (is_live(es) && !(__builtin_fabsf(y[i]) <= 3.0e38f));
                 }
-                *(f32x4*)(row + 8 * q) = y;
+                if (is_live(es)) *(f32x4*)(p.messages + e[es] * H + 32 * t + L::fb(q, h)) = y;
             }
-            }
-            ch.stores_behind = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(live) != 0);
+            bool any_live = is_live(0);
+            if constexpr (NS == 2) any_live = any_live || is_live(1);
+            ch.stores_behind = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(any_live) != 0);
         };
         // Message aggregation inside the kernel (piece_sums): the edges are sorted by source node, so a node's edges are a
-        // run of consecutive edges = consecutive lanes of the accumulator layout (lane = 32 h + edge).  A PIECE = a node's
-        // edges inside one 16-edge group = inside one DPP row; its sum is a segmented scan over the row, four
-        // shift-and-add steps (`row_shr` 1, 2, 4, 8, each gated by "the edge that far down is in my piece") on the
-        // registers where the messages already are -- no staging, no transposition.  The lane of a piece's LAST edge then
-        // holds the piece sum of its 128 features and writes them to that edge's row; mdx_segment_combine adds a node's
-        // pieces (its last row and every row = 15 mod 16 inside its segment) in row order: fixed order, no atomics.  The
-        // messages themselves never reach memory.  Returns the number of store instructions issued (for the next chunk wait).
+        // run of consecutive edges = consecutive lanes of the accumulator layout (32x32 shapes: lane = 32 h + edge; 16x16 shape:
+        // lane = 16 g + edge within column group cg).  A PIECE = a node's edges inside one 16-edge group = inside one DPP row;
+        // its sum is a segmented scan over the row, four shift-and-add steps (`row_shr` 1, 2, 4, 8, each gated by "the edge
+        // that far down is in my piece") on the registers where the messages already are -- no staging, no transposition.  The
+        // lane of a piece's LAST edge then holds the piece sum of its feature quads and writes them to the piece's row of the
+        // compact buffer; mdx_segment_combine adds a node's pieces in edge order: fixed order, no atomics.  The messages
+        // themselves never reach memory.  Returns a lower bound of the store instructions issued (for the next chunk wait).
         auto aggregate_pieces = [&](const Act<H, PREC>& m) -> int {
             const int64_t wave_base = tile * kTileEdges + wave * 32;
             const int n_live = n_edges - wave_base >= 32 ? 32 : (n_edges > wave_base ? (int)(n_edges - wave_base) : 0);
             const int c16 = col & 15;
-            const int my_src = seg_src[col];
-            float gate[4];                                  // 1.0: the edge 1 / 2 / 4 / 8 below is in this lane's piece
+            float gate[NS][4];                              // 1.0: the edge 1 / 2 / 4 / 8 below is in this lane's piece
+            bool ends[NS];
+            float* row[NS];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int d = 1 << k;
-                gate[k] = (c16 >= d && seg_src[c16 >= d ? col - d : col] == my_src) ? 1.0f : 0.0f;
+            for (int es = 0; es < NS; ++es) {
+                const int pos = (W16 ? 16 * es : 0) + col;          // position among the wavefront's 32 edges
+                const int my_src = seg_src[pos];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int d = 1 << k;
+                    gate[es][k] = (c16 >= d && seg_src[c16 >= d ? pos - d : pos] == my_src) ? 1.0f : 0.0f;
+                }
+                ends[es] = pos < n_live && (c16 == 15 || pos + 1 >= n_live || seg_src[pos + 1 < 32 ? pos + 1 : pos] != my_src);
+                // Compact piece rows (no [E, H] buffer): a piece that ends on a 16-edge boundary goes to row e / 16; any other
+                // piece end is the LAST edge of its node (the next edge has another source, and it is inside this wavefront's
+                // 32 edges because its position is not 15 mod 16) and goes to the node's own row behind the ceil(capacity / 16)
+                // boundary rows.
+                const int64_t e_mine = wave_base + pos;
+                const int64_t piece_row = c16 == 15 ? (e_mine >> 4) : ((p.n_edges + 15) >> 4) + (int64_t)my_src;
+                row[es] = p.messages + piece_row * H;
             }
-            const bool ends = col < n_live && (c16 == 15 || col + 1 >= n_live || seg_src[col + 1 < 32 ? col + 1 : col] != my_src);
-            // Compact piece rows (no [E, H] buffer): a piece that ends on a 16-edge boundary goes to row e / 16; any other piece
-            // end is the LAST edge of its node (the next edge has another source, and it is inside this wavefront's 32 edges
-            // because its position is not 15 mod 16) and goes to the node's own row behind the ceil(capacity / 16) boundary rows.
-            const int64_t e_mine = wave_base + col;
-            const int64_t piece_row = c16 == 15 ? (e_mine >> 4) : ((p.n_edges + 15) >> 4) + (int64_t)my_src;
-            float* row = p.messages + piece_row * H + 4 * h;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                float x[16];                                // features 32 t + 8 g + 4 h + i of this lane's edge, x[4 g + i]
+                float x[16];                                // the sixteen values of tile t, as they lie in the accumulator layout
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if constexpr (PREC == 0) {
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 y = get4<H>(m, t, q);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) x[4 * g + i] = m.v[16 * t + 4 * g + i] * kOut;
-                    } else {
-                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                        const int r0 = 4 * g;
-                        const u32x4 vh = __builtin_bit_cast(u32x4, m.hi[2 * t + (r0 >> 3)]), vl = __builtin_bit_cast(u32x4, m.lo[2 * t + (r0 >> 3)]);
+                    for (int i = 0; i < 4; ++i) x[4 * q + i] = y[i] * kOut;
+                }
+                if constexpr (NS == 1) {
+                    segmented_step<1>(x, gate[0][0]);
+                    segmented_step<2>(x, gate[0][1]);
+                    segmented_step<4>(x, gate[0][2]);
+                    segmented_step<8>(x, gate[0][3]);
+                } else {
+                    // (registers 4 q .. 4 q + 3 belong to edge es(q) = q & 1: the gates of that edge)
+                    float g2[16];
 #pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            const uint32_t ph = vh[((r0 & 7) >> 1) + pr], pl = vl[((r0 & 7) >> 1) + pr];
-                            float y0, y1;
-                            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(ph), "v"(pl));
-                            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(y1) : "v"(ph), "v"(pl));
-                            x[4 * g + 2 * pr] = y0 * kOut;
-                            x[4 * g + 2 * pr + 1] = y1 * kOut;
-                        }
+                    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) g2[r] = gate[L::es(r >> 2)][k];
+                        if (k == 0) segmented_step_gates<1>(x, g2);
+                        else if (k == 1) segmented_step_gates<2>(x, g2);
+                        else if (k == 2) segmented_step_gates<4>(x, g2);
+                        else segmented_step_gates<8>(x, g2);
                     }
                 }
-                segmented_step<1>(x, gate[0]);
-                segmented_step<2>(x, gate[1]);
-                segmented_step<4>(x, gate[2]);
-                segmented_step<8>(x, gate[3]);
-                if (ends) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        // (split-f16: no range check here -- a message beyond the f16 range is an infinity or a NaN in
-                        // the operand registers the coordinate layers read next, and reaches this edge's head output,
-                        // which is checked)
-                        const f32x4 y = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
-                        *(f32x4*)(row + 32 * t + 8 * g) = y;
+                for (int q = 0; q < 4; ++q) {
+                    // (split-f16: no range check here -- a message beyond the f16 range is an infinity or a NaN in
+                    // the operand registers the coordinate layers read next, and reaches this edge's head output,
+                    // which is checked)
+                    if (ends[L::es(q)]) {
+                        const f32x4 y = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+                        *(f32x4*)(row[L::es(q)] + 32 * t + L::fb(q, h)) = y;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);         // one slice at a time: the register file is full here
             }
-            // store instructions this wavefront issued: H / 8, each with the piece-end lanes active (none: none issued)
-            const bool any = __builtin_amdgcn_ballot_w64(ends) != 0;
-            return any ? H / 8 : 0;
+            // store instructions this wavefront issued: per edge slot H / (8 NS), each with the piece-end lanes active (none: none)
+            int count = 0;
+#pragma unroll
+            for (int es = 0; es < NS; ++es) count += __builtin_amdgcn_ballot_w64(ends[es]) != 0 ? H / (8 * NS) : 0;
+            return count;
         };
         // The aggregation phase needs registers of its own while both operand sets are live: the next tile's prefetched
         // fragments and initial accumulator (32 registers) are simply read again from LDS afterwards instead of being kept.
@@ -1019,88 +1177,77 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             for (int s2 = 0; s2 < PFD; ++s2) pre[s2] = read_frag(w_cur, s2);
             acc_next = read_bias(bias_row);
         };
-        // the head: one more tile whose image row 0 is w_out (no bias, no activation): s_e = row 0 of the accumulator
+        // the head: one more tile whose image row 0 is w_out (no bias, no activation): s_e = row 0 of the accumulator --
+        // register 0 of the lanes with h == 0 (16x16 shape: registers 0 and 4, the two column groups)
         auto head_tile = [&](Act<H, PREC>& in) {
-            Act<H, PREC> unused;
             const f32x16 acc = run_tile(in, true, NT - 1, in, par, sc_prev);      // after the head: layer 0, tile 0 of the next edges
-            (void)unused;
-            const float s_e = acc[0] * load_scale(layers).out;            // (the head row is packed as it is: ln 2 comes here)
-            if constexpr (PREC == 1) out_of_range = out_of_range || (live && !(__builtin_fabsf(s_e) <= 3.0e38f));
-            if (live && h == 0) p.edge_scalar[e] = s_e;
+            const float to_out = load_scale(layers).out;                          // (the head row is packed as it is: ln 2 comes here)
+#pragma unroll
+            for (int es = 0; es < NS; ++es) {
+                const float s_e = acc[4 * es] * to_out;
+                if constexpr (SPLIT) out_of_range = out_of_range || (is_live(es) && !(__builtin_fabsf(s_e) <= 3.0e38f));
+                if (is_live(es) && h == 0) p.edge_scalar[e[es]] = s_e;
+            }
         };
         // MODE 1: the last tile of the last (linear) layer has no tile after it to run beside; then out = residual + y
         auto finish_rows = [&](Act<H, PREC>& y, Act<H, PREC>& u) {
             epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, y, sc_prev, true);
             const bool project = MODE == 3 && p.proj_out != nullptr;       // out is also the operand of two more linear layers
-            const float* res = p.residual ? p.residual + e * p.ld_in + 4 * h : nullptr;
-            float* row = p.rows_out + e * H + 4 * h;
-            if (live) {
 #pragma unroll
-                for (int q = 0; q < H / 8; ++q) {
-                    f32x4 v;
-                    const int t = q >> 2, r0 = 4 * (q & 3);
-                    if constexpr (PREC == 0) {
+            for (int q8 = 0; q8 < H / 8; ++q8) {
+                const int t = q8 >> 2, q = q8 & 3, es = L::es(q), off = 32 * t + L::fb(q, h);
+                f32x4 v = get4<H>(y, t, q);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = y.v[16 * t + r0 + i] * kOut;
-                    } else {
-                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                        const u32x4 vh = __builtin_bit_cast(u32x4, y.hi[2 * t + (r0 >> 3)]), vl = __builtin_bit_cast(u32x4, y.lo[2 * t + (r0 >> 3)]);
+                for (int i = 0; i < 4; ++i) v[i] *= kOut;
+                if constexpr (SPLIT) {
 #pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            const uint32_t ph = vh[((r0 & 7) >> 1) + pr], pl = vl[((r0 & 7) >> 1) + pr];
-                            float y0, y1;
-                            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(ph), "v"(pl));
-                            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(y1) : "v"(ph), "v"(pl));
-                            v[2 * pr] = y0 * kOut;
-                            v[2 * pr + 1] = y1 * kOut;
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) out_of_range = out_of_range || !(__builtin_fabsf(v[i]) <= 3.0e38f);
-                    }
-                    if (res) {
-                        const f32x4 r4 = *(const f32x4*)(res + 8 * q);
+                    for (int i = 0; i < 4; ++i) out_of_range = out_of_range || (is_live(es) && !(__builtin_fabsf(v[i]) <= 3.0e38f));
+                }
+                if (is_live(es)) {
+                    if (p.residual) {
+                        const f32x4 r4 = *(const f32x4*)(p.residual + e[es] * p.ld_in + off);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = r4[i] + v[i];
                     }
-                    *(f32x4*)(row + 8 * q) = v;
-                    if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // (bounds the hoisting of the residual loads)
+                    *(f32x4*)(p.rows_out + e[es] * H + off) = v;
                 }
+                if ((q8 & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // (bounds the hoisting of the residual loads)
             }
-            ch.stores_behind = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(live) != 0);
+            bool any_live = is_live(0);
+            if constexpr (NS == 2) any_live = any_live || is_live(1);
+            ch.stores_behind = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(any_live) != 0);
             if constexpr (MODE == 3) {
                 if (project) {
                     // [out W_src^T | out W_dst^T]: 2 NT more tiles, each stored as it is (sixteen tiles per 128 rows: not worth
                     // a pipelined epilogue).  Their operand: the rows just written, read back into the free register set
                     // (filling it while y and the residual are live spills 480 B per lane); this lane reads what it wrote.
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    {
-                        const float* pr = p.rows_out + e * H + 4 * h;
 #pragma unroll
-                        for (int q = 0; q < H / 8; ++q) {
-                            const f32x4 a = *(const f32x4*)(pr + 8 * q);
-                            put_pair<H>(u, q >> 2, 4 * (q & 3), a[0] * kIn, a[1] * kIn);
-                            put_pair<H>(u, q >> 2, 4 * (q & 3) + 2, a[2] * kIn, a[3] * kIn);
-                            if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
-                        }
+                    for (int q8 = 0; q8 < H / 8; ++q8) {
+                        const int es = L::es(q8 & 3), off = 32 * (q8 >> 2) + L::fb(q8 & 3, h);
+                        const f32x4 a = *(const f32x4*)(p.rows_out + e[es] * H + off);
+                        put_pair<H>(u, q8 >> 2, 4 * (q8 & 3), a[0] * kIn, a[1] * kIn);
+                        put_pair<H>(u, q8 >> 2, 4 * (q8 & 3) + 2, a[2] * kIn, a[3] * kIn);
+                        if ((q8 & 15) == 15) __builtin_amdgcn_sched_barrier(0);
                     }
-                    float* prow = p.proj_out + e * 2 * H + 4 * h;
 #pragma unroll 1
                     for (int t2 = 0; t2 < 2 * NT; ++t2) {
                         if constexpr (C::SPREAD) ch.scalar_addresses();    // (loop-carried: see scalar_addresses)
                         const f32x16 acc = run_tile(u, false, 0, u, t2 + 1 < 2 * NT ? nullptr : par, sc_prev);
                         const float to_out = load_scale(layers + t2 / NT).out;
-                        if (live) {
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const f32x4 v = {acc[4 * g] * to_out, acc[4 * g + 1] * to_out, acc[4 * g + 2] * to_out, acc[4 * g + 3] * to_out};
-                                if constexpr (PREC == 1) {
+                        for (int q = 0; q < 4; ++q) {
+                            const int es = L::es(q);
+                            const f32x4 v = {acc[4 * q] * to_out, acc[4 * q + 1] * to_out, acc[4 * q + 2] * to_out, acc[4 * q + 3] * to_out};
+                            if constexpr (SPLIT) {
 #pragma unroll
-                                    for (int i = 0; i < 4; ++i) out_of_range = out_of_range || !(__builtin_fabsf(v[i]) <= 3.0e38f);
-                                }
-                                *(f32x4*)(prow + 32 * t2 + 8 * g) = v;
+                                for (int i = 0; i < 4; ++i) out_of_range = out_of_range || (is_live(es) && !(__builtin_fabsf(v[i]) <= 3.0e38f));
                             }
+                            if (is_live(es)) *(f32x4*)(p.proj_out + e[es] * 2 * H + 32 * t2 + L::fb(q, h)) = v;
                         }
-                        ch.stores_count = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(live) != 0) ? 4 : 0;
+                        bool any = is_live(0);
+                        if constexpr (NS == 2) any = any || is_live(1);
+                        ch.stores_count = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(any) != 0) ? 4 / NS : 0;
                     }
                 }
             }
@@ -1114,15 +1261,18 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 park(xb, t, acc);
             }
             // the operand registers again, with agg (columns H .. 2H-1 of the row)
-            {
-                const float* px = p.rows_in + e * p.ld_in + H + 4 * h;
 #pragma unroll
-                for (int q = 0; q < H / 8; ++q) {
-                    const f32x4 a = *(const f32x4*)(px + 8 * q);
+            for (int q8 = 0; q8 < H / 8; ++q8) {
+                const int es = L::es(q8 & 3), off = 32 * (q8 >> 2) + L::fb(q8 & 3, h);
+                const f32x4 a = *(const f32x4*)(p.rows_in + e[es] * p.ld_in + H + off);
+                if constexpr (SPLIT) {
+                    put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3), a[0] * kIn, a[1] * kIn);
+                    put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3) + 2, a[2] * kIn, a[3] * kIn);
+                } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) put<H>(xa, q >> 2, 4 * (q & 3) + i, a[i] * kIn);
-                    if ((q & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < 4; ++i) put<H>(xa, q8 >> 2, 4 * (q8 & 3) + i, a[i] * kIn);
                 }
+                if ((q8 & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
             // pass B: layer 1 = the second half on agg, every tile started from its parked accumulator
             acc_next = unpark(xb, 0);
@@ -1188,7 +1338,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     MDX_STAMP_WRITE(24, ch.dma_cycles);
     MDX_STAMP_WRITE(25, ch.dma_count);
 #endif
-    if constexpr (PREC == 1) {
+    if constexpr (SPLIT) {
         if (p.status && out_of_range) atomicOr(p.status, MDX_STATUS_EGNN_F16_RANGE);
     }
 }
@@ -1269,9 +1419,14 @@ __global__ __launch_bounds__(256) void egnn_chain_pack_kernel(PackArgs p)
             const int n = 32 * t + (lane & 31), k = 8 * q + 4 * (lane >> 5) + i;
             ((float*)p.image)[idx] = weight(n, k);
         } else {
-            // chunk: [s = H/16][hi: lane 64 x 8 halfs | lo: lane 64 x 8 halfs]; element j: k = 16 s + 8 (j >> 2) + 4 h + (j & 3)
+            // chunk: [s = H/16][hi: lane 64 x 8 halfs | lo: lane 64 x 8 halfs];
+            //   precision 1 (32x32x16): lane = row 32 t + (lane & 31), element j: k = 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3)
+            //   precision 2 (16x16x32): fragment s = 2 ks + rho: row 32 t + 16 rho + (lane & 15),
+            //                           element j: k = 32 ks + 16 (j >> 2) + 4 (lane >> 4) + (j & 3)
             const int s = (int)(r / 512), lane = (int)(r % 512) / 8, j = (int)(r % 8);
-            const int n = 32 * t + (lane & 31), k = 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+            const int n = p.precision == 1 ? 32 * t + (lane & 31) : 32 * t + 16 * (s & 1) + (lane & 15);
+            const int k = p.precision == 1 ? 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)
+                                           : 32 * (s >> 1) + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
             const float v = weight(n, k) * pow2_bits(p.exps[l]);      // exact (a power of two; |v| < 2^14)
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)(v - (float)hi);
@@ -1377,8 +1532,8 @@ int64_t mdx_egnn_chain_image_bytes(int hidden, int n_layers)
 int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, const float* w_out, int hidden, int precision,
                         uint32_t tied_layers, void* image_out, int32_t* exponents_out, mdx_stream_t stream)
 {
-    if (!weights_host || !image_out || n_layers < 1 || (precision != 0 && precision != 1)) return MDX_ERR_INVALID_ARG;
-    if (precision == 1 && !exponents_out) return MDX_ERR_INVALID_ARG;
+    if (!weights_host || !image_out || n_layers < 1 || precision < 0 || precision > 2) return MDX_ERR_INVALID_ARG;
+    if (precision >= 1 && !exponents_out) return MDX_ERR_INVALID_ARG;
     if (n_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     if (hidden != 32 && hidden != 64 && hidden != 128 && hidden != 256) return MDX_ERR_UNSUPPORTED;
     PackArgs a{};
@@ -1392,7 +1547,7 @@ int mdx_egnn_chain_pack(const float* const* weights_host, int n_layers, const fl
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (exponents_out) {
         if (hipMemsetAsync(exponents_out, 0, sizeof(int32_t) * (n_layers + 1), st) != hipSuccess) return MDX_ERR_HIP;
-        if (precision == 1) {
+        if (precision >= 1) {
             hipLaunchKernelGGL(egnn_chain_maxabs_kernel, dim3(32, (unsigned)n_layers + 1), dim3(256), 0, st, a);
             hipLaunchKernelGGL(egnn_chain_exponents_kernel, dim3(1), dim3(64), 0, st, a);
         }
@@ -1409,14 +1564,14 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
                         float* edge_scalar_out, uint32_t* status, mdx_stream_t stream)
 {
     if (!c || n_edges < 0 || coord_dimension < 1) return MDX_ERR_INVALID_ARG;
-    if (c->n_message_layers < 1 || c->n_coord_layers < 1 || (c->precision != 0 && c->precision != 1) ||
+    if (c->n_message_layers < 1 || c->n_coord_layers < 1 || (c->precision < 0 || c->precision > 2) ||
         (c->message_mode != MDX_EGNN_MESSAGES_ROWS && c->message_mode != MDX_EGNN_MESSAGES_PIECE_SUMS))
         return MDX_ERR_INVALID_ARG;
     if (c->n_message_layers + c->n_coord_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     if (c->hidden != 32 && c->hidden != 64 && c->hidden != 128 && c->hidden != 256) return MDX_ERR_UNSUPPORTED;
     if (n_edges == 0) return MDX_OK;
     if (!c->weight_image || !c->biases || !c->bias_in || !c->w_radial || !node_proj || !coord || !edges ||
-        !messages_out || !edge_scalar_out || (c->precision == 1 && !c->weight_exponents))
+        !messages_out || !edge_scalar_out || (c->precision >= 1 && !c->weight_exponents))
         return MDX_ERR_INVALID_ARG;
     ChainArgs a{};
     a.image = (const char*)c->weight_image; a.biases = c->biases; a.bias_in = c->bias_in; a.w_radial = c->w_radial;
@@ -1435,8 +1590,8 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define MDX_CHAIN_CASE(HH)                                                                                            \
     case HH:                                                                                                          \
-        if (a.piece_sums) return c->precision == 0 ? launch_chain<HH, 0, 2>(a, layers, st) : launch_chain<HH, 1, 2>(a, layers, st); \
-        return c->precision == 0 ? launch_chain<HH, 0, 0>(a, layers, st) : launch_chain<HH, 1, 0>(a, layers, st);
+        if (a.piece_sums) return c->precision == 0 ? launch_chain<HH, 0, 2>(a, layers, st) : (c->precision == 1 ? launch_chain<HH, 1, 2>(a, layers, st) : launch_chain<HH, 2, 2>(a, layers, st)); \
+        return c->precision == 0 ? launch_chain<HH, 0, 0>(a, layers, st) : (c->precision == 1 ? launch_chain<HH, 1, 0>(a, layers, st) : launch_chain<HH, 2, 0>(a, layers, st));
     switch (c->hidden) {
         MDX_CHAIN_CASE(32)
         MDX_CHAIN_CASE(64)
@@ -1471,11 +1626,11 @@ int mdx_mlp_chain_rows(const mdx_egnn_chain_t* c, const float* x, const float* r
                        const int64_t* n_rows_dev, float* out, uint32_t* status, mdx_stream_t stream)
 {
     if (!c || n_rows < 0) return MDX_ERR_INVALID_ARG;
-    if (c->n_message_layers < 1 || c->n_coord_layers != 0 || (c->precision != 0 && c->precision != 1)) return MDX_ERR_INVALID_ARG;
+    if (c->n_message_layers < 1 || c->n_coord_layers != 0 || (c->precision < 0 || c->precision > 2)) return MDX_ERR_INVALID_ARG;
     if (c->n_message_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     if (c->hidden != 32 && c->hidden != 64 && c->hidden != 128 && c->hidden != 256) return MDX_ERR_UNSUPPORTED;
     if (n_rows == 0) return MDX_OK;
-    if (!c->weight_image || !c->biases || !x || !out || (c->precision == 1 && !c->weight_exponents)) return MDX_ERR_INVALID_ARG;
+    if (!c->weight_image || !c->biases || !x || !out || (c->precision >= 1 && !c->weight_exponents)) return MDX_ERR_INVALID_ARG;
     ChainArgs a{};
     a.image = (const char*)c->weight_image; a.biases = c->biases; a.exps = c->weight_exponents;
     a.n_edges_dev = n_rows_dev; a.n_edges = n_rows; a.n_message = c->n_message_layers; a.n_coord = 0; a.D = 0;
@@ -1483,7 +1638,7 @@ int mdx_mlp_chain_rows(const mdx_egnn_chain_t* c, const float* x, const float* r
     const int layers = a.n_message;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define MDX_ROWS_CASE(HH)                                                                          \
-    case HH: return c->precision == 0 ? launch_chain<HH, 0, 1>(a, layers, st) : launch_chain<HH, 1, 1>(a, layers, st);
+    case HH: return c->precision == 0 ? launch_chain<HH, 0, 1>(a, layers, st) : (c->precision == 1 ? launch_chain<HH, 1, 1>(a, layers, st) : launch_chain<HH, 2, 1>(a, layers, st));
     switch (c->hidden) {
         MDX_ROWS_CASE(32)
         MDX_ROWS_CASE(64)
@@ -1498,11 +1653,11 @@ int mdx_node_mlp_rows(const mdx_egnn_chain_t* c, const float* node_in, int add_r
                       const int64_t* n_rows_dev, float* out, float* proj_out, uint32_t* status, mdx_stream_t stream)
 {
     if (!c || n_rows < 0) return MDX_ERR_INVALID_ARG;
-    if (c->n_message_layers < 3 || c->n_coord_layers != 0 || (c->precision != 0 && c->precision != 1)) return MDX_ERR_INVALID_ARG;
+    if (c->n_message_layers < 3 || c->n_coord_layers != 0 || (c->precision < 0 || c->precision > 2)) return MDX_ERR_INVALID_ARG;
     if (c->n_message_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     if (c->hidden != 32 && c->hidden != 64 && c->hidden != 128 && c->hidden != 256) return MDX_ERR_UNSUPPORTED;
     if (n_rows == 0) return MDX_OK;
-    if (!c->weight_image || !c->biases || !node_in || !out || (c->precision == 1 && !c->weight_exponents)) return MDX_ERR_INVALID_ARG;
+    if (!c->weight_image || !c->biases || !node_in || !out || (c->precision >= 1 && !c->weight_exponents)) return MDX_ERR_INVALID_ARG;
     ChainArgs a{};
     a.image = (const char*)c->weight_image; a.biases = c->biases; a.exps = c->weight_exponents;
     a.n_edges_dev = n_rows_dev; a.n_edges = n_rows; a.n_message = c->n_message_layers; a.n_coord = 0; a.D = 0;
@@ -1513,7 +1668,7 @@ int mdx_node_mlp_rows(const mdx_egnn_chain_t* c, const float* node_in, int add_r
     const int layers = a.n_message;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define MDX_NODE_CASE(HH)                                                                          \
-    case HH: return c->precision == 0 ? launch_chain<HH, 0, 3>(a, layers, st) : launch_chain<HH, 1, 3>(a, layers, st);
+    case HH: return c->precision == 0 ? launch_chain<HH, 0, 3>(a, layers, st) : (c->precision == 1 ? launch_chain<HH, 1, 3>(a, layers, st) : launch_chain<HH, 2, 3>(a, layers, st));
     switch (c->hidden) {
         MDX_NODE_CASE(32)
         MDX_NODE_CASE(64)

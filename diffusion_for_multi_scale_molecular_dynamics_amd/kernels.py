@@ -570,7 +570,10 @@ def segment_rows(data, offsets, degree, mean: bool) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------------------------
 # fused EGNN edge chain on the matrix cores (csrc/mdx_egnn_chain.hip)
 # ----------------------------------------------------------------------------------------------------------------
-EDGE_CHAIN_PRECISIONS = {"f32": 0, "f16x3": 1}
+# "f32": exact binary32 MFMA (v_mfma_f32_32x32x2_f32); "f16x3": split-f16, three products per term, on
+# v_mfma_f32_16x16x32_f16 (the default since round 3: the chip holds a higher clock on this shape); "f16x3_32x32": the same
+# arithmetic on v_mfma_f32_32x32x16_f16 (the round-2 kernel, kept for A/B runs and as a second implementation in the tests)
+EDGE_CHAIN_PRECISIONS = {"f32": 0, "f16x3": 2, "f16x3_32x32": 1}
 
 
 def _pack_chain_image(weights, w_out, H: int, precision: str, tied_layers: int = 0):

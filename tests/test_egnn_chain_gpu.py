@@ -33,10 +33,11 @@ def _chain_reference(lin0, msg, crd, out, n_in, h, coord, edges):
 
 
 # tolerance per arithmetic mode: rel-L2 of the [E, H] messages and of the per-edge scalar against fp64
-TOLERANCE = {"f32": 2e-6, "f16x3": 1e-5}
+TOLERANCE = {"f32": 2e-6, "f16x3": 1e-5, "f16x3_32x32": 1e-5}
+CHAIN_MODES = ["f32", "f16x3", "f16x3_32x32"]       # exact-f32 MFMA | split-f16 on 16x16x32 (default) | split-f16 on 32x32x16
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", CHAIN_MODES)
 @pytest.mark.parametrize("H,n_msg,n_crd,n_nodes,deg", [(32, 1, 1, 40, 7), (64, 2, 3, 300, 11), (128, 3, 2, 500, 25),
                                                         (256, 4, 5, 1200, 25), (256, 1, 1, 3, 2)])
 def test_edge_chain_against_fp64(cuda, precision, H, n_msg, n_crd, n_nodes, deg):
@@ -100,7 +101,7 @@ def test_edge_chain_against_fp64(cuda, precision, H, n_msg, n_crd, n_nodes, deg)
         assert (m2[E - 5:] == -7.0).all() and (s2[E - 5:] == -7.0).all()
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", CHAIN_MODES)
 @pytest.mark.parametrize("case", ["small_activations", "tiny_activations", "small_weights", "mixed_weights"])
 def test_edge_chain_small_magnitudes_against_fp64(cuda, precision, case):
     """The UNDERFLOW side of the split-f16 mode.  f16's subnormal step is 2^-24, so an unscaled split v = hi + lo stops
@@ -353,7 +354,7 @@ def test_radius_graph_static_equals_two_call(cuda):
     assert torch.equal(guard[:small], ref["edges"][:small]) and (guard[small:] == -5).all()
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", CHAIN_MODES)
 def test_egnn_sampler_graph_replay_equals_eager(cuda, precision):
     """The EGNN sampler iteration (radius graph with a capacity-sized edge list + fused edge chain: no host read) captured
     into a hipGraph and replayed equals the eager run bit for bit; and equals the run with the two-call radius graph."""
@@ -445,7 +446,7 @@ def test_sampler_recomputes_in_f32_when_the_f16_range_is_left(cuda, rng_mode):
     assert float(diff.norm() / outs["f32"][1].X.norm()) < 1e-5
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", CHAIN_MODES)
 @pytest.mark.parametrize("H,n_layers,M,with_residual", [(32, 1, 77, True), (64, 2, 500, False), (128, 3, 129, True),
                                                         (256, 5, 1500, True)])
 def test_mlp_chain_rows_against_fp64(cuda, precision, H, n_layers, M, with_residual):
@@ -477,7 +478,7 @@ def test_mlp_chain_rows_against_fp64(cuda, precision, H, n_layers, M, with_resid
     assert float(row_err) < 20 * tol, float(row_err)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", CHAIN_MODES)
 @pytest.mark.parametrize("H,n_nodes,deg", [(32, 40, 7), (128, 500, 25), (256, 900, 25), (256, 300, 90), (64, 70, 1)])
 def test_edge_chain_piece_sums_against_fp64(cuda, precision, H, n_nodes, deg):
     """Message aggregation inside the edge chain (MDX_EGNN_MESSAGES_PIECE_SUMS) + mdx_segment_combine against the fp64
@@ -608,7 +609,7 @@ def test_egnn_node_inputs_and_scores_against_torch(cuda):
     assert _rel_l2(got_s, want_s) < 1e-6
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", CHAIN_MODES)
 @pytest.mark.parametrize("H,n_inner,M,with_residual", [(32, 0, 77, True), (64, 1, 500, False), (128, 2, 129, True),
                                                        (256, 4, 1000, True), (256, 0, 5, False)])
 def test_node_mlp_rows_against_fp64(cuda, precision, H, n_inner, M, with_residual):

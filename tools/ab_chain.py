@@ -36,12 +36,15 @@ args = ap.parse_args()
 
 dev = torch.device("cuda:0")
 tree = _hip.LIB_PATH
-names, handles = [], []
+names, handles, modes = [], [], []
 for entry in args.libs.split(","):
+    entry, _, mode = entry.partition(":")          # "lib[:mode]": e.g. tree:f16x3_32x32
+    modes.append(mode or args.mode)
     path = tree if entry == "tree" else os.path.abspath(entry)
     _hip._lib, _hip.LIB_PATH = None, path
     handles.append(_hip.lib())
-    names.append("tree" if entry == "tree" else os.path.basename(path).replace("libmdx_", "").replace(".so", ""))
+    names.append(("tree" if entry == "tree" else os.path.basename(path).replace("libmdx_", "").replace(".so", "")) +
+                 (":" + mode if mode else ""))
 
 torch.manual_seed(0)
 H, n_in = args.hidden, args.hidden
@@ -59,9 +62,9 @@ status = torch.zeros(1, dtype=torch.int32, device=dev)
 
 packs = []
 with torch.no_grad():
-    for h in handles:
+    for h, mode in zip(handles, modes):
         _hip._lib = h
-        packs.append(kernels.EdgeChainPack(lin0, msg, crd, out, input_size=n_in, precision=args.mode))
+        packs.append(kernels.EdgeChainPack(lin0, msg, crd, out, input_size=n_in, precision=mode))
 
 
 def launch(k):

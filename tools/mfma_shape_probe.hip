@@ -1,0 +1,192 @@
+// Probe: does the f16 MFMA SHAPE matter for a kernel with the edge chain's structure?  (round 3; MI355X_MICROARCH.md, DVFS
+// give-back item 7: in bare loops on random data v_mfma_f32_16x16x32 delivered ~1.12-1.15x the FLOP/s of 32x32x16.)
+//
+// Same work in both instantiations: per workgroup (4 wavefronts, one per SIMD, 128 "edges"), `chunks` weight chunks of 32 rows x
+// 256 k (hi | lo f16 halves, 32 KB) streamed global -> LDS by direct-to-LDS loads into a 4-slot ring (one barrier per chunk),
+// fragments read with ds_read_b128, three MFMAs per (A, B) pair (hi.hi, hi.lo, lo.hi), activations in registers as the B
+// operand (128 registers), a SiLU + split epilogue per accumulator value written back into the operand registers.  The
+// values are meaningless (no layer structure); operands are random, finite and stay O(1).
+//   SHAPE 0: v_mfma_f32_32x32x16_f16, 32 columns per wavefront as one tile   (the shipped kernel's shape)
+//   SHAPE 1: v_mfma_f32_16x16x32_f16, 32 columns as two groups of 16, 32 rows as two tiles of 16
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_c;
+
+constexpr int kChunk = 32 * 256 * 4;      // bytes
+
+__device__ __forceinline__ void request(const char* image, uint32_t src_off, uint32_t lds_dst, uint32_t lane16, int piece)
+{
+    const uint64_t src = (uint64_t)(uintptr_t)image + src_off + (uint32_t)((piece >> 2) * 4096);
+    const uint32_t dst = lds_dst + (uint32_t)((piece >> 2) * 4096);
+    switch (piece & 3) {
+        case 0: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:0" ::"v"(lane16), "s"(src), "s"(dst) : "memory"); break;
+        case 1: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(lane16), "s"(src), "s"(dst) : "memory"); break;
+        case 2: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(lane16), "s"(src), "s"(dst) : "memory"); break;
+        default: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(lane16), "s"(src), "s"(dst) : "memory"); break;
+    }
+}
+
+__device__ __forceinline__ void split_pair(float y0, float y1, uint32_t& hi, uint32_t& lo)
+{
+    float l0, l1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(y0), "v"(y1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(y0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(y1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(l0), "v"(l1));
+}
+__device__ __forceinline__ float act(float a, float neg_c, float k)
+{
+    return a * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(a * neg_c), k, k));
+}
+
+template <int SHAPE, int ORDER>
+__global__ __launch_bounds__(256, 1) void probe_kernel(const char* image, int image_chunks, const float* x0, int chunks, float* out,
+                                                       float neg_c, float k)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    lds_c* ring = (lds_c*)lds_raw;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x % 64;
+    const uint32_t lane16 = lane * 16u;
+    const uint32_t share = (uint32_t)(((unsigned)wave + blockIdx.x / 8u) & 3u) * (kChunk / 4);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // operand registers: 16 k-steps (k16) x hi/lo  |  2 column groups x 8 k-steps (k32) x hi/lo -- 128 registers either way
+    half8 xh[16], xl[16];
+    {
+        const float* px = x0 + ((size_t)blockIdx.x * 256 + threadIdx.x) * 128;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            u32x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t hh, ll;
+                split_pair(px[8 * s + 2 * j], px[8 * s + 2 * j + 1], hh, ll);
+                h[j] = hh;
+                l[j] = ll;
+            }
+            xh[s] = __builtin_bit_cast(half8, h);
+            xl[s] = __builtin_bit_cast(half8, l);
+        }
+    }
+    auto issue_chunk_piece = [&](int chunk, int slot, int piece) {
+        const uint32_t src_off = __builtin_amdgcn_readfirstlane((uint32_t)(chunk % image_chunks) * (uint32_t)kChunk + share);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ring + (uint32_t)(slot * kChunk) + share);
+        request(image, src_off, dst, lane16, piece);
+    };
+    // prime: chunks 0 and 1 whole, chunk 2 first half
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) issue_chunk_piece(c, c, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_chunk_piece(2, 2, i);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 pend = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 bias;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = x0[((size_t)blockIdx.x * 256 + threadIdx.x) * 128 + r] * 104857.6f;      // N(0, 0.5) x 2^22 (x0 ~ N(0, 20))
+    for (int c0 = 0; c0 + 8 <= chunks; c0 += 8) {
+#pragma unroll
+      for (int tp = 0; tp < 8; ++tp) {        // (unrolled: tp = the operand k-steps the epilogue rewrites must be a constant index)
+        const int c = c0 + tp;
+        const lds_c* w = ring + (tp & 3) * kChunk;
+        f32x16 acc = bias;                      // (a layer's bias: keeps the pre-activations of order one, as in a real network)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (s == 8) {
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            // weight-stream requests: chunk c + 2's second half in steps 0..6, chunk c + 3's first half in steps 8..14
+            if ((s & 1) == 0) {
+                const int i = s >> 1;
+                if (i < 4) issue_chunk_piece(c + 2, (c + 2) & 3, 4 + i);
+                else issue_chunk_piece(c + 3, (c + 3) & 3, i - 4);
+            }
+            if constexpr (SHAPE == 0) {
+                const half8 ah = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + lane * 16);
+                const half8 al = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + 1024 + lane * 16);
+                if constexpr (ORDER == 0) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[s], acc, 0, 0, 0);
+                } else if constexpr (ORDER == 1) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[s], acc, 0, 0, 0);
+                } else {
+                    // small terms first, into their own... same accumulator, the large product last
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[s], acc, 0, 0, 0);
+                }
+            } else {
+                // k-step of 32 = s >> 1, row tile = s & 1: fragments of 16 rows x 32 k; column groups 0 / 1 = operand sets
+                // xh[0..7] / xh[8..15]; accumulators: acc[4 (2 rt + cg) .. +3]
+                const int ks = s >> 1, rt = s & 1;
+                const half8 ah = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + lane * 16);
+                const half8 al = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + 1024 + lane * 16);
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) {
+                    f32x4 a4 = {acc[4 * (2 * rt + cg)], acc[4 * (2 * rt + cg) + 1], acc[4 * (2 * rt + cg) + 2], acc[4 * (2 * rt + cg) + 3]};
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[8 * cg + ks], a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[8 * cg + ks], a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[8 * cg + ks], a4, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[4 * (2 * rt + cg) + i] = a4[i];
+                }
+            }
+            // epilogue of the previous chunk, one value per step: pairs written at odd steps into k-steps 2 tp, 2 tp + 1
+            if (s & 1) {
+                const int r = s - 1;
+                uint32_t h, l;
+                split_pair(act(pend[r], neg_c, k), act(pend[r + 1], neg_c, k), h, l);
+                u32x4 vh = __builtin_bit_cast(u32x4, xh[2 * tp + (r >> 3)]), vl = __builtin_bit_cast(u32x4, xl[2 * tp + (r >> 3)]);
+                vh[(r & 7) >> 1] = h;
+                vl[(r & 7) >> 1] = l;
+                xh[2 * tp + (r >> 3)] = __builtin_bit_cast(half8, vh);
+                xl[2 * tp + (r >> 3)] = __builtin_bit_cast(half8, vl);
+            }
+        }
+        pend = acc;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += pend[r];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) sum += (float)xh[s][0] + (float)xl[s][1];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
+template <int SHAPE, int ORDER>
+static int launch_one(const void* image, int image_chunks, const float* x0, int chunks, float* out, int grid, float neg_c, float k,
+                      hipStream_t st)
+{
+    static bool granted = false;
+    if (!granted) {
+        if (hipFuncSetAttribute((const void*)probe_kernel<SHAPE, ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+        granted = true;
+    }
+    hipLaunchKernelGGL((probe_kernel<SHAPE, ORDER>), dim3(grid), dim3(256), 4 * (size_t)kChunk, st, (const char*)image, image_chunks, x0, chunks, out, neg_c, k);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int probe_launch(int shape, const void* image, int image_chunks, const float* x0, int chunks, float* out, int grid,
+                            float neg_c, float k, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (shape) {                     // shape = 0 / 1: the two MFMA shapes; 10 + o: 32x32x16 with product order o
+        case 0: return launch_one<0, 0>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);
+        case 1: return launch_one<1, 0>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);
+        case 11: return launch_one<0, 1>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);
+        case 12: return launch_one<0, 2>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);
+    }
+    return -3;
+}

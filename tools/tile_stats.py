@@ -62,7 +62,7 @@ for ln in lines[start:end]:
 segs.append(cur)
 
 
-n_mfma = 48 if prec == "1" else 128
+n_mfma = {"0": 128, "1": 48, "2": 96}[prec]
 
 
 def cost(op, arg):
@@ -98,7 +98,7 @@ for s in tiles:
         if op.startswith("v_mfma"):
             c["mfma"] += 1
             start_t = max(t, pipe_free)
-            pipe_free = start_t + 32
+            pipe_free = start_t + (16 if "16x16x32" in op else (64 if "32x32x2" in op else 32))
             t = start_t + 8
             k += 1
             if k % (n_mfma // 16) == 0:
