@@ -315,26 +315,33 @@ def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
     pieces = bool(pack.piece_sums_ok)                 # the mode the network's forward uses (models/egnn.py)
     ms = time_launches(lambda: kernels.egnn_edge_chain(pack, proj, coord, edges, piece_sums=pieces), device, launches)
     flops = 2.0 * edges.shape[0] * H * H * n_layers
-    split = pack.precision == "f16x3"
+    split = pack.precision in ("f16x3", "f16x3_32x32")
+    shape16 = pack.precision == "f16x3"
     executed = flops * (3 if split else 1) / (ms * 1e-3) / 1e12
     peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
-    traffic = None              # HBM-side bytes per launch from a separate PMC pass (profiles/traffic_r02.json), C3 shape only
+    traffic = None              # HBM-side bytes per launch from separate PMC passes (profiles/traffic_r03.json), C3 shape only
     try:
-        entry = json.load(open(os.path.join(ROOT, "profiles", "traffic_r02.json")))[f"C3/edge_chain/{pack.precision}"]
+        entry = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json")))[f"C3/edge_chain/{pack.precision}"]
         if abs(edges.shape[0] - 819200) < 0.06 * 819200 and H == 256 and n_layers == 9:
             traffic = entry["bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
+    prec_index = {"f32": 0, "f16x3_32x32": 1, "f16x3": 2}[pack.precision]
+    mfma = {"f32": "v_mfma_f32_32x32x2_f32", "f16x3_32x32": "split-f16: 3 x v_mfma_f32_32x32x16_f16",
+            "f16x3": "split-f16: 3 x v_mfma_f32_16x16x32_f16"}[pack.precision]
+    note = ""
+    if split:
+        note = ("peak = datasheet dense f16 MFMA rate at 2.4 GHz, counting the 3 executed products per algorithmic one.  The chip "
+                "is power-limited on this instruction stream with random operands: measured inside the kernel (s_memtime / "
+                "s_memrealtime) it holds " + ("2.03-2.11 GHz on the 16x16x32 shape" if shape16 else "1.80-1.82 GHz on the 32x32x16 shape") +
+                " and delivers ~1 200 executed TFLOP/s whatever the instruction order; the same stream on all-zero operands runs "
+                "40 % faster (profiles/r03_chain_ablation.md)")
     return dict(bound="mfma", achieved=round(executed, 2), peak=peak, unit="TFLOP/s", frac=round(executed / peak, 4),
-                traffic=traffic, kernel=f"egnn_edge_chain_kernel<{H},{1 if split else 0},{2 if pieces else 0}> ({'split-f16: 3 x v_mfma_f32_32x32x16_f16' if split else 'v_mfma_f32_32x32x2_f32'}"
+                traffic=traffic, kernel=f"egnn_edge_chain_kernel<{H},{prec_index},{2 if pieces else 0}> ({mfma}"
                 f" per product; {n_layers} fused H->H layers + per-node message sums, {edges.shape[0]} edges per launch; 4 launches per "
                 f"network forward)",
                 avg_launch_us=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
-                algorithmic_tflops=round(flops / (ms * 1e-3) / 1e12, 2),
-                note="peak = datasheet dense MFMA rate at 2.4 GHz; measured inside this kernel (s_memtime / s_memrealtime): "
-                     "1.9-2.0 GHz, matrix pipe busy 59 % of the wavefront's cycles; a launch issuing nothing but this "
-                     "kernel's MFMAs, first layer and stores takes 1.9 ms at the C3 shape (profiles/r02_chain_ablation.md)"
-                if split else "")
+                algorithmic_tflops=round(flops / (ms * 1e-3) / 1e12, 2), note=note)
 
 
 def cpu_baseline(w, name, budget_s=15.0, resampling=0):
@@ -457,7 +464,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (with ranks sharing a GPU) exists to rehearse the multi-rank control "
                          "flow on a one-GPU box")
-    ap.add_argument("--egnn-precision", choices=["f32", "f16x3", "library"], default="f16x3",
+    ap.add_argument("--egnn-precision", choices=["f32", "f16x3", "f16x3_32x32", "library"], default="f16x3",
                     help="EGNN workloads: arithmetic of the fused per-edge MFMA kernel -- 'f16x3' (the product's default) "
                          "split-f16 three-product form with binary32 accumulation, binary32-level accuracy (error against fp64 "
                          "equal to the f32 paths': tests/test_egnn_chain_gpu.py); 'f32' exact binary32 MFMA; 'library' = "
@@ -594,9 +601,9 @@ def main():
         job_ms = (trajectory_ms if trajectory_ms is not None else T * ms_per_step) + gather_ms
         value = (batch * world) / (job_ms * 1e-3)
         other_mode = None
-        if not mlp and args.egnn_precision in ("f32", "f16x3"):
+        if not mlp and args.egnn_precision in ("f32", "f16x3", "f16x3_32x32"):
             # the same job through the other arithmetic mode of the edge chain (2 iterations, same timing protocol)
-            other = "f32" if args.egnn_precision == "f16x3" else "f16x3"
+            other = "f32" if args.egnn_precision != "f32" else "f16x3"
             net.edge_chain_precision = other
             loop_o = new_loop()
             advance(loop_o, 1, T)
@@ -663,7 +670,7 @@ def main():
         "value_from": ("one whole %d-iteration trajectory timed end to end (trajectory_ms %.4f) + gather" % (T, trajectory_ms))
         if trajectory_ms is not None else "total_time_steps x ms_per_step + gather",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if mlp or args.egnn_precision != "f16x3" else
+        "dtype": "f32" if mlp or args.egnn_precision not in ("f16x3", "f16x3_32x32") else
         "f32 (per-edge matrix products as split-f16 hi/lo x3 MFMA terms with f32 accumulation: 22-bit products; state, "
         "updates, reductions and every other layer in f32)", "data": "synthetic (random-init score network, uniform-random initial structures)",
         "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": batch, "global_batch": batch * world,

@@ -165,6 +165,104 @@ __global__ __launch_bounds__(256, 1) void probe_kernel(const char* image, int im
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = sum;
 }
 
+
+// SHAPE 2: 16x16x32 with EIGHT wavefronts per workgroup (two per SIMD, 256 registers each), 16 columns per wavefront: the
+// vector work of one wavefront can issue while its partner's MFMAs hold the matrix pipe.  Same work per workgroup (128 columns),
+// the weight-stream requests split over eight wavefronts (4 pieces each per chunk), every wavefront reads every fragment.
+__global__ __launch_bounds__(512, 2) void probe_kernel_8w(const char* image, int image_chunks, const float* x0, int chunks, float* out,
+                                                          float neg_c, float k)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    lds_c* ring = (lds_c*)lds_raw;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x % 64;
+    const uint32_t lane16 = lane * 16u;
+    const uint32_t share = (uint32_t)(((unsigned)wave + blockIdx.x / 8u) & 7u) * (kChunk / 8);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    half8 xh[8], xl[8];
+    {
+        const float* px = x0 + ((size_t)blockIdx.x * 256 + (threadIdx.x & 255)) * 128 + (threadIdx.x >> 8) * 64;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            u32x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t hh, ll;
+                split_pair(px[8 * s + 2 * j], px[8 * s + 2 * j + 1], hh, ll);
+                h[j] = hh;
+                l[j] = ll;
+            }
+            xh[s] = __builtin_bit_cast(half8, h);
+            xl[s] = __builtin_bit_cast(half8, l);
+        }
+    }
+    auto issue_chunk_piece = [&](int chunk, int slot, int piece) {      // piece 0..3 of this wavefront's eighth (4 KB)
+        const uint32_t src_off = __builtin_amdgcn_readfirstlane((uint32_t)(chunk % image_chunks) * (uint32_t)kChunk + share);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ring + (uint32_t)(slot * kChunk) + share);
+        request(image, src_off, dst, lane16, piece);
+    };
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_chunk_piece(c, c, i);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) issue_chunk_piece(2, 2, i);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x8 pend = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x8 bias;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bias[r] = x0[((size_t)blockIdx.x * 256 + (threadIdx.x & 255)) * 128 + r] * 104857.6f;
+    for (int c0 = 0; c0 + 8 <= chunks; c0 += 8) {
+#pragma unroll
+      for (int tp = 0; tp < 8; ++tp) {
+        const int c = c0 + tp;
+        const lds_c* w = ring + (tp & 3) * kChunk;
+        f32x8 acc = bias;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (s == 8) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if ((s & 3) == 0) {
+                const int i = s >> 2;                      // 4 requests per chunk per wavefront
+                if (i < 2) issue_chunk_piece(c + 2, (c + 2) & 3, 2 + i);
+                else issue_chunk_piece(c + 3, (c + 3) & 3, i - 2);
+            }
+            const int ks = s >> 1, rt = s & 1;
+            const half8 ah = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + lane * 16);
+            const half8 al = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + 1024 + lane * 16);
+            f32x4 a4 = {acc[4 * rt], acc[4 * rt + 1], acc[4 * rt + 2], acc[4 * rt + 3]};
+            a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[ks], a4, 0, 0, 0);
+            a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[ks], a4, 0, 0, 0);
+            a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[ks], a4, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[4 * rt + i] = a4[i];
+            // epilogue of the previous chunk: 8 values per wavefront, one pair every fourth step, into k-step tp
+            if ((s & 3) == 3) {
+                const int r = (s >> 2) * 2;
+                uint32_t h, l;
+                split_pair(act(pend[r], neg_c, k), act(pend[r + 1], neg_c, k), h, l);
+                u32x4 vh = __builtin_bit_cast(u32x4, xh[tp]), vl = __builtin_bit_cast(u32x4, xl[tp]);
+                vh[r >> 1] = h;
+                vl[r >> 1] = l;
+                xh[tp] = __builtin_bit_cast(half8, vh);
+                xl[tp] = __builtin_bit_cast(half8, vl);
+            }
+        }
+        pend = acc;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sum += pend[r];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) sum += (float)xh[s][0] + (float)xl[s][1];
+    atomicAdd(&out[(size_t)blockIdx.x * 256 + (threadIdx.x & 255)], sum);
+}
+
 template <int SHAPE, int ORDER>
 static int launch_one(const void* image, int image_chunks, const float* x0, int chunks, float* out, int grid, float neg_c, float k,
                       hipStream_t st)
@@ -187,6 +285,15 @@ extern "C" int probe_launch(int shape, const void* image, int image_chunks, cons
         case 1: return launch_one<1, 0>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);
         case 11: return launch_one<0, 1>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);
         case 12: return launch_one<0, 2>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);
+        case 2: {
+            static bool granted = false;
+            if (!granted) {
+                if (hipFuncSetAttribute((const void*)probe_kernel_8w, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+                granted = true;
+            }
+            hipLaunchKernelGGL(probe_kernel_8w, dim3(grid), dim3(512), 4 * (size_t)kChunk, st, (const char*)image, image_chunks, x0, chunks, out, neg_c, k);
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
     }
     return -3;
 }
