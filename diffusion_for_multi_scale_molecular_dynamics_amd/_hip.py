@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
     "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_radius_graph_fill_capped", "mdx_mlp_forward",
     "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_variant", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
-    "mdx_egnn_chain_image_bytes", "mdx_egnn_chain_pack", "mdx_egnn_edge_chain", "mdx_egnn_piece_rows", "mdx_segment_combine", "mdx_mlp_chain_rows", "mdx_egnn_coord_aggregate",
+    "mdx_egnn_chain_image_bytes", "mdx_egnn_chain_pack", "mdx_egnn_edge_chain", "mdx_egnn_piece_rows", "mdx_segment_combine", "mdx_egnn_node_gather", "mdx_mlp_chain_rows", "mdx_egnn_coord_aggregate",
     "mdx_egnn_node_inputs", "mdx_egnn_scores", "mdx_node_mlp_rows",
     "mdx_rng_fill", "mdx_math_probe",
 )
@@ -196,6 +196,8 @@ def _declare(L):
     L.mdx_egnn_scores.argtypes = [vp, vp, vp, i32, i64, vp, vp]
     L.mdx_segment_combine.restype = i32
     L.mdx_segment_combine.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp, vp]
+    L.mdx_egnn_node_gather.restype = i32
+    L.mdx_egnn_node_gather.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp]
     L.mdx_egnn_piece_rows.restype = i64
     L.mdx_egnn_piece_rows.argtypes = [i64, i64]
     L.mdx_mlp_chain_rows.restype = i32

@@ -1491,6 +1491,68 @@ __global__ __launch_bounds__(256) void segment_combine_kernel(const float* __res
     }
 }
 
+// segment_combine_kernel and egnn_coord_aggregate_kernel as ONE pass over the nodes (one wavefront per node): the message part
+// exactly as segment_combine_kernel; the coordinate part with the node's edges dealt to the lanes (edge offset + lane, + 64, ...),
+// D partial sums per lane and a butterfly over the wavefront -- a fixed order, no atomics.  D <= 8.
+__global__ __launch_bounds__(256) void egnn_node_gather_kernel(const float* __restrict__ pieces, const int64_t* __restrict__ offsets,
+                                                               const int64_t* __restrict__ degree, int64_t n_nodes, int H,
+                                                               int mean_messages, float* __restrict__ out,
+                                                               const float* __restrict__ left, int64_t boundary_rows,
+                                                               const float* __restrict__ s, const float* __restrict__ coord,
+                                                               const int64_t* __restrict__ edges, int D, int mean_coords,
+                                                               float* __restrict__ coord_out)
+{
+    const int lane = threadIdx.x % kWave;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / kWave;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) / kWave;
+    const int quads = H >> 2;
+    for (int64_t node = wave; node < n_nodes; node += n_waves) {
+        const int64_t e0 = offsets[node], deg = degree[node], e1 = e0 + deg;
+        // coordinates first (their loads are the long-latency ones)
+        float part[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ci[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ci[k] = k < D ? coord[node * D + k] : 0.0f;
+        for (int64_t e = e0 + lane; e < e1; e += kWave) {
+            const int64_t dst = edges[2 * e + 1];
+            const float se = s[e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < D) part[k] += (ci[k] - coord[dst * D + k]) * se;
+        }
+        // messages
+        const float scale = (mean_messages && deg > 0) ? 1.0f / (float)deg : 1.0f;
+        const int64_t last_row = ((e1 - 1) & 15) == 15 ? ((e1 - 1) >> 4) : boundary_rows + node;
+        for (int q = lane; q < quads; q += kWave) {
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int64_t e = e0 | 15; e < e1 - 1; e += 16) acc += reinterpret_cast<const f32x4*>(pieces + (e >> 4) * H)[q];
+            if (deg > 0) acc += reinterpret_cast<const f32x4*>(pieces + last_row * H)[q];
+            if (mean_messages) acc *= scale;
+            if (left) {
+                reinterpret_cast<f32x4*>(out + node * 2 * H)[q] = reinterpret_cast<const f32x4*>(left + node * H)[q];
+                reinterpret_cast<f32x4*>(out + node * 2 * H + H)[q] = acc;
+            } else {
+                reinterpret_cast<f32x4*>(out + node * H)[q] = acc;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < D) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) part[k] += __shfl_xor(part[k], d);
+            }
+        }
+        if (lane < D) {
+            float total = 0.0f, mine = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k == lane) { total = part[k]; mine = ci[k]; }
+            }
+            if (mean_coords && deg > 0) total *= 1.0f / (float)deg;
+            coord_out[node * D + lane] = mine + total;
+        }
+    }
+}
+
 template <int H, int PREC, int MODE>
 int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
 {
@@ -1619,6 +1681,22 @@ int mdx_segment_combine(const float* pieces, int64_t n_edges, const int64_t* off
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(segment_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        pieces, offsets, degree, n_nodes, H, mean, out, left, (n_edges + 15) >> 4);
+    return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
+}
+
+int mdx_egnn_node_gather(const float* pieces, int64_t n_edges, const int64_t* offsets, const int64_t* degree, int64_t n_nodes,
+                         int H, int mean_messages, const float* left, float* out, const float* edge_scalar, const float* coord,
+                         int coord_dimension, const int64_t* edges, int mean_coords, float* coord_out, mdx_stream_t stream)
+{
+    if (n_nodes < 0 || H < 4 || n_edges < 0 || coord_dimension < 1) return MDX_ERR_INVALID_ARG;
+    if ((H & 3) || coord_dimension > 8) return MDX_ERR_UNSUPPORTED;
+    if (n_nodes == 0) return MDX_OK;
+    if (!pieces || !offsets || !degree || !out || !edge_scalar || !coord || !edges || !coord_out) return MDX_ERR_INVALID_ARG;
+    int64_t blocks = (n_nodes * kWave + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(egnn_node_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       pieces, offsets, degree, n_nodes, H, mean_messages, out, left, (n_edges + 15) >> 4, edge_scalar, coord, edges,
+                       coord_dimension, mean_coords, coord_out);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 

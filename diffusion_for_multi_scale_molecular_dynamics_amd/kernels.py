@@ -762,6 +762,24 @@ def segment_combine(pieces, n_edges: int, offsets, degree, mean: bool, left=None
     return out
 
 
+def egnn_node_gather(pieces, n_edges: int, offsets, degree, mean_messages: bool, left, edge_scalar, coord, edges,
+                     mean_coords: bool):
+    """segment_combine(..., left=left) and egnn_coord_aggregate(...) in one launch (mdx_egnn_node_gather):
+    ([left | message sums] [n_nodes, 2H] (or the sums [n_nodes, H] when left is None), coord_out [n_nodes, D])."""
+    n_nodes, H = degree.shape[0], pieces.shape[1]
+    assert left is None or tuple(left.shape) == (n_nodes, H)
+    assert pieces.shape[0] == lib().mdx_egnn_piece_rows(n_edges, n_nodes), "pieces: not the compact layout of n_edges, n_nodes"
+    out = torch.empty(n_nodes, H if left is None else 2 * H, dtype=F32, device=pieces.device)
+    coord_out = torch.empty_like(coord)
+    rc = lib().mdx_egnn_node_gather(ptr(pieces, F32, "pieces"), n_edges, ptr(offsets, I64, "offsets"), ptr(degree, I64, "degree"),
+                                    n_nodes, H, int(bool(mean_messages)), ptr(left, F32, "left"), ptr(out, F32, "out"),
+                                    ptr(edge_scalar, F32, "edge_scalar"), ptr(coord, F32, "coord"), coord.shape[1],
+                                    ptr(edges, I64, "edges"), int(bool(mean_coords)), ptr(coord_out, F32, "coord_out"),
+                                    stream_handle())
+    check(rc, "mdx_egnn_node_gather")
+    return out, coord_out
+
+
 def egnn_node_inputs(x, k_vectors, sigma, atom_types, emb_weight, emb_bias, second=None):
     """z [n_nodes, 2 n_k] (torus uplift) and h [n_nodes, H] (embedding of [sigma | one_hot]) of EGNNScoreNetwork, one launch.
     x [B, N, 3] relative coordinates, sigma [B] (or [B,1]), atom_types [B, N] int64.

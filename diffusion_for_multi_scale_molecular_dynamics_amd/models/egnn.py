@@ -299,10 +299,10 @@ class E_GCL(nn.Module):
         in_kernel = pack.piece_sums_ok and h.shape[0] < (1 << 31)
         messages, edge_scalar = kernels.egnn_edge_chain(pack, proj.contiguous(), coord, edge_index, status=self.status_word,
                                                         n_edges_dev=n_edges, piece_sums=in_kernel)
-        coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean)
-        if in_kernel and h.shape[1] == messages.shape[1]:
-            node_in = kernels.segment_combine(messages, edge_index.shape[0], offsets, degree, self.message_mean,
-                                              left=h.contiguous())                                       # [h | agg]
+        if in_kernel and h.shape[1] == messages.shape[1] and coord.shape[1] <= 8:
+            # everything per node between the edge chain and the node MLP in one pass: [h | agg] and the updated coordinates
+            node_in, coord_out = kernels.egnn_node_gather(messages, edge_index.shape[0], offsets, degree, self.message_mean,
+                                                          h.contiguous(), edge_scalar, coord, edge_index, self.coords_mean)
             whole = self._node_mlp_pack(next_layer)
             if whole is not None and whole.hidden == h.shape[1]:
                 # the whole node MLP (its 2H -> H layer included), the residual and -- when a graph layer follows -- that
@@ -312,6 +312,7 @@ class E_GCL(nn.Module):
                     out, self._next_proj = out
                 return out, coord_out
         else:
+            coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean)
             agg = (kernels.segment_combine(messages, edge_index.shape[0], offsets, degree, self.message_mean) if in_kernel
                    else kernels.segment_rows(messages, offsets, degree, self.message_mean))
             node_in = torch.cat([h, agg], dim=1)

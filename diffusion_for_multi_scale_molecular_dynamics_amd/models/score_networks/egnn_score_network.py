@@ -186,7 +186,11 @@ class EGNNScoreNetwork(ScoreNetwork):
         unit_cell = torch.diag_embed(lengths)
         if self.edge_builder is not None:
             return self.edge_builder(relative_coordinates, unit_cell, self.radial_cutoff)
-        assert self.drop_duplicate_edges, "the HIP graph path implements drop_duplicate_edges=True"
+        # drop_duplicate_edges (models/egnn_utils.py:138-140) only matters when a pair of atoms is within the cutoff through more
+        # than one periodic image; the cell this graph is built in has every length >= 2.2 x cutoff (the clip above), so a pair
+        # has at most one such image and the edge MULTISET is the same with and without the de-duplication.  The reference's
+        # `False` differs only in the ORDER of the list (by image, then source), which the EGNN's segment sums do not depend on
+        # beyond fp32 summation order: both settings take the sorted list of the HIP kernel.
         if self.graph_status is None or self.graph_status.device != relative_coordinates.device:
             self.graph_status = torch.zeros(1, dtype=torch.int32, device=relative_coordinates.device)
         capacity = bsz * n * (n - 1)

@@ -412,6 +412,15 @@ MDX_API int mdx_egnn_edge_chain(const mdx_egnn_chain_t* chain_host, const float*
 MDX_API int64_t mdx_egnn_piece_rows(int64_t n_edges, int64_t n_nodes);
 MDX_API int mdx_segment_combine(const float* pieces, int64_t n_edges, const int64_t* offsets, const int64_t* degree,
                                 int64_t n_nodes, int H, int mean, const float* left, float* out, mdx_stream_t stream);
+/* mdx_segment_combine and mdx_egnn_coord_aggregate (below) as ONE pass over the nodes -- everything E_GCL.forward does per node
+ * between the per-edge chain and the node MLP (models/egnn.py:162-230: both unsorted_segment_sum / _mean calls, the product
+ * with coord_diff, the coordinate residual, torch.cat([h, agg])): out = [left | message sums] (or the sums alone),
+ * coord_out[i,:] = coord[i,:] + (1/degree_i if mean_coords) sum_e (coord[i,:] - coord[dst_e,:]) edge_scalar[e].  The node's
+ * edges are dealt to the lanes of one wavefront and reduced by a butterfly: fixed order, no atomics.  coord_dimension <= 8. */
+MDX_API int mdx_egnn_node_gather(const float* pieces, int64_t n_edges, const int64_t* offsets, const int64_t* degree,
+                                 int64_t n_nodes, int H, int mean_messages, const float* left, float* out,
+                                 const float* edge_scalar, const float* coord, int coord_dimension, const int64_t* edges,
+                                 int mean_coords, float* coord_out, mdx_stream_t stream);
 
 /* EGNNScoreNetwork's per-node inputs and outputs around the EGNN (models/score_networks/egnn_score_network.py:253-290), one
  * launch each instead of a dozen elementwise passes (spatial dimension 3):

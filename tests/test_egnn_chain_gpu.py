@@ -258,7 +258,7 @@ def test_egnn_forward_edge_chain_modes(cuda, hidden, n_layers, n_hidden):
              TIME: torch.rand(B, 1, device=cuda), NOISE: torch.rand(B, 1, device=cuda) * 0.2,
              CARTESIAN_FORCES: torch.zeros(B, N, 3, device=cuda)}
     outs = {}
-    for mode in ("f32", "f16x3", None, "plain"):
+    for mode in ("f32", "f16x3", "f16x3_32x32", None, "plain"):
         net.edge_chain_precision = None if mode == "plain" else mode
         for layer in net.egnn.graph_layers:
             layer.use_fused_ops = mode != "plain"
@@ -283,11 +283,18 @@ def test_egnn_forward_edge_chain_modes(cuda, hidden, n_layers, n_hidden):
     for mode, got in outs.items():
         errs[mode] = (_rel_l2(got.X, want.X), _rel_l2(got.A[..., :-1], want.A[..., :-1]))
     print("EGNN forward rel-L2 vs fp64 (scores, logits):", {str(k): tuple(f"{e:.2e}" for e in v) for k, v in errs.items()})
-    for mode in ("f32", "f16x3", None, "plain"):
-        assert errs[mode][0] < 3e-5 and errs[mode][1] < 1e-5, (mode, errs[mode])
-    # the MFMA modes are as accurate as the reference arithmetic (plain PyTorch fp32), within a small factor
-    for mode in ("f32", "f16x3"):
-        assert errs[mode][0] < 4 * errs["plain"][0] + 1e-7 and errs[mode][1] < 4 * errs["plain"][1] + 1e-7, (mode, errs)
+    # (1) against the REFERENCE ARITHMETIC -- the plain PyTorch fp32 module on the same device: north_star's 1e-5.  (The
+    # reference-made fixture at the production shape is tests/test_egnn_c3_reference_gpu.py; this test sweeps widths.)
+    plain = outs["plain"]
+    for mode in ("f32", "f16x3", "f16x3_32x32", None):
+        vs_plain = (_rel_l2(outs[mode].X, plain.X), _rel_l2(outs[mode].A[..., :-1], plain.A[..., :-1]))
+        assert vs_plain[0] < 1e-5 and vs_plain[1] < 1e-5, (mode, vs_plain)
+    # (2) against fp64: every fp32 evaluation of this network -- the reference's included (1.4e-5 at the production shape,
+    # DESIGN.md section 3a) -- carries the same rounding of the coordinate update `x + trans` (x of order one, the score is
+    # extracted from the small update), 3e-6 .. 9e-6 here.  The fused paths must not be further from fp64 than plain fp32 is.
+    for mode in ("f32", "f16x3", "f16x3_32x32", None):
+        assert errs[mode][0] < 1.25 * errs["plain"][0] + 1e-7 and errs[mode][1] < 1.25 * errs["plain"][1] + 1e-7, (mode, errs)
+    assert errs["plain"][0] < 1.5e-5 and errs["plain"][1] < 1e-5, errs
 
 
 def test_egnn_fused_path_is_off_under_autograd(cuda):
@@ -531,6 +538,21 @@ def test_edge_chain_piece_sums_against_fp64(cuda, precision, H, n_nodes, deg):
     left = torch.randn(n_nodes, H, generator=g).to(cuda)
     both = kernels.segment_combine(pieces, E, offsets, degree.to(cuda), True, left=left)
     assert both.shape == (n_nodes, 2 * H) and torch.equal(both, torch.cat([left, got_mean], dim=1))
+    # the same and the coordinate update in ONE pass over the nodes (mdx_egnn_node_gather): messages bit for bit, coordinates
+    # against fp64 and against the stand-alone kernel (another, equally fixed, summation order)
+    for mean_c in (True, False):
+        both2, coord_new = kernels.egnn_node_gather(pieces, E, offsets, degree.to(cuda), True, left, scalar, coord_d, edges_d, mean_c)
+        assert torch.equal(both2, both)
+        want_c = torch.zeros(n_nodes, D, dtype=torch.float64).index_add_(
+            0, src, (coord.double()[src] - coord.double()[dst]) * scalar.double().cpu()[:, None])
+        if mean_c:
+            want_c = want_c / degree.clamp(min=1).double()[:, None]
+        want_c = coord.double() + want_c
+        assert _rel_l2(coord_new, want_c) < 1e-6
+        alone = kernels.egnn_coord_aggregate(scalar, coord_d, edges_d, offsets, degree.to(cuda), mean_c)
+        assert _rel_l2(coord_new, alone) < 1e-6 and torch.equal(coord_new[degree == 0], coord_d[degree == 0])
+    sums_only, _ = kernels.egnn_node_gather(pieces, E, offsets, degree.to(cuda), False, None, scalar, coord_d, edges_d, True)
+    assert torch.equal(sums_only, got_sum)
     node_err = ((got_mean.double().cpu() - want_mean).norm(dim=1) / want_mean.norm(dim=1).clamp(min=1e-30))[degree > 0].max()
     assert float(node_err) < 20 * tol, float(node_err)
 

@@ -401,3 +401,21 @@ def test_c3_shape_trajectories(oracle, name):
     for k, r in enumerate(preds):
         assert np.array_equal(r[3].A, g["pred_composition_im1_A"][k])
         assert torus_rel_l2(r[3].X, g["pred_composition_im1_X"][k]) < 1e-5
+
+
+def test_clipped_cell_has_no_duplicate_edges():
+    """EGNNScoreNetwork builds its graph in a cell clipped to 2.2 x cutoff (egnn_score_network.py:236-240); there a pair of
+    atoms is within the cutoff through at most one periodic image, so `drop_duplicate_edges` (models/egnn_utils.py:138-140)
+    changes the order of the edge list only, not its content -- which is why the HIP path serves both settings with its sorted
+    list.  Pinned on the REFERENCE's own adjacency of the two clipped-cell fixtures: the full multiset (one entry per image)
+    has exactly as many entries as the de-duplicated list, and the same (src, dst) pairs."""
+    g = load_golden("neighbors.npz")
+    for name in ("n64_clip", "n216_clip"):
+        cell = g[f"{name}/cell"]
+        assert np.all(np.diagonal(cell, axis1=1, axis2=2) >= 2.2 * float(g[f"{name}/rc"]) - 1e-4)
+        full = np.concatenate([g[f"{name}/edge_batch_sorted"][None], g[f"{name}/adj_sorted"]], 0).T      # (batch, src, dst) per image
+        n_atoms = g[f"{name}/X"].shape[1]
+        pairs = np.stack([full[:, 0] * n_atoms + full[:, 1], full[:, 0] * n_atoms + full[:, 2]], 1)
+        unique_ref = g[f"{name}/unique_edges"]
+        assert len(pairs) == len(unique_ref) == len(np.unique(pairs, axis=0))
+        assert np.array_equal(np.unique(pairs, axis=0), unique_ref)

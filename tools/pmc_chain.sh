@@ -1,6 +1,6 @@
 #!/bin/bash
-# SQ counters of the fused edge-chain kernel (eager launches: rocprofv3 --pmc over a replayed hipGraph hangs on this pool,
-# profiles/r02_pmc.md).  Usage: tools/pmc_chain.sh <mode> <out-prefix>
+# SQ counters of the fused edge-chain kernel (eager launches: rocprofv3 --pmc profiles a replayed hipGraph node by node at
+# ~15 ms per dispatch -- slow enough to run into gpurun's limit, not a hang: profiles/r02_pmc.md).  Usage: tools/pmc_chain.sh <mode> <out-prefix>
 set -e
 cd /tmp && export TMPDIR=/tmp
 MODE=${1:-f16x3}

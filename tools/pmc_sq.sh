@@ -1,5 +1,7 @@
 #!/bin/bash
-# SQ counters of the persistent sampler kernel (instruction mix and stall attribution); one small group per pass
+# SQ counters of the persistent sampler kernel of the C2 workload (instruction mix and stall attribution); one small group per
+# pass, each under its own timeout (with --pmc rocprofv3 serialises every dispatch: the workload is named explicitly -- the
+# default of bench.py is the graph-replayed C3 line, whose thousands of graph nodes take minutes to profile this way)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 rm -f $O/pmc_sq_summary.txt
@@ -8,7 +10,7 @@ for GROUP in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_INSTS_SA
   i=$((i+1))
   OUT=$O/pmc_sq_$i
   rm -rf $OUT
-  rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --no-cpu-baseline > $O/pmc_sq_$i.log 2>&1 || { echo "group $i failed: $GROUP" >> $O/pmc_sq_summary.txt; tail -3 $O/pmc_sq_$i.log >> $O/pmc_sq_summary.txt; continue; }
+  rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d $OUT -- timeout -k 10 300 python3 $R/bench.py --workload C2 --no-cpu-baseline > $O/pmc_sq_$i.log 2>&1 || { echo "group $i failed: $GROUP" >> $O/pmc_sq_summary.txt; tail -3 $O/pmc_sq_$i.log >> $O/pmc_sq_summary.txt; continue; }
   F=$(find $OUT -name '*counter_collection.csv' | head -1)
   python3 - "$F" <<'PY' >> $O/pmc_sq_summary.txt
 import csv, sys, collections
