@@ -769,6 +769,41 @@ def golden_c3_shape():
         save(name + ".npz", **out)
 
 
+def golden_egnn_variants():
+    """E_GCL options the BASELINE configurations do not use but the module accepts (models/egnn.py:36-66,128-131,157,234-264;
+    models/egnn_utils.py:111-140): attention, normalize, tanh, sum aggregations, no residual, drop_duplicate_edges=False.
+    Small networks (hidden 32), the reference's forward on B = 3 structures of N = 64 atoms; state_dict stored."""
+    g = torch.Generator().manual_seed(808)
+    variants = {
+        "attention": dict(attention=True),
+        "normalize_tanh": dict(normalize=True, tanh=True),
+        "sum_noresidual": dict(coords_agg="sum", message_agg="sum", residual=False),
+        "all_duplicates_kept": dict(attention=True, normalize=True, tanh=True, drop_duplicate_edges=False),
+    }
+    out = {"names": np.array(list(variants))}
+    B, N, cell = 3, 64, 10.86
+    for k, (name, kw) in enumerate(variants.items()):
+        torch.manual_seed(900 + k)
+        p = EGNNScoreNetworkParameters(num_atom_types=2, n_layers=2, coordinate_hidden_dimensions_size=32,
+                                       coordinate_n_hidden_dimensions=2, message_hidden_dimensions_size=32,
+                                       message_n_hidden_dimensions=2, node_hidden_dimensions_size=32,
+                                       node_n_hidden_dimensions=2, edges="radial_cutoff", radial_cutoff=7.5, **kw)
+        net = EGNNScoreNetwork(p).eval()
+        batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.randint(0, 3, (B, N), generator=g), X=torch.rand(B, N, 3, generator=g),
+                                            L=torch.tensor([cell, cell, cell, 0, 0, 0.0]).repeat(B, 1)),
+                 TIME: torch.rand(B, 1, generator=g), NOISE: torch.rand(B, 1, generator=g) * 0.2,
+                 CARTESIAN_FORCES: torch.zeros(B, N, 3)}
+        with torch.no_grad():
+            o = net(batch, conditional=False)
+        for key, val in (("A", batch[NOISY_AXL_COMPOSITION].A), ("X", batch[NOISY_AXL_COMPOSITION].X),
+                         ("L", batch[NOISY_AXL_COMPOSITION].L), ("time", batch[TIME]), ("noise", batch[NOISE]),
+                         ("out_A", o.A), ("out_X", o.X), ("out_L", o.L)):
+            out[f"{name}/{key}"] = _np(val)
+        for key, val in net.state_dict().items():
+            out[f"{name}/net/{key}"] = _np(val)
+    save("net_egnn_variants.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -788,3 +823,5 @@ if __name__ == "__main__":
         golden_c1_exact()
     if which in ("all", "c3"):
         golden_c3_shape()
+    if which in ("all", "variants"):
+        golden_egnn_variants()

@@ -155,3 +155,24 @@ def test_c3_arithmetic_modes_agree_over_many_iterations(cuda):
         assert np.array_equal(outs[precision][0], outs["f32"][0])
         err = torus_rel_l2(outs[precision][1], outs["f32"][1])
         assert err < 1e-5, f"{precision} vs f32 after 24 iterations: {err:.2e}"
+
+
+@pytest.mark.parametrize("name", ["attention", "normalize_tanh", "sum_noresidual", "all_duplicates_kept"])
+def test_egnn_option_variants_on_the_gpu_against_reference(cuda, name):
+    """The same options on the GPU: HIP radius graph (one sorted list for either drop_duplicate_edges setting), the fused edge
+    chain where the layer shape allows it (sum aggregations, no residual) and the per-layer library path where it does not
+    (attention, normalize, tanh), against the reference's forward: scores within 1e-5 rel-L2."""
+    from test_host_cpu import variant_case, variant_net
+    g = load_golden("net_egnn_variants.npz")
+    net, batch = variant_case(g, name, variant_net(name), device=cuda)
+    with torch.no_grad():
+        out = net(batch, conditional=False)
+    net.check_status()
+    ref = g[f"{name}/out_X"].astype(np.float64)
+    err = np.linalg.norm(out.X.cpu().numpy() - ref) / np.linalg.norm(ref)
+    from test_host_cpu import variant_tolerance
+    tol = variant_tolerance(g, name)          # 1e-5, or the reference's own distance from the exact answer where that is larger
+    assert err < tol, f"{name}: {err:.2e} (tolerance {tol:.2e})"
+    np.testing.assert_allclose(out.A.cpu().numpy()[..., :-1], g[f"{name}/out_A"][..., :-1], rtol=1e-4, atol=1e-5)
+    fused = net.egnn.graph_layers[0]._chain[1] is not None
+    assert fused == (name == "sum_noresidual")
