@@ -446,9 +446,9 @@ struct Chain {
     // Called in the MIDDLE of a tile's MFMA stream: makes the NEXT chunk readable (so that its first fragments can be read
     // beside the second half of the current tile's MFMAs) and opens the requests of the chunk three ahead into the slot of
     // the chunk before the current one -- every wavefront is past that one.  Returns the LDS address of the next chunk.
-    bool stores_behind;     // the message stores of this tile were issued after the last chunk request: they are younger
-                            // than the chunk waited for next, so that wait may leave them pending too
-    int stores_count;       // the same for a data-dependent number of stores (piece sums): at least this many were issued
+    int stores_count;       // store instructions issued after the last chunk request (messages, piece sums, rows): they are
+                            // younger than the chunk waited for next, so that wait may leave them pending too; any LOWER
+                            // bound of the true number is safe
 
     __device__ __forceinline__ lds_c* acquire_next()
     {
@@ -478,13 +478,6 @@ struct Chain {
                 if (k >= 8) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             }
-        } else if (stores_behind) {
-            // H / 8 store instructions were issued behind the youngest chunk request
-            if constexpr (LPW == 8) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-            else if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else if constexpr (LPW == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            stores_behind = false;
         } else {
             if constexpr (LPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (LPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -783,7 +776,6 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     C ch;
     ch.image = p.image; ch.chunks_total = (layers + (MODE == 3 && p.proj_out ? 2 : 0)) * NT + (!ROWS ? 1 : 0); ch.next_issue = 0; ch.slot_issue = 0; ch.slot_read = 0;
     ch.ring = ring; ch.wave = wave; ch.lane = lane;
-    ch.stores_behind = false;
     ch.stores_count = 0;
     ch.share = (int)(((unsigned)wave + blockIdx.x / 8u) & 3u) * (C::CHUNK / 4);      // (blockIdx / 8: its slot on its XCD)
     ch.lane16 = (uint32_t)lane * 16u;
@@ -856,6 +848,17 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         // (evaluated where it is needed, not carried through the tile as a pair of scalar registers per edge: the 16x16-shape
         // kernels are short of those)
         auto is_live = [&](int es) -> bool { return e_raw[es] < n_edges; };
+        // Store instructions a phase that issues `total` of them per wavefront -- total / NS per edge slot, each under
+        // `if (is_live(es))` -- has really issued: a slot none of whose lanes is live is skipped as a whole (the ragged last
+        // wavefront of a launch with the 16x16 shape can have edges in its first column group only).  The next chunk wait
+        // leaves that many of the youngest operations pending (Chain::stores_count); over-counting would let it return
+        // before the chunk it waits for has landed.
+        auto stores_issued = [&](int total) -> int {
+            int count = 0;
+#pragma unroll
+            for (int es = 0; es < NS; ++es) count += __builtin_amdgcn_ballot_w64(is_live(es)) != 0 ? total / NS : 0;
+            return __builtin_amdgcn_readfirstlane(count);
+        };
         Act<H, PREC> xa, xb;
         // float4 group q8 = 4 t + q of the lane's H / 2 values: registers 4 q .. 4 q + 3 of tile t = features
         // 32 t + fb(q) .. + 3 of edge es(q)  (struct Lay)
@@ -1075,7 +1078,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             if (e_raw[0] >= 0) return;
 #endif
             // every wavefront issues exactly H / 8 store instructions (lanes beyond the edge count masked off, the address
-            // clamped): the next chunk wait counts on them (Chain::stores_behind)
+            // clamped; an edge slot without a live lane issues none): the next chunk wait counts on them (Chain::stores_count)
 #pragma unroll
             for (int q8 = 0; q8 < H / 8; ++q8) {
                 const int t = q8 >> 2, q = q8 & 3, es = L::es(q);
@@ -1088,9 +1091,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 }
                 if (is_live(es)) *(f32x4*)(p.messages + e[es] * H + 32 * t + L::fb(q, h)) = y;
             }
-            bool any_live = is_live(0);
-            if constexpr (NS == 2) any_live = any_live || is_live(1);
-            ch.stores_behind = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(any_live) != 0);
+            ch.stores_count = stores_issued(H / 8);
         };
         // Message aggregation inside the kernel (piece_sums): the edges are sorted by source node, so a node's edges are a
         // run of consecutive edges = consecutive lanes of the accumulator layout (32x32 shapes: lane = 32 h + edge; 16x16 shape:
@@ -1213,9 +1214,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 }
                 if ((q8 & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // (bounds the hoisting of the residual loads)
             }
-            bool any_live = is_live(0);
-            if constexpr (NS == 2) any_live = any_live || is_live(1);
-            ch.stores_behind = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(any_live) != 0);
+            ch.stores_count = stores_issued(H / 8);
             if constexpr (MODE == 3) {
                 if (project) {
                     // [out W_src^T | out W_dst^T]: 2 NT more tiles, each stored as it is (sixteen tiles per 128 rows: not worth
@@ -1245,9 +1244,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                             }
                             if (is_live(es)) *(f32x4*)(p.proj_out + e[es] * 2 * H + 32 * t2 + L::fb(q, h)) = v;
                         }
-                        bool any = is_live(0);
-                        if constexpr (NS == 2) any = any || is_live(1);
-                        ch.stores_count = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(any) != 0) ? 4 / NS : 0;
+                        ch.stores_count = stores_issued(4);
                     }
                 }
             }
