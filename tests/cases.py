@@ -62,3 +62,8 @@ C1_EXACT = (noise_ns(100, sigma_min=1e-4, sigma_max=0.25), sampling_ns(8, 1), la
 # T = 1000 schedule at the top and at the bottom, B = 4, the production EGNN with formula weights)
 C3_SHAPE = (noise_ns(1000, **LIN), sampling_ns(64, 1, M=2, one=False, greedy=False, cell=[10.86] * 3),
             lambda eb: nets.egnn_c3_net(1, edge_builder=eb))
+
+# BASELINE configs[3]'s settings at the same network shape (SiGe: two atom types, greedy sampling + one transition per step,
+# cell 11.084): tests/golden/traj_egnn_c4_{top,mid}.npz
+C4_SHAPE = (noise_ns(1000, **LIN), sampling_ns(64, 2, M=2, one=True, greedy=True, cell=[11.084] * 3),
+            lambda eb: nets.egnn_c3_net(2, edge_builder=eb))

@@ -730,7 +730,7 @@ def _egnn_c3(num_atom_types=1):
     return fill_with_formula(EGNNScoreNetwork(p).eval())
 
 
-def golden_c3_shape():
+def golden_c3_shape(only=None):
     """The network shape and sampler settings BASELINE configs[2] is quoted on (the benchmarked kernels'
     instantiation), on the reference's CPU path:
       net_egnn_c3.npz          EGNNScoreNetwork forward (models/score_networks/egnn_score_network.py:226-303), B = 8, N = 64
@@ -738,8 +738,11 @@ def golden_c3_shape():
       traj_egnn_c3_bottom.npz  the same 2 -> 0 (index 0: the corrector's sigma_min special case, :719-725)
     with T = 1000, sigma 1e-4 .. 0.2 linear, corrector_step_epsilon 2.5e-8, M = 2, no greedy / one-transition
     (config_diffusion_egnn.yaml:84-103).  Draws and per-step compositions recorded; weights by formula."""
+    c4 = only is not None                 # (the two configs[3] trajectories were added later: their own pass and seed)
+    if only is None:
+        only = ("traj_egnn_c3_top", "traj_egnn_c3_bottom")
     net = _egnn_c3(1)
-    g = torch.Generator().manual_seed(909)
+    g = torch.Generator().manual_seed(911 if c4 else 909)
     B, N, cell = 8, 64, 10.86
     batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.randint(0, 2, (B, N), generator=g), X=torch.rand(B, N, 3, generator=g),
                                         L=torch.tensor([cell, cell, cell, 0, 0, 0.0]).repeat(B, 1)),
@@ -747,17 +750,28 @@ def golden_c3_shape():
              CARTESIAN_FORCES: torch.zeros(B, N, 3)}
     with torch.no_grad():
         o = net(batch, conditional=False)
-    save("net_egnn_c3.npz", A=_np(batch[NOISY_AXL_COMPOSITION].A), X=_np(batch[NOISY_AXL_COMPOSITION].X),
-         L=_np(batch[NOISY_AXL_COMPOSITION].L), time=_np(batch[TIME]), noise=_np(batch[NOISE]),
-         out_A=_np(o.A), out_X=_np(o.X), out_L=_np(o.L))
+    if not c4:
+        save("net_egnn_c3.npz", A=_np(batch[NOISY_AXL_COMPOSITION].A), X=_np(batch[NOISY_AXL_COMPOSITION].X),
+             L=_np(batch[NOISY_AXL_COMPOSITION].L), time=_np(batch[TIME]), noise=_np(batch[NOISE]),
+             out_A=_np(o.A), out_X=_np(o.X), out_L=_np(o.L))
 
     kw = dict(T=1000, N=64, num_atom_types=1, M=2, one=False, greedy=False, cell=[10.86] * 3,
               noise_kw=dict(sigma_min=1e-4, sigma_max=0.2, schedule_type="linear", corrector_step_epsilon=2.5e-8))
+    # BASELINE configs[3] (SiGe 2x2x2: two atom types, greedy sampling and one transition per step ON --
+    # experiments/.../SiGe_2x2x2 config, :97-98; cell 11.084): the same network shape with num_atom_types = 2
+    kw4 = dict(kw, num_atom_types=2, one=True, greedy=True, cell=[11.084] * 3)
+    net4 = _egnn_c3(2)
     B = 4
-    for name, start, end, masked_fraction in (("traj_egnn_c3_top", 1000, 998, 1.0), ("traj_egnn_c3_bottom", 2, 0, 0.1)):
-        gen, npar, spar = make_generator(record=True, net=net, **kw)
+    for name, start, end, masked_fraction, run_kw, run_net, run_cell, nat in (
+            ("traj_egnn_c3_top", 1000, 998, 1.0, kw, net, 10.86, 1), ("traj_egnn_c3_bottom", 2, 0, 0.1, kw, net, 10.86, 1),
+            ("traj_egnn_c4_top", 1000, 998, 1.0, kw4, net4, 11.084, 2), ("traj_egnn_c4_mid", 500, 498, 0.5, kw4, net4, 11.084, 2)):
+        if name not in only:
+            continue
+        cell = run_cell
+        gen, npar, spar = make_generator(record=True, net=run_net, **run_kw)
         X0 = torch.rand(B, N, 3, generator=g)
-        A0 = (torch.rand(B, N, generator=g) < masked_fraction).long()          # MASK = num_atom_types = 1
+        masked = torch.rand(B, N, generator=g) < masked_fraction               # MASK = num_atom_types
+        A0 = torch.where(masked, torch.full((B, N), nat), torch.randint(0, nat, (B, N), generator=g))
         L0 = torch.tensor([cell, cell, cell, 0, 0, 0.0]).repeat(B, 1)
         torch.manual_seed(910 + start)
         with torch.no_grad(), DrawRecorder() as rec:
@@ -823,5 +837,7 @@ if __name__ == "__main__":
         golden_c1_exact()
     if which in ("all", "c3"):
         golden_c3_shape()
+    if which in ("all", "c4"):
+        golden_c3_shape(only=("traj_egnn_c4_top", "traj_egnn_c4_mid"))
     if which in ("all", "variants"):
         golden_egnn_variants()

@@ -54,10 +54,10 @@ def test_c3_network_forward_against_reference(cuda, precision):
                    for layer in net.egnn.graph_layers)
 
 
-def _generator(cuda, precision, **extra):
+def _generator(cuda, precision, shape=None, **extra):
     import warnings
     P = _pkg()
-    noise_kw, sampling_kw, netf = cases.C3_SHAPE
+    noise_kw, sampling_kw, netf = shape or cases.C3_SHAPE
     skw = dict(sampling_kw)
     skw.update(extra)
     with warnings.catch_warnings():
@@ -68,11 +68,19 @@ def _generator(cuda, precision, **extra):
     return P["Langevin"](npar, spar, net), spar
 
 
+C3_C4_TRAJECTORIES = ["traj_egnn_c3_top", "traj_egnn_c3_bottom", "traj_egnn_c4_top", "traj_egnn_c4_mid"]
+
+
+def _shape_of(name):
+    """configs[2] (Si, one atom type) or configs[3] (SiGe: two atom types, greedy sampling + one transition per step)"""
+    return cases.C4_SHAPE if "_c4_" in name else cases.C3_SHAPE
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
-@pytest.mark.parametrize("name", ["traj_egnn_c3_top", "traj_egnn_c3_bottom"])
+@pytest.mark.parametrize("name", C3_C4_TRAJECTORIES)
 def test_c3_teacher_forced_steps(cuda, name, precision):
     g = load_golden(name + ".npz")
-    gen, spar = _generator(cuda, precision)
+    gen, spar = _generator(cuda, precision, shape=_shape_of(name))
     gen.noise_source = _replayed(g)
     B, M = int(g["batch"]), spar.number_of_corrector_steps
 
@@ -100,10 +108,10 @@ def test_c3_teacher_forced_steps(cuda, name, precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
-@pytest.mark.parametrize("name", ["traj_egnn_c3_top", "traj_egnn_c3_bottom"])
+@pytest.mark.parametrize("name", C3_C4_TRAJECTORIES)
 def test_c3_free_run_against_reference(cuda, name, precision):
     g = load_golden(name + ".npz")
-    gen, spar = _generator(cuda, precision)
+    gen, spar = _generator(cuda, precision, shape=_shape_of(name))
     gen.noise_source = _replayed(g)
     start = RS.AXL(A=torch.from_numpy(g["start_A"]).to(cuda), X=torch.from_numpy(g["start_X"]).to(cuda),
                    L=torch.from_numpy(g["start_L"]).to(cuda))

@@ -380,13 +380,13 @@ def test_c3_shape_network_against_reference_forward(oracle):
     np.testing.assert_allclose(out.L.numpy(), g["out_L"], rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("name", ["traj_egnn_c3_top", "traj_egnn_c3_bottom"])
+@pytest.mark.parametrize("name", ["traj_egnn_c3_top", "traj_egnn_c3_bottom", "traj_egnn_c4_top", "traj_egnn_c4_mid"])
 def test_c3_shape_trajectories(oracle, name):
     """The oracle sampler on the reference's draws at BASELINE configs[2]'s settings (T = 1000 linear schedule, M = 2,
     production EGNN): two indices from the top (1000 -> 998) and the last two (2 -> 0, index 0 = the corrector's sigma_min
     special case): atom types exact, coordinates within 1e-5 at every step and at the end."""
     g = load_golden(name + ".npz")
-    noise_kw, sampling_kw, netf = cases.C3_SHAPE
+    noise_kw, sampling_kw, netf = cases.C4_SHAPE if "_c4_" in name else cases.C3_SHAPE      # (c4: two atom types, greedy + one-transition)
     npar, spar = cases.as_objects(noise_kw, sampling_kw)
     replay = RS.ReplayNoise(g)
     gen = RS.OracleLangevinGenerator(npar, spar, netf(nets.oracle_edge_builder), noise=replay)
