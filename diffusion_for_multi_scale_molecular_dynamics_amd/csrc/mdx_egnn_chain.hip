@@ -998,13 +998,18 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     const int ks = s >> 1, rho = s & 1;
                     f32x4 a0 = {acc[8 * rho], acc[8 * rho + 1], acc[8 * rho + 2], acc[8 * rho + 3]};
                     f32x4 a1 = {acc[8 * rho + 4], acc[8 * rho + 5], acc[8 * rho + 6], acc[8 * rho + 7]};
+#ifndef MDX_CHAIN_DMA_POS
+#define MDX_CHAIN_DMA_POS 1          // (timing experiments: the request behind the step's 1st / 3rd / 6th MFMA)
+#endif
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.hi[0][ks], a0, 0, 0, 0);
-                    if (C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
+                    if (MDX_CHAIN_DMA_POS == 1 && C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.hi[1][ks], a1, 0, 0, 0);
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.lo[0][ks], a0, 0, 0, 0);
+                    if (MDX_CHAIN_DMA_POS == 3 && C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.lo[1][ks], a1, 0, 0, 0);
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].lo, in.hi[0][ks], a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].lo, in.hi[1][ks], a1, 0, 0, 0);
+                    if (MDX_CHAIN_DMA_POS == 6 && C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         acc[8 * rho + i] = a0[i];
@@ -1024,7 +1029,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 }
 #ifdef MDX_CHAIN_PIN_STEPS
                 __builtin_amdgcn_sched_barrier(0);      // keep each k-step's share of vector work beside ITS MFMAs
-#else
+#elif !defined(MDX_CHAIN_STAGED_UNPINNED)
                 if constexpr (STAGED) __builtin_amdgcn_sched_barrier(0);
 #endif
             }
