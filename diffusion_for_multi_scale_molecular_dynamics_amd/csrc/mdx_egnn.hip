@@ -99,6 +99,69 @@ __global__ __launch_bounds__(kBlock) void egnn_node_inputs_kernel(const float* _
     }
 }
 
+// The same with one wavefront per node and 16-byte stores (H, H2 multiples of 4): no index division per element, the node's
+// sigma and atom type read once, and both weight matrices staged TRANSPOSED in LDS ([F][H] behind the bias), so that a lane's
+// four columns are one 16-byte LDS read instead of eight strided global reads.  Same operations per value, same bits.
+__device__ __forceinline__ float4 embed_quad(const float* __restrict__ t, int H, int q, float s, int64_t a, int F)
+{
+    // t: bias [H], then W^T [F][H]
+    const float4 bias = reinterpret_cast<const float4*>(t)[q];
+    const float4 w0 = reinterpret_cast<const float4*>(t + H)[q];
+    float4 v;
+    v.x = bias.x + s * w0.x;
+    v.y = bias.y + s * w0.y;
+    v.z = bias.z + s * w0.z;
+    v.w = bias.w + s * w0.w;
+    if (a >= 0 && a + 1 < F) {
+        const float4 wa = reinterpret_cast<const float4*>(t + (2 + a) * H)[q];
+        v.x = v.x + wa.x;
+        v.y = v.y + wa.y;
+        v.z = v.z + wa.z;
+        v.w = v.w + wa.w;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void egnn_node_inputs_rows_kernel(const float* __restrict__ x, const float* __restrict__ k_vectors,
+                                                                       int n_k, const float* __restrict__ sigma,
+                                                                       int atoms_per_structure,
+                                                                       const int64_t* __restrict__ atom_types,
+                                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                                       int F, int H, int64_t n_nodes, float* __restrict__ z,
+                                                                       float* __restrict__ h, const float* __restrict__ w2,
+                                                                       const float* __restrict__ b2, int H2,
+                                                                       float* __restrict__ h2)
+{
+    extern __shared__ float tables[];                   // [ (1 + F) H | (1 + F) H2 ]
+    float* t1 = tables;
+    float* t2 = tables + (1 + F) * H;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        t1[j] = b[j];
+        for (int f = 0; f < F; ++f) t1[(1 + f) * H + j] = w[(int64_t)j * F + f];
+    }
+    if (h2)
+        for (int j = threadIdx.x; j < H2; j += blockDim.x) {
+            t2[j] = b2[j];
+            for (int f = 0; f < F; ++f) t2[(1 + f) * H2 + j] = w2[(int64_t)j * F + f];
+        }
+    __syncthreads();
+    const int lane = threadIdx.x % 64;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / 64, n_waves = ((int64_t)gridDim.x * blockDim.x) / 64;
+    for (int64_t i = wave; i < n_nodes; i += n_waves) {
+        const float s = sigma[i / atoms_per_structure];
+        const int64_t a = atom_types[i];
+        if (h2)
+            for (int q = lane; q < (H2 >> 2); q += 64) reinterpret_cast<float4*>(h2 + i * H2)[q] = embed_quad(t2, H2, q, s, a, F);
+        for (int q = lane; q < (H >> 2); q += 64) reinterpret_cast<float4*>(h + i * H)[q] = embed_quad(t1, H, q, s, a, F);
+        for (int k = lane; k < n_k; k += 64) {
+            float kr = 0.0f;
+            for (int d = 0; d < 3; ++d) kr = kr + (6.2831855f * x[3 * i + d]) * k_vectors[3 * k + d];
+            z[2 * (i * n_k + k)] = cosf(kr);
+            z[2 * (i * n_k + k) + 1] = sinf(kr);
+        }
+    }
+}
+
 // S^alpha_i = z_i . Gamma^alpha . xhat_i with Gamma^alpha = blockdiag_k(K_k[alpha] [[0,-1],[1,0]])  (egnn_score_network.py:103-133,
 // 283-290): per node and direction, sum_k K_k[alpha] (z_{2k+1} xhat_{2k} - z_{2k} xhat_{2k+1}).
 __global__ __launch_bounds__(kBlock) void egnn_scores_kernel(const float* __restrict__ z, const float* __restrict__ x_hat,
@@ -116,6 +179,67 @@ __global__ __launch_bounds__(kBlock) void egnn_scores_kernel(const float* __rest
             acc = acc + ((zi[2 * k] * -kk) * xi[2 * k + 1] + (zi[2 * k + 1] * kk) * xi[2 * k]);
         }
         scores[t] = acc;
+    }
+}
+
+// Everything EGNNScoreNetwork computes per node behind the last graph layer, in one launch (one wavefront per node):
+//   logits[i, c] = h_i . W_c + b_c          EGNN.node_classification_layer (models/egnn.py:362-385), with the MASK class's
+//                                           logit set to -inf (score_network.py:183-185) when mask_class >= 0
+//   scores[i, :]                            as egnn_scores_kernel
+//   zero_out[0 .. n_zero)                   the all-zero lattice output of the network (egnn_score_network.py:299-303)
+// A row of h is read once as 16-byte lane loads; the C <= kMaxClasses dot products share it and end in a butterfly.
+constexpr int kMaxClasses = 8;
+constexpr int kWaveSize = 64;
+
+__global__ __launch_bounds__(kBlock) void egnn_outputs_kernel(const float* __restrict__ z, const float* __restrict__ x_hat,
+                                                              const float* __restrict__ k_vectors, int n_k,
+                                                              const float* __restrict__ h, const float* __restrict__ cw,
+                                                              const float* __restrict__ cb, int H, int C, int mask_class,
+                                                              int64_t n_nodes, float* __restrict__ scores,
+                                                              float* __restrict__ logits, float* __restrict__ zero_out,
+                                                              int64_t n_zero)
+{
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, n_threads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = tid; t < n_zero; t += n_threads) zero_out[t] = 0.0f;
+    const int lane = threadIdx.x % kWaveSize;
+    const int quads = H >> 2;
+    for (int64_t node = tid / kWaveSize; node < n_nodes; node += n_threads / kWaveSize) {
+        // the three score lanes fetch their operands while the others are busy with the row of h
+        float acc = 0.0f;
+        if (lane >= kWaveSize - 3) {
+            const int alpha = lane - (kWaveSize - 3);
+            const float* zi = z + node * 2 * n_k;
+            const float* xi = x_hat + node * 2 * n_k;
+            for (int k = 0; k < n_k; ++k) {
+                const float kk = k_vectors[3 * k + alpha];
+                acc = acc + ((zi[2 * k] * -kk) * xi[2 * k + 1] + (zi[2 * k + 1] * kk) * xi[2 * k]);
+            }
+        }
+        float part[kMaxClasses];
+#pragma unroll
+        for (int c = 0; c < kMaxClasses; ++c) part[c] = 0.0f;
+        for (int q = lane; q < quads; q += kWaveSize) {
+            const float4 hv = reinterpret_cast<const float4*>(h + node * H)[q];
+#pragma unroll
+            for (int c = 0; c < kMaxClasses; ++c) {
+                if (c < C && c != mask_class) {
+                    const float4 wv = reinterpret_cast<const float4*>(cw + (int64_t)c * H)[q];
+                    part[c] += (hv.x * wv.x + hv.y * wv.y) + (hv.z * wv.z + hv.w * wv.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kMaxClasses; ++c) {
+            if (c < C) {
+                float v = part[c];
+                if (c != mask_class) {
+#pragma unroll
+                    for (int o = kWaveSize / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWaveSize);
+                }
+                if (lane == 0) logits[node * C + c] = (c == mask_class) ? -__builtin_inff() : v + cb[c];
+            }
+        }
+        if (lane >= kWaveSize - 3) scores[node * 3 + lane - (kWaveSize - 3)] = acc;
     }
 }
 
@@ -295,6 +419,17 @@ int mdx_egnn_node_inputs(const float* x, const float* k_vectors, int n_k, const 
     if (n_nodes == 0) return MDX_OK;
     if (!x || !k_vectors || !sigma || !atom_types || !emb_weight || !emb_bias || !z_out || !h_out) return MDX_ERR_INVALID_ARG;
     if (second_out && (!second_weight || !second_bias || second_width < 1)) return MDX_ERR_INVALID_ARG;
+    const size_t table_bytes = sizeof(float) * (size_t)(1 + n_features) * ((size_t)H + (second_out ? (size_t)second_width : 0));
+    if ((H & 3) == 0 && (!second_out || (second_width & 3) == 0) && table_bytes <= 48 * 1024) {
+        // few workgroups (each stages the tables once), many nodes each
+        int64_t blocks = (n_nodes + 63) / 64;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(egnn_node_inputs_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), table_bytes,
+                           reinterpret_cast<hipStream_t>(stream), x, k_vectors, n_k, sigma, atoms_per_structure, atom_types,
+                           emb_weight, emb_bias, n_features, H, n_nodes, z_out, h_out, second_weight, second_bias, second_width,
+                           second_out);
+        return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
+    }
     int64_t blocks = (n_nodes * H + kBlock - 1) / kBlock;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(egnn_node_inputs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), x,
@@ -313,6 +448,23 @@ int mdx_egnn_scores(const float* z, const float* x_hat, const float* k_vectors, 
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(egnn_scores_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), z, x_hat,
                        k_vectors, n_k, n_nodes, scores_out);
+    return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
+}
+
+int mdx_egnn_outputs(const float* z, const float* x_hat, const float* k_vectors, int n_k, const float* h,
+                     const float* class_weight, const float* class_bias, int H, int num_classes, int mask_class,
+                     int64_t n_nodes, float* scores_out, float* logits_out, float* zero_out, int64_t n_zero,
+                     mdx_stream_t stream)
+{
+    if (n_nodes < 0 || n_k < 1 || H < 4 || num_classes < 1 || n_zero < 0 || mask_class >= num_classes) return MDX_ERR_INVALID_ARG;
+    if ((H & 3) || num_classes > kMaxClasses) return MDX_ERR_UNSUPPORTED;
+    if (n_zero > 0 && !zero_out) return MDX_ERR_INVALID_ARG;
+    if (n_nodes == 0 && n_zero == 0) return MDX_OK;
+    if (n_nodes > 0 && (!z || !x_hat || !k_vectors || !h || !class_weight || !class_bias || !scores_out || !logits_out))
+        return MDX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(egnn_outputs_kernel, dim3(node_grid(n_nodes)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), z,
+                       x_hat, k_vectors, n_k, h, class_weight, class_bias, H, num_classes, mask_class, n_nodes, scores_out,
+                       logits_out, zero_out, n_zero);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 

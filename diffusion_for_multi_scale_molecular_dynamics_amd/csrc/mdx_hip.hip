@@ -1598,7 +1598,8 @@ __global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __res
                                                               int64_t* __restrict__ counts, const int64_t* __restrict__ offsets,
                                                               int64_t* __restrict__ edges, int32_t* __restrict__ image_out,
                                                               float* __restrict__ shifts_out, uint32_t* status,
-                                                              int64_t capacity)
+                                                              int64_t capacity, const float* __restrict__ lattice,
+                                                              int lattice_stride, float clip_min)
 {
     extern __shared__ float lds[];
     float* pos = lds;            // [N][3]
@@ -1606,13 +1607,33 @@ __global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __res
     const int64_t b = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
     const float* P = cart + b * N * 3;
-    const float* cl = cell + b * 9;
-    for (int i = threadIdx.x; i < 3 * N; i += blockDim.x) pos[i] = P[i];
+    // lattice != nullptr (the EGNN score network's graph, egnn_score_network.py:236-247): `cart` holds RELATIVE coordinates and
+    // the cell is diag(max(lattice[b, k], clip_min)); relative x diagonal cell is one product per component -- the bits
+    // torch.matmul(relative, diag_embed(lengths)) gives (its other terms are exact zeros)
+    float cl[9];
+    if (lattice) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cl[k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = lattice[b * lattice_stride + k];
+            cl[4 * k] = v < clip_min ? clip_min : v;          // torch.clip(min=): a NaN stays a NaN
+        }
+        for (int i = threadIdx.x; i < 3 * N; i += blockDim.x) {
+            const int c = i % 3;
+            pos[i] = P[i] * (c == 0 ? cl[0] : c == 1 ? cl[4] : cl[8]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cl[k] = cell[b * 9 + k];
+        for (int i = threadIdx.x; i < 3 * N; i += blockDim.x) pos[i] = P[i];
+    }
     if (threadIdx.x < 81) {
         const int l = threadIdx.x / 3, c = threadIdx.x % 3;
         const float rel[3] = {(float)(l / 9 - 1), (float)((l / 3) % 3 - 1), (float)(l % 3 - 1)};
         float acc = 0.0f;
-        for (int k = 0; k < 3; ++k) acc = __builtin_fmaf(rel[k], cl[k * 3 + c], acc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc = __builtin_fmaf(rel[k], c == 0 ? cl[k * 3] : c == 1 ? cl[k * 3 + 1] : cl[k * 3 + 2], acc);
         lv[threadIdx.x] = acc;
     }
     if (!FILL && chunk == 0 && threadIdx.x == 96 && status) {
@@ -1709,6 +1730,74 @@ __global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __res
         // a caller-sized edge list that is too small: nothing is written beyond it, and the caller is told
         if (FILL && lane == 0 && status && base + running > capacity) atomicOr(status, MDX_STATUS_GRAPH_CAPACITY);
     }
+}
+
+// offsets[i] = counts[0] + ... + counts[i-1], *total = the sum: ONE workgroup walks the list in tiles of kScanItems x kScanBlock
+// entries (the list is the per-atom edge count of a batch -- 32 768 entries, two tiles, at C3; a launch of its own between the
+// two radius-graph passes costs less than the three library launches of cumsum + subtraction it replaces).  Each thread owns
+// kScanItems consecutive entries (read and written as 16-byte pairs); the sums inside a tile are 32-bit (an entry is an edge
+// count of ONE atom: < 2^15 at the largest structure the radius graph takes), the carry between tiles 64-bit.
+constexpr int kScanBlock = 1024, kScanItems = 16;
+
+__global__ __launch_bounds__(kScanBlock) void offsets_scan_kernel(const int64_t* __restrict__ counts, int64_t n,
+                                                                  int64_t* __restrict__ offsets, int64_t* __restrict__ total)
+{
+    __shared__ int wave_sums[kScanBlock / kWave];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    int64_t carry = 0;
+    for (int64_t base = 0; base < n; base += (int64_t)kScanItems * kScanBlock) {
+        const int64_t i0 = base + (int64_t)kScanItems * threadIdx.x;
+        int v[kScanItems];
+        if (i0 + kScanItems <= n) {
+#pragma unroll
+            for (int k = 0; k < kScanItems; k += 2) {
+                const longlong2 pair = reinterpret_cast<const longlong2*>(counts + i0)[k >> 1];
+                v[k] = (int)pair.x;
+                v[k + 1] = (int)pair.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kScanItems; ++k) v[k] = i0 + k < n ? (int)counts[i0 + k] : 0;
+        }
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) s += v[k];
+        int incl = s;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const int t = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += t;
+        }
+        if (lane == kWave - 1) wave_sums[wave] = incl;
+        __syncthreads();
+        int before = 0, tile = 0;
+#pragma unroll
+        for (int w = 0; w < kScanBlock / kWave; ++w) {
+            const int x = wave_sums[w];
+            if (w < wave) before += x;
+            tile += x;
+        }
+        int64_t run = carry + (int64_t)(before + (incl - s));
+        if (i0 + kScanItems <= n) {
+#pragma unroll
+            for (int k = 0; k < kScanItems; k += 2) {
+                longlong2 pair;
+                pair.x = run;
+                pair.y = run + v[k];
+                run += v[k] + v[k + 1];
+                reinterpret_cast<longlong2*>(offsets + i0)[k >> 1] = pair;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kScanItems; ++k) {
+                if (i0 + k < n) offsets[i0 + k] = run;
+                run += v[k];
+            }
+        }
+        carry += tile;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2068,7 +2157,7 @@ int mdx_radius_graph_count(const float* cart, const float* cell, float rc, int64
     const size_t lds = sizeof(float) * (3 * (size_t)N + 81);
     hipLaunchKernelGGL(radius_graph_kernel<false>, dim3((unsigned)(batch * chunks)), dim3(kBlock), lds, as_stream(stream),
                        cart, cell, rc, batch, N, unique, chunks, counts, (const int64_t*)nullptr, (int64_t*)nullptr,
-                       (int32_t*)nullptr, (float*)nullptr, status, (int64_t)0);
+                       (int32_t*)nullptr, (float*)nullptr, status, (int64_t)0, (const float*)nullptr, 0, 0.0f);
     return launch_status();
 }
 
@@ -2085,7 +2174,30 @@ int mdx_radius_graph_fill_capped(const float* cart, const float* cell, float rc,
     const size_t lds = sizeof(float) * (3 * (size_t)N + 81);
     hipLaunchKernelGGL(radius_graph_kernel<true>, dim3((unsigned)(batch * chunks)), dim3(kBlock), lds, as_stream(stream),
                        cart, cell, rc, batch, N, unique, chunks, (int64_t*)nullptr, offsets, edges_out, image_out,
-                       shifts_out, status, capacity);
+                       shifts_out, status, capacity, (const float*)nullptr, 0, 0.0f);
+    return launch_status();
+}
+
+int mdx_egnn_radius_graph(const float* relative_coordinates, const float* lattice_parameters, int lattice_stride, float clip_min,
+                          float rc, int64_t batch, int N, int64_t capacity, int64_t* counts, int64_t* offsets,
+                          int64_t* n_edges, int64_t* edges_out, uint32_t* status, mdx_stream_t stream)
+{
+    if (batch < 0 || N < 1 || !(rc > 0.0f) || capacity < 0 || lattice_stride < 3 || !(clip_min >= 0.0f)) return MDX_ERR_INVALID_ARG;
+    if (N > 5000) return MDX_ERR_UNSUPPORTED;
+    if (!n_edges) return MDX_ERR_INVALID_ARG;
+    if (batch == 0) return hipMemsetAsync(n_edges, 0, sizeof(int64_t), as_stream(stream)) == hipSuccess ? MDX_OK : MDX_ERR_HIP;
+    if (!relative_coordinates || !lattice_parameters || !counts || !offsets || (capacity > 0 && !edges_out)) return MDX_ERR_INVALID_ARG;
+    const int chunks = (int)cdiv(N, kRowsPerBlock);
+    const size_t lds = sizeof(float) * (3 * (size_t)N + 81);
+    const dim3 grid((unsigned)(batch * chunks));
+    hipLaunchKernelGGL(radius_graph_kernel<false>, grid, dim3(kBlock), lds, as_stream(stream), relative_coordinates,
+                       (const float*)nullptr, rc, batch, N, 1, chunks, counts, (const int64_t*)nullptr, (int64_t*)nullptr,
+                       (int32_t*)nullptr, (float*)nullptr, status, (int64_t)0, lattice_parameters, lattice_stride, clip_min);
+    hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(kScanBlock), 0, as_stream(stream), (const int64_t*)counts, batch * N,
+                       offsets, n_edges);
+    hipLaunchKernelGGL(radius_graph_kernel<true>, grid, dim3(kBlock), lds, as_stream(stream), relative_coordinates,
+                       (const float*)nullptr, rc, batch, N, 1, chunks, (int64_t*)nullptr, (const int64_t*)offsets, edges_out,
+                       (int32_t*)nullptr, (float*)nullptr, status, capacity, lattice_parameters, lattice_stride, clip_min);
     return launch_status();
 }
 

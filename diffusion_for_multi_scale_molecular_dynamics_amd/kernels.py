@@ -265,6 +265,26 @@ def radius_graph_static(cartesian_positions, basis_vectors, radial_cutoff: float
     return dict(counts=counts, offsets=offsets, edges=edges, n_edges=inclusive[-1:])
 
 
+def egnn_radius_graph(relative_coordinates, lattice_parameters, clip_min: float, radial_cutoff: float, capacity: int,
+                      status: Optional[torch.Tensor] = None):
+    """radius_graph_static for the graph EGNNScoreNetwork builds (egnn_score_network.py:236-247): relative coordinates
+    [B,N,3] in the cell diag(max(lattice_parameters[:, :3], clip_min)); count, device-side scan and fill behind ONE call
+    (mdx_egnn_radius_graph: three launches, no library kernel, no host read).  Same dict as radius_graph_static."""
+    B, N, d = relative_coordinates.shape
+    assert d == 3 and lattice_parameters.dim() == 2 and lattice_parameters.shape[0] == B and lattice_parameters.shape[1] >= 3
+    dev = relative_coordinates.device
+    counts = torch.empty(B * N, dtype=I64, device=dev)
+    offsets = torch.empty(B * N, dtype=I64, device=dev)
+    n_edges = torch.empty(1, dtype=I64, device=dev)
+    edges = torch.empty(int(capacity), 2, dtype=I64, device=dev)
+    check(lib().mdx_egnn_radius_graph(ptr(relative_coordinates, F32, "relative_coordinates"),
+                                      ptr(lattice_parameters, F32, "lattice_parameters"), lattice_parameters.shape[1],
+                                      float(clip_min), float(radial_cutoff), B, N, int(capacity), ptr(counts, I64, "counts"),
+                                      ptr(offsets, I64, "offsets"), ptr(n_edges, I64, "n_edges"), ptr(edges, I64, "edges"),
+                                      ptr(status, I32, "status"), stream_handle()), "mdx_egnn_radius_graph")
+    return dict(counts=counts, offsets=offsets, edges=edges, n_edges=n_edges)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # fused MLP score network
 # ----------------------------------------------------------------------------------------------------------------
@@ -811,6 +831,22 @@ def egnn_scores(z, x_hat, k_vectors):
                                ptr(out, F32, "scores"), stream_handle())
     check(rc, "mdx_egnn_scores")
     return out
+
+
+def egnn_outputs(z, x_hat, k_vectors, h, class_weight, class_bias, mask_class: int, n_zero: int):
+    """(scores [n_nodes,3], logits [n_nodes,C] with the MASK logit at -inf, zeros [n_zero]) in one launch (mdx_egnn_outputs)."""
+    n_nodes, n_k = z.shape[0], k_vectors.shape[0]
+    C, H = class_weight.shape
+    assert z.shape == x_hat.shape == (n_nodes, 2 * n_k) and h.shape == (n_nodes, H) and class_bias.shape == (C,)
+    scores = torch.empty(n_nodes, 3, dtype=F32, device=z.device)
+    logits = torch.empty(n_nodes, C, dtype=F32, device=z.device)
+    zeros = torch.empty(int(n_zero), dtype=F32, device=z.device)
+    rc = lib().mdx_egnn_outputs(ptr(z, F32, "z"), ptr(x_hat, F32, "x_hat"), ptr(k_vectors, F32, "k_vectors"), n_k,
+                                ptr(h, F32, "h"), ptr(class_weight, F32, "class_weight"), ptr(class_bias, F32, "class_bias"),
+                                H, C, int(mask_class), n_nodes, ptr(scores, F32, "scores"), ptr(logits, F32, "logits"),
+                                ptr(zeros, F32, "zeros") if n_zero else None, int(n_zero), stream_handle())
+    check(rc, "mdx_egnn_outputs")
+    return scores, logits, zeros
 
 
 def egnn_coord_aggregate(edge_scalar, coord, edges, offsets, degree, mean: bool) -> torch.Tensor:

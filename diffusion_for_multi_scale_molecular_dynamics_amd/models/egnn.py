@@ -357,11 +357,12 @@ class EGNN(nn.Module):
                 message_agg=message_agg, tanh=tanh))
 
     def forward(self, h: torch.Tensor, edges: torch.Tensor, x: torch.Tensor, degree=None, embedded: bool = False,
-                first_proj: Optional[torch.Tensor] = None) -> AXL:
+                first_proj: Optional[torch.Tensor] = None, classify: bool = True) -> AXL:
         """degree: None (a caller's own edge list, any order), the edge count per node [n_nodes] of a list sorted by source,
         or the triple (degree, offsets, n_edges) of a capacity-sized list (utils/neighbors.get_edges_static).
         embedded: h is already embedding_in(node features) (kernels.egnn_node_inputs); first_proj: the first graph layer's
-        per-node projections [n_nodes, 2H] of that h, when the caller has them."""
+        per-node projections [n_nodes, 2H] of that h, when the caller has them.  classify=False: A is the last layer's h (the
+        caller applies node_classification_layer: kernels.egnn_outputs) and L is None."""
         emb = self.embedding_in
         if embedded:
             assert h.shape[1] == emb.out_features
@@ -389,4 +390,6 @@ class EGNN(nn.Module):
             following = self.graph_layers[k + 1] if k + 1 < len(self.graph_layers) else None
             h, x = layer(h, edges, x, degree, offsets, n_edges, node_proj=proj, next_layer=following)
             proj = layer.__dict__.pop("_next_proj", None)       # left there by the layer's node kernel, if it computed them
+        if not classify:
+            return AXL(A=h, X=x, L=None)
         return AXL(A=self.node_classification_layer(h), X=x, L=torch.zeros_like(x))

@@ -133,6 +133,11 @@ class EGNNScoreNetwork(ScoreNetwork):
             finally:
                 self.graph_status.zero_()
 
+    def _impose_non_mask_atomic_type_prediction(self, output: AXL):
+        """The MASK logit is forced to -inf (score_network.py:183-185) -- already done by mdx_egnn_outputs on the fused path."""
+        if not getattr(output.A, "_mdx_mask_imposed", False):
+            super()._impose_non_mask_atomic_type_prediction(output)
+
     def _first_projection_of_inputs(self):
         """(P W_emb, P b_emb) for the first graph layer's per-node projection matrix P = [W_src; W_dst]: the projections of
         the embedded inputs are then a linear map of [sigma | one_hot] like the embedding itself (no [n_nodes, H] x [H, 2H]
@@ -182,10 +187,9 @@ class EGNNScoreNetwork(ScoreNetwork):
             edges = neighbors.get_edges_batch(n, bsz, device=relative_coordinates.device)
             degree = torch.full((bsz * n,), n - 1, dtype=torch.int64, device=relative_coordinates.device)
             return edges, degree
-        lengths = lattice_parameters[:, :d].clip(min=2.2 * self.radial_cutoff)   # "avoid box collapse" (:236-239)
-        unit_cell = torch.diag_embed(lengths)
         if self.edge_builder is not None:
-            return self.edge_builder(relative_coordinates, unit_cell, self.radial_cutoff)
+            lengths = lattice_parameters[:, :d].clip(min=2.2 * self.radial_cutoff)   # "avoid box collapse" (:236-239)
+            return self.edge_builder(relative_coordinates, torch.diag_embed(lengths), self.radial_cutoff)
         # drop_duplicate_edges (models/egnn_utils.py:138-140) only matters when a pair of atoms is within the cutoff through more
         # than one periodic image; the cell this graph is built in has every length >= 2.2 x cutoff (the clip above), so a pair
         # has at most one such image and the edge MULTISET is the same with and without the de-duplication.  The reference's
@@ -209,9 +213,10 @@ class EGNNScoreNetwork(ScoreNetwork):
                 decisions[key] = (needed <= self.static_edge_list_max_fraction * free, free)
             fits, free = decisions.get(key, (True, 0))
             if fits:
-                edges, degree, offsets, n_edges = neighbors.get_edges_static(relative_coordinates, unit_cell,
-                                                                             self.radial_cutoff, capacity,
-                                                                             status=self.graph_status)
+                # clip, diagonal cell, cartesian positions, count, scan and fill behind one call (three launches)
+                edges, degree, offsets, n_edges = neighbors.get_edges_static_clipped(
+                    relative_coordinates, lattice_parameters.to(torch.float32), 2.2 * self.radial_cutoff, self.radial_cutoff,
+                    capacity, status=self.graph_status)
                 return edges, (degree, offsets, n_edges)
             if not self._logged_two_call_switch:
                 import logging
@@ -220,7 +225,8 @@ class EGNNScoreNetwork(ScoreNetwork):
                     "the two-call protocol (one host read per forward, the sampler iteration is not captured in a hipGraph)",
                     needed / 2 ** 30, free / 2 ** 30)
                 self._logged_two_call_switch = True
-        return neighbors.get_edges_with_radial_cutoff(relative_coordinates, unit_cell, self.radial_cutoff,
+        lengths = lattice_parameters[:, :d].clip(min=2.2 * self.radial_cutoff)       # "avoid box collapse" (:236-239)
+        return neighbors.get_edges_with_radial_cutoff(relative_coordinates, torch.diag_embed(lengths), self.radial_cutoff,
                                                       status=self.graph_status, return_degree=True)
 
     def _forward_unchecked(self, batch: Dict[AnyStr, torch.Tensor], conditional: bool = False) -> AXL:
@@ -247,6 +253,16 @@ class EGNNScoreNetwork(ScoreNetwork):
                                            comp.A.reshape(bsz, n).long().contiguous(), emb.weight.detach().contiguous(),
                                            emb.bias.detach().contiguous(), second=second)
             z, h, first_proj = res if second is not None else (res[0], res[1], None)
+            head = self.egnn.node_classification_layer
+            if head.out_features <= 8 and head.in_features % 4 == 0 and comp.L.dtype == torch.float32:
+                # classification layer (MASK logit at -inf), scores and the zero lattice output: one launch
+                out = self.egnn(h=h, edges=edges, x=z, degree=degree, embedded=True, first_proj=first_proj, classify=False)
+                scores, logits, zeros = kernels.egnn_outputs(
+                    z, out.X.contiguous(), k_vectors.contiguous(), out.A.contiguous(), head.weight.detach().contiguous(),
+                    head.bias.detach().contiguous(), self.num_atom_types, comp.L.numel())
+                logits = logits.reshape(bsz, n, -1)
+                logits._mdx_mask_imposed = True
+                return AXL(A=logits, X=scores.reshape(bsz, n, d), L=zeros.reshape(comp.L.shape))
             out = self.egnn(h=h, edges=edges, x=z, degree=degree, embedded=True, first_proj=first_proj)
             scores = kernels.egnn_scores(z, out.X.contiguous(), k_vectors.contiguous())
             return AXL(A=out.A.reshape(bsz, n, -1), X=scores.reshape(bsz, n, d), L=torch.zeros_like(comp.L))

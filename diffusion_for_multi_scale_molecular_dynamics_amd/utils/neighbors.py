@@ -114,6 +114,15 @@ def get_edges_static(relative_coordinates: torch.Tensor, unit_cell: torch.Tensor
     return out["edges"], out["counts"], out["offsets"], out["n_edges"]
 
 
+def get_edges_static_clipped(relative_coordinates: torch.Tensor, lattice_parameters: torch.Tensor, clip_min: float,
+                             radial_cutoff: float, capacity: int, status: Optional[torch.Tensor] = None):
+    """get_edges_static for the cell EGNNScoreNetwork searches in -- orthogonal, lengths lattice_parameters[:, :3] clipped from
+    below (egnn_score_network.py:236-240) -- straight from the relative coordinates: one call, three launches."""
+    out = kernels.egnn_radius_graph(relative_coordinates.contiguous(), lattice_parameters.contiguous(), clip_min, radial_cutoff,
+                                    capacity, status=status)
+    return out["edges"], out["counts"], out["offsets"], out["n_edges"]
+
+
 def get_edges_batch(n_nodes: int, batch_size: int, device=None) -> torch.Tensor:
     """Fully connected edges without self loops, [B n (n-1), 2], sorted by source (models/egnn_utils.py:73-104)."""
     idx = torch.arange(n_nodes, device=device)

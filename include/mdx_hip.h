@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 8
+#define MDX_ABI_VERSION 9
 
 /* status codes */
 #define MDX_OK 0
@@ -225,6 +225,17 @@ MDX_API int mdx_radius_graph_fill_capped(const float* cartesian_positions, const
                                          int64_t batch, int number_of_atoms, int unique, const int64_t* offsets,
                                          int64_t capacity, int64_t* edges_out, int32_t* image_out, float* shifts_out,
                                          uint32_t* status, mdx_stream_t stream);
+
+/* The graph EGNNScoreNetwork builds per forward (models/score_networks/egnn_score_network.py:236-247): the unique-pair radius
+ * graph of RELATIVE coordinates [batch, N, 3] in the orthogonal cell diag(max(lattice_parameters[b, 0..2], clip_min)) (the
+ * reference clips the cell lengths to 2.2 x cutoff and zeroes the angles), as count -> device-side exclusive scan -> fill: three
+ * launches, no host read, nothing but the caller's buffers (counts, offsets [batch*N]; n_edges [1]; edges_out [capacity, 2]).
+ * Cartesian positions are formed in the kernels as relative x length, the bits of the reference's matmul with the diagonal cell.
+ * lattice_stride = row length of lattice_parameters (>= 3).  Status bits as mdx_radius_graph_count / _fill_capped. */
+MDX_API int mdx_egnn_radius_graph(const float* relative_coordinates, const float* lattice_parameters, int lattice_stride,
+                                  float clip_min, float radial_cutoff, int64_t batch, int number_of_atoms, int64_t capacity,
+                                  int64_t* counts, int64_t* offsets, int64_t* n_edges, int64_t* edges_out, uint32_t* status,
+                                  mdx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused score network: the reference's MLPScoreNetwork (models/score_networks/mlp_score_network.py:54-370,
@@ -440,6 +451,15 @@ MDX_API int mdx_egnn_node_inputs(const float* x, const float* k_vectors, int n_k
                                  const float* second_bias, int second_width, float* second_out, mdx_stream_t stream);
 MDX_API int mdx_egnn_scores(const float* z, const float* x_hat, const float* k_vectors, int n_k, int64_t n_nodes,
                             float* scores_out, mdx_stream_t stream);
+
+/* Everything behind the last graph layer in one launch: logits [n_nodes, num_classes] = EGNN.node_classification_layer(h)
+ * (models/egnn.py:362-385; class_weight [num_classes, H] row-major, num_classes <= 8) with the logit of class `mask_class` set to
+ * -inf (score_network.py:183-185; -1: none), the scores of mdx_egnn_scores, and n_zero zeros into zero_out (nullable with
+ * n_zero = 0): the network's all-zero lattice output. */
+MDX_API int mdx_egnn_outputs(const float* z, const float* x_hat, const float* k_vectors, int n_k, const float* h,
+                             const float* class_weight, const float* class_bias, int H, int num_classes, int mask_class,
+                             int64_t n_nodes, float* scores_out, float* logits_out, float* zero_out, int64_t n_zero,
+                             mdx_stream_t stream);
 
 /* The same pipeline over the ROWS of a matrix (the per-node MLP of an EGNN layer, models/egnn.py:202-230, after its first
  * layer): out[r,:] = residual[r,:] + W_L (SiLU(W_{L-1} ... SiLU(W_1 x[r,:] + b_1) ...)) + b_L -- L = chain->n_message_layers

@@ -361,6 +361,56 @@ def test_radius_graph_static_equals_two_call(cuda):
     assert torch.equal(guard[:small], ref["edges"][:small]) and (guard[small:] == -5).all()
 
 
+@pytest.mark.parametrize("B,N", [(3, 5), (7, 64), (70, 64), (2, 200)])
+def test_egnn_radius_graph_from_relative_coordinates(cuda, B, N):
+    """mdx_egnn_radius_graph (relative coordinates + lattice parameters in, clip / diagonal cell / positions / scan inside: three
+    launches) gives bit for bit what the score network built before from torch.clip, diag_embed, matmul, the two radius-graph
+    launches and torch.cumsum -- lengths below the clip, lists longer than one scan tile (70 x 64 > 4096) and ragged ones
+    included; a capacity that is too small is reported and respected."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
+    g = torch.Generator().manual_seed(100 * B + N)
+    rc = 3.2
+    x = torch.rand(B, N, 3, generator=g).to(cuda)
+    lattice = torch.cat([torch.rand(B, 3, generator=g) * 9.0 + 4.0, torch.zeros(B, 3)], dim=1).to(cuda)   # some < 2.2 rc = 7.04
+    lengths = lattice[:, :3].clip(min=2.2 * rc)
+    cell = torch.diag_embed(lengths)
+    cart = torch.matmul(x, cell).contiguous()
+    status = torch.zeros(1, dtype=torch.int32, device=cuda)
+    capacity = B * N * (N - 1)
+    want = kernels.radius_graph_static(cart, cell.contiguous(), rc, capacity, status=status)
+    got = kernels.egnn_radius_graph(x, lattice, 2.2 * rc, rc, capacity, status=status)
+    E = int(want["n_edges"].item())
+    assert E > 0 and int(got["n_edges"].item()) == E and int(status.item()) == 0
+    assert torch.equal(got["counts"], want["counts"]) and torch.equal(got["offsets"], want["offsets"])
+    assert torch.equal(got["edges"][:E], want["edges"][:E])
+    small = kernels.egnn_radius_graph(x, lattice, 2.2 * rc, rc, E - 3, status=status)
+    assert int(status.item()) == _hip.STATUS_GRAPH_CAPACITY and torch.equal(small["edges"], want["edges"][:E - 3])
+    assert int(small["n_edges"].item()) == E          # the count is the graph's, not the list's
+
+
+@pytest.mark.parametrize("H,C,n_nodes", [(256, 2, 1000), (64, 3, 77), (32, 8, 5)])
+def test_egnn_outputs_against_torch(cuda, H, C, n_nodes):
+    """mdx_egnn_outputs: the classification layer with the MASK logit at -inf, the scores (the bits of mdx_egnn_scores) and the
+    zero lattice output in one launch."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+    from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import \
+        positive_bloch_wave_vectors
+    g = torch.Generator().manual_seed(H + C)
+    kv = positive_bloch_wave_vectors(1, 3).to(cuda)
+    z = torch.randn(n_nodes, 2 * kv.shape[0], generator=g).to(cuda)
+    x_hat = torch.randn(n_nodes, 2 * kv.shape[0], generator=g).to(cuda)
+    h = torch.randn(n_nodes, H, generator=g).to(cuda)
+    head = torch.nn.Linear(H, C).to(cuda)
+    scores, logits, zeros = kernels.egnn_outputs(z, x_hat, kv, h, head.weight.detach(), head.bias.detach(), C - 1, 42)
+    assert torch.equal(scores, kernels.egnn_scores(z, x_hat, kv))
+    want = torch.nn.functional.linear(h.double(), head.weight.detach().double(), head.bias.detach().double())
+    assert _rel_l2(logits[:, :C - 1], want[:, :C - 1]) < 1e-6
+    assert torch.isinf(logits[:, C - 1]).all() and (logits[:, C - 1] < 0).all()
+    assert zeros.shape == (42,) and not zeros.any()
+    _, plain, _ = kernels.egnn_outputs(z, x_hat, kv, h, head.weight.detach(), head.bias.detach(), -1, 0)
+    assert _rel_l2(plain, want) < 1e-6
+
+
 @pytest.mark.parametrize("precision", CHAIN_MODES)
 def test_egnn_sampler_graph_replay_equals_eager(cuda, precision):
     """The EGNN sampler iteration (radius graph with a capacity-sized edge list + fused edge chain: no host read) captured
@@ -592,15 +642,17 @@ def test_edge_chain_tile_order_covers_every_tile(cuda, n_tiles):
         assert _rel_l2(got_s[:E], want_s) < 1e-5
 
 
-def test_egnn_node_inputs_and_scores_against_torch(cuda):
+@pytest.mark.parametrize("H", [96, 30, 256])
+def test_egnn_node_inputs_and_scores_against_torch(cuda, H):
     """mdx_egnn_node_inputs / mdx_egnn_scores against the expressions they replace in EGNNScoreNetwork: the embedded node
     features bit for bit (a one-hot input is a column pick: the same binary32 operations), the torus uplift and the score
-    contraction to rounding (a different summation order over three / 2 n_k terms)."""
+    contraction to rounding (a different summation order over three / 2 n_k terms).  H = 30: the element-wise kernel; the
+    others: one wavefront per node with 16-byte stores."""
     from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
     from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import (
         EGNNScoreNetwork, positive_bloch_wave_vectors)
     g = torch.Generator().manual_seed(5)
-    B, N, C, H = 7, 13, 2, 96
+    B, N, C = 7, 13, 2
     x = torch.rand(B, N, 3, generator=g).to(cuda)
     sigma = (torch.rand(B, 1, generator=g) * 0.5 + 0.01).to(cuda)
     a = torch.randint(0, C + 1, (B, N), generator=g).to(cuda)             # MASK class included
