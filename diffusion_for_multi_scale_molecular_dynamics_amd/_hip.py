@@ -26,7 +26,8 @@ ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
     "mdx_relative_coordinates_update_dev", "mdx_lattice_parameters_update_dev",
-    "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types",
+    "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types", "mdx_noise_relative_coordinates_sigmas", "mdx_noise_atom_types_per_atom",
+    "mdx_noise_lattice_parameters",
     "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_radius_graph_fill_capped", "mdx_egnn_radius_graph", "mdx_mlp_forward",
     "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_variant", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
     "mdx_egnn_chain_image_bytes", "mdx_egnn_chain_pack", "mdx_egnn_edge_chain", "mdx_egnn_piece_rows", "mdx_segment_combine", "mdx_egnn_node_gather", "mdx_mlp_chain_rows", "mdx_egnn_coord_aggregate",
@@ -146,6 +147,12 @@ def _declare(L):
     L.mdx_noise_relative_coordinates.argtypes = [vp, vp, f32, i64, vp, vp]
     L.mdx_noise_atom_types.restype = i32
     L.mdx_noise_atom_types.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+    L.mdx_noise_atom_types_per_atom.restype = i32
+    L.mdx_noise_atom_types_per_atom.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+    L.mdx_noise_relative_coordinates_sigmas.restype = i32
+    L.mdx_noise_relative_coordinates_sigmas.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.mdx_noise_lattice_parameters.restype = i32
+    L.mdx_noise_lattice_parameters.argtypes = [vp, vp, vp, i64, vp, vp]
     L.mdx_repaint_constrained_rows.restype = i32
     L.mdx_repaint_constrained_rows.argtypes = [C.POINTER(Schedule), i32, vp, vp, vp, vp, i32, vp, vp, Rng, i64, i32,
                                                i32, vp, vp, vp]

@@ -282,6 +282,21 @@ __global__ __launch_bounds__(kBlock) void noise_coords_kernel(const float* x0, c
         out[i] = wrap01(x0[i] + sigma * z[i]);
 }
 
+// the reference's own signatures: one sigma per element (noisers/relative_coordinates_noiser.py:33-67, lattice_noiser.py:47-81)
+__global__ __launch_bounds__(kBlock) void noise_coords_sigmas_kernel(const float* x0, const float* z, const float* sigmas,
+                                                                     int64_t count, float* out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = wrap01(x0[i] + sigmas[i] * z[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void noise_lattice_kernel(const float* l0, const float* z, const float* sigmas_n,
+                                                               int64_t count, float* out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = sigmas_n[i] * z[i] + l0[i];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // P2 (+P1 +P3): fused per-step update
 // ---------------------------------------------------------------------------------------------------------------
@@ -1450,13 +1465,14 @@ __device__ __forceinline__ int noised_atom_type(int a0, const float* __restrict_
     return arg;
 }
 
-__global__ __launch_bounds__(kBlock) void noise_atom_types_kernel(const int64_t* a0, const float* qbar, const float* u,
-                                                                  int64_t n_atoms, int C, int64_t* out)
+// atom_stride: 0 = one [C,C] matrix for every atom, C*C = a matrix per atom (the reference's broadcast q_bar [..., C, C])
+__global__ __launch_bounds__(kBlock) void noise_atom_types_kernel(const int64_t* a0, const float* qbar, int64_t atom_stride,
+                                                                  const float* u, int64_t n_atoms, int C, int64_t* out)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_atoms; i += (int64_t)gridDim.x * blockDim.x) {
         float uu[MDX_MAX_CLASSES];
         for (int c = 0; c < C; ++c) uu[c] = u[i * C + c];
-        out[i] = noised_atom_type((int)a0[i], qbar, C, uu, true);
+        out[i] = noised_atom_type((int)a0[i], qbar + i * atom_stride, C, uu, true);
     }
 }
 
@@ -2090,7 +2106,39 @@ int mdx_noise_atom_types(const int64_t* a0, const float* q_bar, const float* u, 
     if (n_atoms == 0) return MDX_OK;
     if (!a0 || !q_bar || !u || !out) return MDX_ERR_INVALID_ARG;
     hipLaunchKernelGGL(noise_atom_types_kernel, dim3(flat_grid(n_atoms)), dim3(kBlock), 0, as_stream(stream), a0, q_bar,
-                       u, n_atoms, num_classes, out);
+                       (int64_t)0, u, n_atoms, num_classes, out);
+    return launch_status();
+}
+
+int mdx_noise_atom_types_per_atom(const int64_t* a0, const float* q_bar, const float* u, int64_t n_atoms, int num_classes,
+                                  int64_t* out, mdx_stream_t stream)
+{
+    if (n_atoms < 0 || num_classes < 2) return MDX_ERR_INVALID_ARG;
+    if (num_classes > MDX_MAX_CLASSES) return MDX_ERR_UNSUPPORTED;
+    if (n_atoms == 0) return MDX_OK;
+    if (!a0 || !q_bar || !u || !out) return MDX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(noise_atom_types_kernel, dim3(flat_grid(n_atoms)), dim3(kBlock), 0, as_stream(stream), a0, q_bar,
+                       (int64_t)num_classes * num_classes, u, n_atoms, num_classes, out);
+    return launch_status();
+}
+
+int mdx_noise_relative_coordinates_sigmas(const float* x0, const float* z, const float* sigmas, int64_t count, float* out,
+                                          mdx_stream_t stream)
+{
+    if (count < 0 || (count > 0 && (!x0 || !z || !sigmas || !out))) return MDX_ERR_INVALID_ARG;
+    if (count == 0) return MDX_OK;
+    hipLaunchKernelGGL(noise_coords_sigmas_kernel, dim3(flat_grid(count)), dim3(kBlock), 0, as_stream(stream), x0, z, sigmas,
+                       count, out);
+    return launch_status();
+}
+
+int mdx_noise_lattice_parameters(const float* l0, const float* z, const float* sigmas_n, int64_t count, float* out,
+                                 mdx_stream_t stream)
+{
+    if (count < 0 || (count > 0 && (!l0 || !z || !sigmas_n || !out))) return MDX_ERR_INVALID_ARG;
+    if (count == 0) return MDX_OK;
+    hipLaunchKernelGGL(noise_lattice_kernel, dim3(flat_grid(count)), dim3(kBlock), 0, as_stream(stream), l0, z, sigmas_n, count,
+                       out);
     return launch_status();
 }
 

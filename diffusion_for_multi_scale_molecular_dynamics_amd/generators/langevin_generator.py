@@ -155,6 +155,93 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         return self.noise_source.rand(number_of_samples, self.number_of_atoms)
 
     # ---------------------------------------------------------------------------------------------------------
+    # the reference's private update methods, same names and operands (langevin_generator.py:155-534, 669-691): what its
+    # unit tests and subclasses call.  Each is ONE stand-alone kernel (P1 / P2 / P3); the sampling loop itself goes through
+    # the fused per-step kernel (_step), which computes the same expressions.
+    # ---------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _three_scalars(score_weight, gaussian_noise_weight, sigma, like: torch.Tensor) -> torch.Tensor:
+        """{score weight, noise weight, sigma} as float32 [3] on the device (no host read).  The reference broadcasts these
+        against the whole batch; the sampler only ever passes one value each (g2_i, g_i, sigma_i of ONE time index)."""
+        vals = []
+        for name, v in (("score_weight", score_weight), ("gaussian_noise_weight", gaussian_noise_weight), ("sigma", sigma)):
+            t = torch.as_tensor(v)
+            if t.numel() != 1:
+                raise MdxError(f"{name}: one value per call is supported (got shape {tuple(t.shape)}); the sampler's steps "
+                               "are taken at a single time index")
+            vals.append(t.reshape(()).to(device=like.device, dtype=torch.float32))
+        return torch.stack(vals)
+
+    def _relative_coordinates_update(self, relative_coordinates: torch.Tensor, sigma_normalized_scores: torch.Tensor,
+                                     sigma_i: torch.Tensor, score_weight: torch.Tensor, gaussian_noise_weight: torch.Tensor,
+                                     z: Optional[torch.Tensor]) -> torch.Tensor:
+        """wrap(x + score_weight * s / sigma_i + gaussian_noise_weight * z)  (:155-201); z None: drawn here."""
+        x = relative_coordinates
+        if z is None:
+            z = self._draw_coordinates_gaussian_sample(x.shape[0])
+        weights = self._three_scalars(score_weight, gaussian_noise_weight, sigma_i, x)
+        return kernels.relative_coordinates_update(x.contiguous(), sigma_normalized_scores.to(x).contiguous(),
+                                                   z.to(x).contiguous(), weights=weights)
+
+    _relative_coordinates_update_predictor_step = _relative_coordinates_update       # (:203-245: both return the generic one)
+    _relative_coordinates_update_corrector_step = _relative_coordinates_update
+
+    def _lattice_parameters_update(self, lattice_parameters: torch.Tensor, sigma_normalized_scores: torch.Tensor,
+                                   sigma_n_i: torch.Tensor, score_weight: torch.Tensor, gaussian_noise_weight: torch.Tensor,
+                                   z: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """l + score_weight * s / sigma_n_i + gaussian_noise_weight * z; the input itself when the lattice is fixed  (:441-490)."""
+        if self.use_fixed_lattice_parameters:
+            return lattice_parameters
+        lat = lattice_parameters
+        if z is None:
+            z = self._draw_lattice_gaussian_sample(lat.shape[0])
+        weights = self._three_scalars(score_weight, gaussian_noise_weight, sigma_n_i, lat)
+        return kernels.lattice_parameters_update(lat.contiguous(), sigma_normalized_scores.to(lat).contiguous(),
+                                                 z.to(lat).contiguous(), weights=weights)
+
+    _lattice_parameters_update_predictor_step = _lattice_parameters_update           # (:492-534)
+    _lattice_parameters_update_corrector_step = _lattice_parameters_update
+
+    def _atom_types_update(self, predicted_logits: torch.Tensor, atom_types_i: torch.LongTensor, q_matrices_i: torch.Tensor,
+                           q_bar_matrices_i: torch.Tensor, q_bar_tm1_matrices_i: torch.Tensor,
+                           atom_type_greedy_sampling: bool, one_atom_type_transition_per_step: bool) -> torch.LongTensor:
+        """a_{i-1} ~ p(a_{i-1} | a_i, logits) with the Gumbel trick, greedy MASK handling and the one-transition rule
+        (:247-337).  The three matrices: [C, C], or the reference's [number_of_samples, number_of_atoms, C, C] broadcast of
+        one time index's matrix (its first entry is used)."""
+        logits = predicted_logits
+        batch = logits.shape[0]
+        gumbel = self._draw_gumbel_sample(batch).to(device=logits.device, dtype=torch.float32).contiguous()
+        u = None
+        if atom_type_greedy_sampling:                           # drawn inside _adjust_..._for_greedy_sampling (:417)
+            u = self._draw_binary_sample(batch).to(device=logits.device, dtype=torch.float32).contiguous()
+        q, q_bar, q_bar_tm1 = [m.reshape(-1, m.shape[-2], m.shape[-1])[0].to(logits).contiguous()
+                               for m in (q_matrices_i, q_bar_matrices_i, q_bar_tm1_matrices_i)]
+        a_in = atom_types_i.to(logits.device).contiguous()
+        a_out, probs = kernels.atom_types_update(logits.contiguous(), a_in, q, q_bar, q_bar_tm1, gumbel, u, self.small_epsilon,
+                                                 atom_type_greedy_sampling, one_atom_type_transition_per_step,
+                                                 return_probabilities=True)
+        if self.record_atom_type_update:
+            if atom_type_greedy_sampling:                       # the Gumbel rows of fully masked samples are kept (:419-437)
+                all_masked = (a_in == self.masked_atom_type_index).all(dim=-1)
+                gumbel = torch.where(all_masked.view(-1, 1, 1), gumbel, torch.zeros_like(gumbel))
+            self.sample_trajectory_recorder.record(key="atom_type_update", entry=dict(
+                predicted_logits=logits.detach().cpu(), one_step_transition_probabilities=probs.cpu(),
+                gumbel_sample=gumbel.cpu(), a_i=a_in.cpu(), a_im1=a_out.cpu()))
+        return a_out
+
+    def _get_coordinates_corrector_step_size(self, index_i: int, sigma_i: torch.Tensor, model_predictions_i: torch.Tensor,
+                                             z: torch.Tensor) -> torch.Tensor:
+        """epsilon_i of the tabulated Langevin dynamics, indexed with 0..T-1  (:669-679)."""
+        self._prepare(model_predictions_i.device)
+        return self.langevin_dynamics.epsilon[index_i].to(model_predictions_i)
+
+    def _get_lattice_parameters_corrector_step_size(self, index_i: int, sigma_n_i: torch.Tensor,
+                                                    model_predictions_i: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+        """(:681-691)"""
+        self._prepare(model_predictions_i.device)
+        return self.langevin_dynamics.epsilon[index_i].to(model_predictions_i)
+
+    # ---------------------------------------------------------------------------------------------------------
     # network
     # ---------------------------------------------------------------------------------------------------------
     def _get_model_predictions(self, composition: AXL, time_tensor: torch.Tensor, sigma_noise_tensor: torch.Tensor,

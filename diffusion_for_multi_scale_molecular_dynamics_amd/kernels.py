@@ -167,19 +167,44 @@ def pc_step_update(sched: DeviceSchedule, mode: int, index_i: int, d_index: Opti
 # ----------------------------------------------------------------------------------------------------------------
 # F1 / F2 / R1
 # ----------------------------------------------------------------------------------------------------------------
-def noise_relative_coordinates(x0, z, sigma: float, out=None):
+def noise_relative_coordinates(x0, z, sigma, out=None):
+    """wrap(x0 + sigma z); sigma: one number, or a tensor of x0's shape (the reference's per-element sigmas)."""
     assert x0.shape == z.shape
     out = torch.empty_like(x0) if out is None else out
+    if isinstance(sigma, torch.Tensor):
+        assert sigma.shape == x0.shape, "sigmas array is expected to be of the same shape as the real_relative_coordinates array"
+        rc = lib().mdx_noise_relative_coordinates_sigmas(ptr(x0, F32, "x0"), ptr(z, F32, "z"), ptr(sigma, F32, "sigmas"),
+                                                         x0.numel(), ptr(out, F32, "out"), stream_handle())
+        check(rc, "mdx_noise_relative_coordinates_sigmas")
+        return out
     rc = lib().mdx_noise_relative_coordinates(ptr(x0, F32, "x0"), ptr(z, F32, "z"), float(sigma), x0.numel(),
                                               ptr(out, F32, "out"), stream_handle())
     check(rc, "mdx_noise_relative_coordinates")
     return out
 
 
+def noise_lattice_parameters(l0, z, sigmas_n):
+    """sigmas_n * z + l0, element by element (mdx_noise_lattice_parameters)."""
+    assert l0.shape == z.shape == sigmas_n.shape
+    out = torch.empty_like(l0)
+    rc = lib().mdx_noise_lattice_parameters(ptr(l0, F32, "l0"), ptr(z, F32, "z"), ptr(sigmas_n, F32, "sigmas_n"), l0.numel(),
+                                            ptr(out, F32, "out"), stream_handle())
+    check(rc, "mdx_noise_lattice_parameters")
+    return out
+
+
 def noise_atom_types(a0, q_bar, u):
+    """q_bar: one [C, C] matrix for the call, or one per atom [*a0.shape, C, C]."""
     Cn = u.shape[-1]
-    assert q_bar.shape == (Cn, Cn) and u.shape[:-1] == a0.shape
+    assert u.shape[:-1] == a0.shape
     out = torch.empty_like(a0)
+    if q_bar.dim() > 2:
+        assert q_bar.shape == tuple(a0.shape) + (Cn, Cn), "q_bar array first dimensions should match real_atom_types array"
+        rc = lib().mdx_noise_atom_types_per_atom(ptr(a0, I64, "a0"), ptr(q_bar, F32, "q_bar"), ptr(u, F32, "u"), a0.numel(),
+                                                 Cn, ptr(out, I64, "out"), stream_handle())
+        check(rc, "mdx_noise_atom_types_per_atom")
+        return out
+    assert q_bar.shape == (Cn, Cn)
     rc = lib().mdx_noise_atom_types(ptr(a0, I64, "a0"), ptr(q_bar, F32, "q_bar"), ptr(u, F32, "u"), a0.numel(), Cn,
                                     ptr(out, I64, "out"), stream_handle())
     check(rc, "mdx_noise_atom_types")

@@ -176,6 +176,19 @@ MDX_API int mdx_noise_relative_coordinates(const float* x0, const float* z, floa
 MDX_API int mdx_noise_atom_types(const int64_t* a0, const float* q_bar, const float* u, int64_t n_atoms, int num_classes,
                          int64_t* out, mdx_stream_t stream);
 
+/* F1 / F2 / F3 with the reference's own operands -- one sigma per ELEMENT, one cumulative transition matrix per ATOM (the training
+ * transform hands the noisers tensors broadcast from per-structure values, data/diffusion/noising_transform.py:140-195):
+ *   mdx_noise_relative_coordinates_sigmas   out = wrap(x0 + sigmas * z)           (relative_coordinates_noiser.py:56-66)
+ *   mdx_noise_atom_types_per_atom           q_bar [n_atoms, C, C]; a one-hot a0 times q_bar is the row pick a0 -> q_bar[a0,:]
+ *                                           (every other term an exact zero)      (atom_types_noiser.py:42-60)
+ *   mdx_noise_lattice_parameters            out = sigmas_n * z + l0               (lattice_noiser.py:69-81) */
+MDX_API int mdx_noise_relative_coordinates_sigmas(const float* x0, const float* z, const float* sigmas, int64_t count,
+                                                  float* out, mdx_stream_t stream);
+MDX_API int mdx_noise_atom_types_per_atom(const int64_t* a0, const float* q_bar, const float* u, int64_t n_atoms,
+                                          int num_classes, int64_t* out, mdx_stream_t stream);
+MDX_API int mdx_noise_lattice_parameters(const float* l0, const float* z, const float* sigmas_n, int64_t count, float* out,
+                                         mdx_stream_t stream);
+
 /* R1 -- ConstrainedLangevinGenerator._repaint_composition (generators/constrained_langevin_generator.py:136-163):
  * for each sample and each constrained row k: forward-noise the known (x_k, a_k) to time index `index_i`
  * (NoisingTransform.transform_given_time_index, data/diffusion/noising_transform.py:98-200; identity when

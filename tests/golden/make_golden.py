@@ -396,6 +396,31 @@ def golden_noisers():
             out[f"{nm}/qbar"] = _np(noise.q_bar_matrix[idx])
             out[f"{nm}/at"] = _np(at)
     out["f2_names"] = np.array(names)
+    # the operands the training transform hands over (noising_transform.py:140-195): a time index PER STRUCTURE, hence a
+    # cumulative transition matrix per atom (F2) and a sigma per element that differs between structures (F1 above, F3 here)
+    C, T = 3, 10
+    sched = NoiseScheduler(NoiseParameters(total_time_steps=T), num_classes=C)
+    noise, _ = sched.get_all_sampling_parameters()
+    indices = torch.randint(0, T, (B,), generator=g)
+    a0 = torch.randint(0, C, (B, N), generator=g)                  # MASK as a starting class included
+    u = torch.rand(B, N, C, generator=g)
+    AtomTypesNoiser._get_uniform_noise = staticmethod(lambda shape, u=u: u.clone())
+    qb = noise.q_bar_matrix[indices][:, None, :, :].expand(B, N, C, C).contiguous()
+    at = AtomTypesNoiser.get_noisy_atom_types_sample(class_index_to_onehot(a0, C), qb)
+    out.update(f2b_a0=_np(a0), f2b_u=_np(u), f2b_qbar=_np(qb), f2b_at=_np(at))
+    from diffusion_for_multi_scale_molecular_dynamics.noisers.lattice_noiser import LatticeDataParameters, LatticeNoiser
+    orig_lattice = LatticeNoiser.__dict__["_get_gaussian_noise"]
+    l0 = torch.rand(B, 6, generator=g) * 4.0 + 3.0
+    sigmas_n = (torch.rand(B, 1, generator=g) * 0.3).expand(B, 6).contiguous()
+    zl = torch.randn(B, 6, generator=g)
+    LatticeNoiser._get_gaussian_noise = staticmethod(lambda shape: zl.clone())
+    lt = LatticeNoiser(LatticeDataParameters(spatial_dimension=3, use_fixed_lattice_parameters=False)) \
+        .get_noisy_lattice_parameters(l0, sigmas_n)
+    fixed = LatticeNoiser(LatticeDataParameters(spatial_dimension=3, use_fixed_lattice_parameters=True)) \
+        .get_noisy_lattice_parameters(l0, sigmas_n)
+    assert torch.equal(fixed, l0)
+    out.update(f3_l0=_np(l0), f3_sigmas_n=_np(sigmas_n), f3_z=_np(zl), f3_lt=_np(lt))
+    LatticeNoiser._get_gaussian_noise = orig_lattice
     RelativeCoordinatesNoiser._get_gaussian_noise = orig_gauss
     AtomTypesNoiser._get_uniform_noise = orig_unif
     save("noisers.npz", **out)
@@ -829,6 +854,8 @@ if __name__ == "__main__":
         golden_neighbors()
         golden_trajectories()
         golden_networks()
+    if which in ("noisers",):
+        golden_noisers()
     if which in ("all", "next"):
         golden_next()
     if which in ("all", "distances"):

@@ -587,6 +587,74 @@ def test_atom_type_update_recording(cuda):
         assert ulp_diff(e["one_step_transition_probabilities"].numpy(), g["rec_one_step_transition_probabilities"][k]).max() <= 4
 
 
+def test_reference_private_update_methods_against_golden(cuda):
+    """LangevinGenerator._relative_coordinates_update / _lattice_parameters_update / _atom_types_update (and their
+    _predictor_step / _corrector_step aliases, the corrector step sizes): the reference's private methods under the reference's
+    names and operands -- tests/golden/make_golden.py called exactly these on the reference's generator to produce
+    p1_coordinates / p3_lattice / p2_atom_types; here the same calls go to the HIP generator.  Coordinates, lattice and atom
+    types bit for bit, the recorded transition probabilities within 4 ulp (exp inside the softmax)."""
+    from conftest import load_golden, ulp_diff
+    P = _pkg()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+    def generator(num_atom_types, greedy=True, one=True, fixed=True, T=10, N=8, record=False):
+        npar = P["Noise"](**cases.noise_ns(T))
+        skw = cases.sampling_ns(N, num_atom_types, greedy=greedy, one=one, fixed=fixed)
+        if record:
+            skw.update(record_samples=True, record_atom_type_update=True)
+        gen = P["Langevin"](npar, P["Sampling"](**skw), nets.fake_net(num_atom_types))
+        gen._prepare(cuda)
+        return gen
+
+    g = load_golden("p1_coordinates.npz")
+    gen = generator(1)
+    for k in range(len(g["scalars"])):
+        w, n, sig = (torch.tensor(v) for v in g["scalars"][k])
+        for method in (gen._relative_coordinates_update, gen._relative_coordinates_update_predictor_step,
+                       gen._relative_coordinates_update_corrector_step):
+            got = method(t(g["x"]).to(cuda), t(g["s"]).to(cuda), sig, w, n, t(g["z"]).to(cuda))
+            assert np.array_equal(got.cpu().numpy(), g["x_out"][k])
+    # z = None: the draw comes from the generator's own hook, like the reference's (:190-193)
+    gen._draw_coordinates_gaussian_sample = lambda number_of_samples: t(g["z"])
+    w, n, sig = (torch.tensor(v).to(cuda) for v in g["scalars"][0])          # device scalars: no host read needed
+    got = gen._relative_coordinates_update(t(g["x"]).to(cuda), t(g["s"]).to(cuda), sig, w, n, None)
+    assert np.array_equal(got.cpu().numpy(), g["x_out"][0])
+    with pytest.raises(Exception, match="one value per call"):
+        gen._relative_coordinates_update(t(g["x"]).to(cuda), t(g["s"]).to(cuda), torch.ones(6), w, n, t(g["z"]).to(cuda))
+
+    g = load_golden("p3_lattice.npz")
+    free, fixed = generator(1, fixed=False), generator(1, fixed=True)
+    for k in range(len(g["scalars"])):
+        w, n, _, sigma_n = (torch.tensor(v) for v in g["scalars"][k])
+        for method in (free._lattice_parameters_update, free._lattice_parameters_update_predictor_step,
+                       free._lattice_parameters_update_corrector_step):
+            got = method(t(g["l"]).to(cuda), t(g["s"]).to(cuda), sigma_n, w, n, t(g["z"]).to(cuda))
+            assert np.array_equal(got.cpu().numpy(), g["l_out"][k])
+        lat = t(g["l"]).to(cuda)
+        assert fixed._lattice_parameters_update(lat, t(g["s"]).to(cuda), sigma_n, w, n, t(g["z"]).to(cuda)) is lat
+    eps = free._get_coordinates_corrector_step_size(3, torch.tensor(0.1), t(g["s"]).to(cuda), None)
+    assert eps.is_cuda and float(eps) == float(free.langevin_dynamics.epsilon[3])
+    assert float(free._get_lattice_parameters_corrector_step_size(0, None, t(g["s"]).to(cuda), None)) == \
+        float(free.langevin_dynamics.epsilon[0])
+
+    g = load_golden("p2_atom_types.npz")
+    for name in g["names"]:
+        greedy, one_eff, idx, T = (int(v) for v in g[f"{name}/flags"])
+        C = g[f"{name}/logits"].shape[-1]
+        gen = generator(C - 1, greedy=bool(greedy), one=bool(one_eff), T=T, record=True)
+        gen._draw_gumbel_sample = lambda number_of_samples: t(g[f"{name}/gumbel"])
+        gen._draw_binary_sample = lambda number_of_samples: t(g[f"{name}/u"])
+        B, N = g[f"{name}/a"].shape
+        q, qb, qbm = [t(g[f"{name}/{k}"]).to(cuda)[None, None].expand(B, N, C, C) for k in ("q", "qbar", "qbar_tm1")]
+        a_out = gen._atom_types_update(t(g[f"{name}/logits"]).to(cuda), t(g[f"{name}/a"]).to(cuda), q, qb, qbm,
+                                       atom_type_greedy_sampling=bool(greedy), one_atom_type_transition_per_step=bool(one_eff))
+        assert np.array_equal(a_out.cpu().numpy(), g[f"{name}/a_out"]), name
+        rec = gen.sample_trajectory_recorder._internal_data["atom_type_update"][0]
+        assert np.array_equal(rec["gumbel_sample"].numpy(), g[f"{name}/gumbel_used"]), name
+        assert ulp_diff(rec["one_step_transition_probabilities"].numpy(), g[f"{name}/p"]).max() <= 4, name
+        assert np.array_equal(rec["a_i"].numpy(), g[f"{name}/a"]) and np.array_equal(rec["a_im1"].numpy(), g[f"{name}/a_out"])
+
+
 def test_noising_transform_given_time_index(cuda, oracle):
     """F1 + F2 + F3 behind the reference's NoisingTransform.transform_given_time_index, against the oracle on the draws
     torch's CPU generator produces for a fixed seed (same order: X noise, A noise, L noise)."""

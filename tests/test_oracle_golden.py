@@ -95,6 +95,11 @@ def test_noisers(oracle):
                               g["f1_xt"][b])
     for nm in g["f2_names"]:
         assert np.array_equal(oracle.noise_atom_types(g[f"{nm}/a0"], g[f"{nm}/qbar"], g[f"{nm}/u"]), g[f"{nm}/at"])
+    # the reference's own operand forms: a matrix per atom (constant within a structure), a sigma per element
+    for b in range(g["f2b_a0"].shape[0]):
+        assert np.array_equal(oracle.noise_atom_types(g["f2b_a0"][b:b + 1], g["f2b_qbar"][b, 0], g["f2b_u"][b:b + 1]),
+                              g["f2b_at"][b:b + 1])
+    assert np.array_equal(g["f3_sigmas_n"] * g["f3_z"] + g["f3_l0"], g["f3_lt"])
 
 
 def test_radius_graph(oracle):
