@@ -1007,6 +1007,14 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.lo[0][ks], a0, 0, 0, 0);
                     if (MDX_CHAIN_DMA_POS == 3 && C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.lo[1][ks], a1, 0, 0, 0);
+#ifdef MDX_CHAIN_DUMMY_VALU      // (calibration: MDX_CHAIN_DUMMY_VALU more independent vector instructions per k-step)
+#pragma unroll
+                    for (int dv = 0; dv < MDX_CHAIN_DUMMY_VALU + 0; ++dv) { float dummy_; asm volatile("v_mov_b32 %0, 0" : "=v"(dummy_)); }
+#endif
+#ifdef MDX_CHAIN_DUMMY_TRANS     // (the same with a transcendental)
+#pragma unroll
+                    for (int dv = 0; dv < MDX_CHAIN_DUMMY_TRANS + 0; ++dv) { float dummy_; asm volatile("v_exp_f32 %0, 1.0" : "=v"(dummy_)); }
+#endif
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].lo, in.hi[0][ks], a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].lo, in.hi[1][ks], a1, 0, 0, 0);
                     if (MDX_CHAIN_DMA_POS == 6 && C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
