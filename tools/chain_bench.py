@@ -25,6 +25,9 @@ ap.add_argument("--piece-sums", action="store_true", help="aggregate the message
 ap.add_argument("--stamps", action="store_true", help="with a -DMDX_CHAIN_STAMPS build: print the stamped intervals")
 ap.add_argument("--clocks", action="store_true", help="with a -DMDX_CHAIN_STAMPS=2 build: the shader clock during a launch")
 ap.add_argument("--rows", action="store_true", help="also time the row chain (mdx_mlp_chain_rows): --nodes rows, --n-crd layers + residual")
+ap.add_argument("--zero-activations", action="store_true", help="zero projections, coordinates and biases: every activation of "
+                "every layer is an exact zero while the weights stay random (what the same instruction stream costs without "
+                "operand switching activity)")
 ap.add_argument("--lib", default=None, help="alternative libmdx_hip.so (ablation builds)")
 args = ap.parse_args()
 if args.lib:
@@ -43,6 +46,11 @@ dst = (src // 64) * 64 + torch.randint(0, 64, (E,), device=dev)
 edges = torch.stack([src, dst], 1).contiguous()
 proj = torch.randn(n_nodes, 2 * H, device=dev)
 coord = torch.rand(n_nodes, 6, device=dev)
+if args.zero_activations:
+    with torch.no_grad():
+        proj.zero_(); coord.zero_(); lin0.bias.zero_()
+        for layer in msg + crd:
+            layer.bias.zero_()
 flops = 2.0 * E * H * H * (n_msg + n_crd)
 res = {"edges": E, "hidden": H, "layers": n_msg + n_crd, "algorithmic_gflop": flops / 1e9}
 with torch.no_grad():
