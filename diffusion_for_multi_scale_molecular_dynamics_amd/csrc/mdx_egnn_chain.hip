@@ -564,7 +564,28 @@ __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const 
 // (tools/tile_stats.py) -- and no step waits on a chain of nine dependent instructions.  The last pair is complete at the
 // end of step 13: the tile that follows a layer's last tile reads these values in its steps 14 and 15 (the 16x16 shape: all
 // sixteen as one k-step of 32 in both; the 32x32 shape: eight in each).
+// The six operations of a value -- 0: A from the accumulator, t = A c   1: e = 2^t   2: d = k + k e   3: r = 1 / d   4: y = A r
+// 5: split into the operand registers -- are dealt to the steps by kOpStep (step offset of each operation from the pair's
+// first step); MDX_CHAIN_EPI_STAGES picks the dealing (timing experiments; 3 = the form described above).
+#ifndef MDX_CHAIN_EPI_STAGES
+#define MDX_CHAIN_EPI_STAGES 3
+#endif
+#if MDX_CHAIN_EPI_STAGES == 3
 constexpr int kPairStart[8] = {0, 1, 3, 4, 6, 8, 9, 11};
+constexpr int kOpStep[6] = {0, 0, 1, 1, 1, 2};
+#elif MDX_CHAIN_EPI_STAGES == 4
+constexpr int kPairStart[8] = {0, 1, 3, 4, 6, 7, 9, 10};
+constexpr int kOpStep[6] = {0, 0, 1, 1, 2, 3};
+#elif MDX_CHAIN_EPI_STAGES == 5
+constexpr int kPairStart[8] = {0, 1, 2, 4, 5, 6, 8, 9};
+constexpr int kOpStep[6] = {0, 1, 2, 2, 3, 4};
+#elif MDX_CHAIN_EPI_STAGES == 6
+constexpr int kPairStart[8] = {0, 1, 2, 3, 4, 5, 6, 8};
+constexpr int kOpStep[6] = {0, 1, 2, 3, 4, 5};
+#elif MDX_CHAIN_EPI_STAGES == 44          // exp and rcp each alone in a step, their neighbours paired
+constexpr int kPairStart[8] = {0, 1, 3, 4, 6, 7, 9, 10};
+constexpr int kOpStep[6] = {0, 1, 2, 2, 3, 3};
+#endif
 template <int H>
 struct EpiloguePipe {
     float a[8][2], e[8][2];
@@ -573,20 +594,36 @@ struct EpiloguePipe {
     {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            if (s == kPairStart[j]) {
+#pragma unroll
+            for (int op = 0; op < 6; ++op) {
+                if (s != kPairStart[j] + kOpStep[op]) continue;
+                if (op == 5) {
+                    put_pair<H>(dst, tp, 2 * j, e[j][0], e[j][1]);
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    a[j][i] = pend[2 * j + i];
-                    e[j][i] = __builtin_amdgcn_exp2f(a[j][i] * sc.neg_c);
+                    if (op == 0) {
+                        a[j][i] = pend[2 * j + i];
+                        e[j][i] = a[j][i] * sc.neg_c;
+                    } else if (op == 1) {
+#if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 128)      // (timing only: a plain instruction in place of v_exp_f32)
+                        e[j][i] = __builtin_fmaf(e[j][i], 0.0f, 1.0f);
+#else
+                        e[j][i] = __builtin_amdgcn_exp2f(e[j][i]);
+#endif
+                    } else if (op == 2) {
+                        e[j][i] = __builtin_fmaf(e[j][i], sc.k, sc.k);
+                    } else if (op == 3) {
+#if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 256)      // (timing only: a plain instruction in place of v_rcp_f32)
+                        e[j][i] = __builtin_fmaf(e[j][i], 0.0f, 0.5f * sc.inv_a);
+#else
+                        e[j][i] = __builtin_amdgcn_rcpf(e[j][i]);
+#endif
+                    } else {
+                        e[j][i] = linear ? a[j][i] * sc.inv_a : a[j][i] * e[j][i];
+                    }
                 }
-            } else if (s == kPairStart[j] + 1) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float y = a[j][i] * __builtin_amdgcn_rcpf(__builtin_fmaf(e[j][i], sc.k, sc.k));
-                    e[j][i] = linear ? a[j][i] * sc.inv_a : y;
-                }
-            } else if (s == kPairStart[j] + 2) {
-                put_pair<H>(dst, tp, 2 * j, e[j][0], e[j][1]);
             }
         }
     }
@@ -1010,6 +1047,15 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #ifdef MDX_CHAIN_DUMMY_VALU      // (calibration: MDX_CHAIN_DUMMY_VALU more independent vector instructions per k-step)
 #pragma unroll
                     for (int dv = 0; dv < MDX_CHAIN_DUMMY_VALU + 0; ++dv) { float dummy_; asm volatile("v_mov_b32 %0, 0" : "=v"(dummy_)); }
+#endif
+#ifdef MDX_CHAIN_DUMMY_READS     // (the same with instructions that READ two / three live vector registers: operand-port contention?)
+#pragma unroll
+                    for (int dv = 0; dv < MDX_CHAIN_DUMMY_READS % 100; ++dv) {
+                        float dummy_;
+                        const f32x4 lv_ = __builtin_bit_cast(f32x4, in.hi[0][(ks + dv) % (H / 32)]);
+                        if (MDX_CHAIN_DUMMY_READS >= 100) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(dummy_) : "v"(lv_[0]), "v"(lv_[1]), "v"(lv_[2]));
+                        else asm volatile("v_add_f32 %0, %1, %2" : "=v"(dummy_) : "v"(lv_[0]), "v"(lv_[1]));
+                    }
 #endif
 #ifdef MDX_CHAIN_DUMMY_TRANS     // (the same with a transcendental)
 #pragma unroll
