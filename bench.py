@@ -331,11 +331,12 @@ def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
             "f16x3": "split-f16: 3 x v_mfma_f32_16x16x32_f16"}[pack.precision]
     note = ""
     if split:
-        note = ("peak = datasheet dense f16 MFMA rate at 2.4 GHz, counting the 3 executed products per algorithmic one.  The chip "
-                "is power-limited on this instruction stream with random operands: measured inside the kernel (s_memtime / "
-                "s_memrealtime) it holds " + ("2.03-2.11 GHz on the 16x16x32 shape" if shape16 else "1.80-1.82 GHz on the 32x32x16 shape") +
-                " and delivers ~1 200 executed TFLOP/s whatever the instruction order; the same stream on all-zero operands runs "
-                "40 % faster (profiles/r03_chain_ablation.md)")
+        note = ("peak = datasheet dense f16 MFMA rate at 2.4 GHz, counting the 3 executed products per algorithmic one.  Measured "
+                "inside the kernel (s_memtime / s_memrealtime) the chip holds " +
+                ("2.03-2.11 GHz on the 16x16x32 shape (2.32 GHz, same cycle count, on all-zero activations: power sets the clock); "
+                 "its one wavefront per SIMD is instruction-issue-bound: ~1 800-2 000 cycles of in-order issue per 1 536 cycles of MFMAs"
+                 if shape16 else "1.80-1.82 GHz on the 32x32x16 shape: power-bound") +
+                " (profiles/r03_chain_ablation.md)")
     return dict(bound="mfma", achieved=round(executed, 2), peak=peak, unit="TFLOP/s", frac=round(executed / peak, 4),
                 traffic=traffic, kernel=f"egnn_edge_chain_kernel<{H},{prec_index},{2 if pieces else 0}> ({mfma}"
                 f" per product; {n_layers} fused H->H layers + per-node message sums, {edges.shape[0]} edges per launch; 4 launches per "
