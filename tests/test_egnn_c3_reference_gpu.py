@@ -54,6 +54,92 @@ def test_c3_network_forward_against_reference(cuda, precision):
                    for layer in net.egnn.graph_layers)
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_c3_full_size_batch_properties(cuda, precision):
+    """BASELINE configs[2] at its FULL batch (512 structures x 64 atoms, ~800 k edges: what bench.py runs) held to the reference
+    through properties that do not depend on the size:
+      * the reference's eight structures of net_egnn_c3, scattered among 504 random ones, come out as the REFERENCE computed
+        them alone (<= 1e-5 rel-L2 on the scores; logits close) -- a structure's output does not depend on its batch, and the
+        512-structure launch geometry (6 000+ workgroups, XCD tile order, the capacity-sized edge list, piece rows shared by
+        neighbouring nodes) is the one that is benchmarked;
+      * the same eight inside the batch and alone on the HIP path agree to 1e-5 (3e-6 measured: the message sums are grouped
+        by 16-edge pieces whose boundaries move with the structure's place in the edge list);
+      * permuting the atoms of every structure permutes scores and logits (<= 1e-5: the edge order changes);
+      * two forwards of the same batch are bit-identical (no atomics, fixed summation order)."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
+                                                                              NOISY_AXL_COMPOSITION, TIME)
+    g = load_golden("net_egnn_c3.npz")
+    net = nets.egnn_c3_net(1).to(cuda)
+    net.edge_chain_precision = precision
+    B, N = 512, 64
+    gen = torch.Generator().manual_seed(512)
+    X = torch.rand(B, N, 3, generator=gen)
+    A = torch.randint(0, 2, (B, N), generator=gen)
+    L = torch.from_numpy(g["L"][:1]).repeat(B, 1)
+    noise = torch.rand(B, 1, generator=gen) * 0.4 + 0.01
+    time = torch.rand(B, 1, generator=gen)
+    where = torch.tensor([3, 64, 65, 200, 255, 256, 400, 511])               # both ends of workgroup tiles and of the batch
+    for k, b in enumerate(where.tolist()):
+        X[b], A[b], L[b] = torch.from_numpy(g["X"][k]), torch.from_numpy(g["A"][k]), torch.from_numpy(g["L"][k])
+        noise[b], time[b] = torch.from_numpy(g["noise"][k]), torch.from_numpy(g["time"][k])
+
+    def forward(X, A, L, time, noise):
+        batch = {NOISY_AXL_COMPOSITION: AXL(A=A.to(cuda), X=X.to(cuda), L=L.to(cuda)), TIME: time.to(cuda),
+                 NOISE: noise.to(cuda), CARTESIAN_FORCES: torch.zeros(X.shape, device=cuda)}
+        with torch.no_grad():
+            out = net(batch, conditional=False)
+        net.check_status()
+        return out
+
+    full = forward(X, A, L, time, noise)
+    ref = g["out_X"].astype(np.float64)
+    got = full.X[where.to(cuda)].cpu().numpy()
+    err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert err < 1e-5, f"{precision}: the reference's structures inside a 512-structure batch: scores rel-L2 {err:.2e}"
+    np.testing.assert_allclose(full.A[where.to(cuda)].cpu().numpy()[..., :-1], g["out_A"][..., :-1], rtol=1e-4, atol=1e-5)
+    alone = forward(X[where], A[where], L[where], time[where], noise[where])
+    assert float((alone.X - full.X[where.to(cuda)]).norm() / alone.X.norm()) < 1e-5
+    again = forward(X, A, L, time, noise)
+    assert torch.equal(again.X, full.X) and torch.equal(again.A, full.A)
+    perm = torch.stack([torch.randperm(N, generator=gen) for _ in range(B)])
+    rows = torch.arange(B)[:, None]
+    permuted = forward(X[rows, perm], A[rows, perm], L, time, noise)
+    want = full.X[rows.to(cuda), perm.to(cuda)]
+    assert float((permuted.X - want).norm() / want.norm()) < 1e-5
+    wl, gl = full.A[rows.to(cuda), perm.to(cuda)][..., :-1], permuted.A[..., :-1]
+    assert float((gl - wl).norm() / wl.norm()) < 1e-5
+
+
+def test_c3_full_size_sampler_graph_replay_equals_eager(cuda):
+    """The benchmarked iteration at its full size (512 structures, the production-size EGNN, device RNG, M = 2) on a four-index
+    schedule: captured into a hipGraph and replayed, against the same iterations launched eagerly and against the two-call
+    radius graph (edge list sized to the real edge count after a host read) -- the same bits; every atom ends unmasked and
+    inside the unit cell."""
+    import warnings
+    P = _pkg()
+    noise_kw, sampling_kw, _ = cases.C3_SHAPE
+    noise_kw = dict(noise_kw, total_time_steps=4)
+    outs = {}
+    for mode in ("eager", "graph", "two_call"):
+        net = nets.egnn_c3_net(1).to(cuda)
+        if mode == "two_call":
+            net.static_edge_list_max_fraction = 0.0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            npar = P["Noise"](**noise_kw)
+            spar = P["Sampling"](**dict(sampling_kw), rng_mode="device", seed=77, use_hip_graph=mode == "graph")
+        gen = P["Langevin"](npar, spar, net)
+        with torch.no_grad():
+            out = gen.sample(512, cuda)
+        assert gen.f16_range_fallbacks == 0
+        outs[mode] = (out.A.cpu().numpy(), out.X.cpu().numpy())
+    for mode in ("graph", "two_call"):
+        assert np.array_equal(outs["eager"][0], outs[mode][0]), mode
+        assert np.array_equal(outs["eager"][1].view(np.int32), outs[mode][1].view(np.int32)), mode
+    assert (outs["eager"][0] == 0).all() and np.isfinite(outs["eager"][1]).all()       # every atom unmasked, on the torus
+    assert (outs["eager"][1] >= 0).all() and (outs["eager"][1] < 1).all()
+
+
 def _generator(cuda, precision, shape=None, **extra):
     import warnings
     P = _pkg()
