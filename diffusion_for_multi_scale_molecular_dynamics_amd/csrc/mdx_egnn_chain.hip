@@ -79,6 +79,8 @@ struct ChainArgs {
     const float* rows_in;       // [M][ld_in]: the first H columns (MODE 3: [M][2H] = h | agg, ld_in = 2 H)
     const float* residual;      // [M][ld_in] first H columns, nullable
     int64_t ld_in;              // row stride of rows_in and residual, in floats
+    const float* rows_in2;      // MODE 3: the second H columns (agg) as rows of their own, row stride ld_in2
+    int64_t ld_in2;
     float* proj_out;            // MODE 3, nullable: [M][2H] = out W_p^T for the 2 H x H layers that follow the MLP in the image
     float* rows_out;            // [M][H]
     void* stamp_buf;            // -DMDX_CHAIN_STAMPS builds only (else null): see MDX_STAMP_WRITE
@@ -1320,7 +1322,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #pragma unroll
             for (int q8 = 0; q8 < H / 8; ++q8) {
                 const int es = L::es(q8 & 3), off = 32 * (q8 >> 2) + L::fb(q8 & 3, h);
-                const f32x4 a = *(const f32x4*)(p.rows_in + e[es] * p.ld_in + H + off);
+                const f32x4 a = *(const f32x4*)(p.rows_in2 + e[es] * p.ld_in2 + off);
                 if constexpr (SPLIT) {
                     put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3), a[0] * kIn, a[1] * kIn);
                     put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3) + 2, a[2] * kIn, a[3] * kIn);
@@ -1783,20 +1785,41 @@ int mdx_mlp_chain_rows(const mdx_egnn_chain_t* c, const float* x, const float* r
     return MDX_ERR_UNSUPPORTED;
 }
 
+// node_in: [n_rows][ld] rows whose first H columns are h; agg: [n_rows][ld_agg]
+static int node_mlp_rows(const mdx_egnn_chain_t* c, const float* node_in, int64_t ld, const float* agg, int64_t ld_agg,
+                         int add_residual, int64_t n_rows, const int64_t* n_rows_dev, float* out, float* proj_out,
+                         uint32_t* status, mdx_stream_t stream);
+
 int mdx_node_mlp_rows(const mdx_egnn_chain_t* c, const float* node_in, int add_residual, int64_t n_rows,
                       const int64_t* n_rows_dev, float* out, float* proj_out, uint32_t* status, mdx_stream_t stream)
+{
+    if (!c) return MDX_ERR_INVALID_ARG;
+    return node_mlp_rows(c, node_in, 2 * (int64_t)c->hidden, node_in ? node_in + c->hidden : nullptr, 2 * (int64_t)c->hidden,
+                         add_residual, n_rows, n_rows_dev, out, proj_out, status, stream);
+}
+
+int mdx_node_mlp_rows_split(const mdx_egnn_chain_t* c, const float* h, const float* agg, int add_residual, int64_t n_rows,
+                            const int64_t* n_rows_dev, float* out, float* proj_out, uint32_t* status, mdx_stream_t stream)
+{
+    if (!c) return MDX_ERR_INVALID_ARG;
+    return node_mlp_rows(c, h, c->hidden, agg, c->hidden, add_residual, n_rows, n_rows_dev, out, proj_out, status, stream);
+}
+
+static int node_mlp_rows(const mdx_egnn_chain_t* c, const float* node_in, int64_t ld, const float* agg, int64_t ld_agg,
+                         int add_residual, int64_t n_rows, const int64_t* n_rows_dev, float* out, float* proj_out,
+                         uint32_t* status, mdx_stream_t stream)
 {
     if (!c || n_rows < 0) return MDX_ERR_INVALID_ARG;
     if (c->n_message_layers < 3 || c->n_coord_layers != 0 || (c->precision < 0 || c->precision > 2)) return MDX_ERR_INVALID_ARG;
     if (c->n_message_layers > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     if (c->hidden != 32 && c->hidden != 64 && c->hidden != 128 && c->hidden != 256) return MDX_ERR_UNSUPPORTED;
     if (n_rows == 0) return MDX_OK;
-    if (!c->weight_image || !c->biases || !node_in || !out || (c->precision >= 1 && !c->weight_exponents)) return MDX_ERR_INVALID_ARG;
+    if (!c->weight_image || !c->biases || !node_in || !agg || !out || (c->precision >= 1 && !c->weight_exponents)) return MDX_ERR_INVALID_ARG;
     ChainArgs a{};
     a.image = (const char*)c->weight_image; a.biases = c->biases; a.exps = c->weight_exponents;
     a.n_edges_dev = n_rows_dev; a.n_edges = n_rows; a.n_message = c->n_message_layers; a.n_coord = 0; a.D = 0;
     a.rows_in = node_in; a.residual = add_residual ? node_in : nullptr; a.rows_out = out; a.status = status;
-    a.ld_in = 2 * (int64_t)c->hidden;
+    a.ld_in = ld; a.rows_in2 = agg; a.ld_in2 = ld_agg;
     a.proj_out = proj_out;
     if (proj_out && c->n_message_layers + 2 > MDX_EGNN_CHAIN_MAX_LAYERS) return MDX_ERR_UNSUPPORTED;
     const int layers = a.n_message;

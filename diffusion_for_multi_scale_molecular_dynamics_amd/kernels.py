@@ -749,13 +749,21 @@ class NodeMlpPack:
                 all(l.in_features == H and l.out_features == H for l in layers[1:]) and all(l.bias is not None for l in layers))
 
 
-def node_mlp_rows(pack: NodeMlpPack, node_in, add_residual: bool, status=None):
-    """(node_in[:, :H] if add_residual) + MLP(node_in) over the rows of node_in [M, 2H]  (mdx_node_mlp_rows); with a pack
-    built with next_projection: (out, out @ next_projection.T [M, 2H])."""
+def node_mlp_rows(pack: NodeMlpPack, node_in, add_residual: bool, status=None, agg=None):
+    """(h if add_residual) + MLP([h | agg]) over the rows; with a pack built with next_projection: (out, out @
+    next_projection.T [M, 2H]).  node_in [M, 2H] = [h | agg] (mdx_node_mlp_rows), or node_in = h [M, H] with agg [M, H] given
+    separately (mdx_node_mlp_rows_split: the concatenation is never formed)."""
     M, W = node_in.shape
-    assert W == 2 * pack.hidden
     out = torch.empty(M, pack.hidden, dtype=F32, device=node_in.device)
     proj = torch.empty(M, 2 * pack.hidden, dtype=F32, device=node_in.device) if pack.projects else None
+    if agg is not None:
+        assert W == pack.hidden and agg.shape == node_in.shape
+        rc = lib().mdx_node_mlp_rows_split(C.byref(pack.c_struct), ptr(node_in, F32, "h"), ptr(agg, F32, "agg"),
+                                           int(bool(add_residual)), M, None, ptr(out, F32, "out"), ptr(proj, F32, "proj_out"),
+                                           ptr(status, I32, "status"), stream_handle())
+        check(rc, "mdx_node_mlp_rows_split")
+        return (out, proj) if pack.projects else out
+    assert W == 2 * pack.hidden
     rc = lib().mdx_node_mlp_rows(C.byref(pack.c_struct), ptr(node_in, F32, "node_in"), int(bool(add_residual)), M, None,
                                  ptr(out, F32, "out"), ptr(proj, F32, "proj_out"), ptr(status, I32, "status"), stream_handle())
     check(rc, "mdx_node_mlp_rows")

@@ -300,17 +300,21 @@ class E_GCL(nn.Module):
         messages, edge_scalar = kernels.egnn_edge_chain(pack, proj.contiguous(), coord, edge_index, status=self.status_word,
                                                         n_edges_dev=n_edges, piece_sums=in_kernel)
         if in_kernel and h.shape[1] == messages.shape[1] and coord.shape[1] <= 8:
-            # everything per node between the edge chain and the node MLP in one pass: [h | agg] and the updated coordinates
-            node_in, coord_out = kernels.egnn_node_gather(messages, edge_index.shape[0], offsets, degree, self.message_mean,
-                                                          h.contiguous(), edge_scalar, coord, edge_index, self.coords_mean)
             whole = self._node_mlp_pack(next_layer)
             if whole is not None and whole.hidden == h.shape[1]:
-                # the whole node MLP (its 2H -> H layer included), the residual and -- when a graph layer follows -- that
-                # layer's per-node projections: one launch on the matrix cores
-                out = kernels.node_mlp_rows(whole, node_in, self.residual, status=self.status_word)
+                # everything per node between the edge chain and the node MLP in one pass (the message sums and the updated
+                # coordinates), then the whole node MLP (its 2H -> H layer included, reading h and the sums as the two halves of
+                # its input row: [h | agg] is never formed), the residual and -- when a graph layer follows -- that layer's
+                # per-node projections: one launch on the matrix cores
+                h = h.contiguous()
+                agg, coord_out = kernels.egnn_node_gather(messages, edge_index.shape[0], offsets, degree, self.message_mean,
+                                                          None, edge_scalar, coord, edge_index, self.coords_mean)
+                out = kernels.node_mlp_rows(whole, h, self.residual, status=self.status_word, agg=agg)
                 if whole.projects:
                     out, self._next_proj = out
                 return out, coord_out
+            node_in, coord_out = kernels.egnn_node_gather(messages, edge_index.shape[0], offsets, degree, self.message_mean,
+                                                          h.contiguous(), edge_scalar, coord, edge_index, self.coords_mean)
         else:
             coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean)
             agg = (kernels.segment_combine(messages, edge_index.shape[0], offsets, degree, self.message_mean) if in_kernel

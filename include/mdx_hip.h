@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 9
+#define MDX_ABI_VERSION 10
 
 /* status codes */
 #define MDX_OK 0
@@ -491,6 +491,11 @@ MDX_API int mdx_mlp_chain_rows(const mdx_egnn_chain_t* chain_host, const float* 
  * proj_out[r,:] = [out[r,:] W_src^T | out[r,:] W_dst^T]: the node_proj input of that layer's mdx_egnn_edge_chain. */
 MDX_API int mdx_node_mlp_rows(const mdx_egnn_chain_t* chain_host, const float* node_in, int add_residual, int64_t n_rows,
                               const int64_t* n_rows_dev, float* out, float* proj_out, uint32_t* status, mdx_stream_t stream);
+/* The same with the two halves of the row as separate matrices, h [n_rows, H] and agg [n_rows, H] (what mdx_egnn_node_gather
+ * writes with left = NULL): the concatenated [h | agg] never exists -- 134 MB less through HBM per layer at C3. */
+MDX_API int mdx_node_mlp_rows_split(const mdx_egnn_chain_t* chain_host, const float* h, const float* agg, int add_residual,
+                                    int64_t n_rows, const int64_t* n_rows_dev, float* out, float* proj_out, uint32_t* status,
+                                    mdx_stream_t stream);
 /* coord_out[i,:] = coord[i,:] + (1/degree_i if mean) sum_{e in segment i} (coord[i,:] - coord[dst_e,:]) edge_scalar[e]
  * -- E_GCL.coord_model's trans = coord_diff * coord_mlp(m), unsorted_segment_sum / _mean and the residual add
  * (models/egnn.py:162-200), on the sorted segments; no atomics, fixed summation order. */

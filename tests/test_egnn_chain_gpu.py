@@ -724,3 +724,8 @@ def test_node_mlp_rows_against_fp64(cuda, precision, H, n_inner, M, with_residua
     assert int(status.item()) == 0 and torch.equal(got2, got)
     want_p = want.detach() @ proj_w.double().t()
     assert _rel_l2(proj, want_p) < tol, _rel_l2(proj, want_p)
+    # the two halves of the row as separate matrices (mdx_node_mlp_rows_split: what the EGNN layer passes): the same bits
+    xd = x.to(cuda)
+    got3, proj3 = kernels.node_mlp_rows(pack_p, xd[:, :H].contiguous(), with_residual, status=status, agg=xd[:, H:].contiguous())
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and torch.equal(got3, got) and torch.equal(proj3, proj)
