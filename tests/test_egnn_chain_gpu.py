@@ -361,12 +361,13 @@ def test_radius_graph_static_equals_two_call(cuda):
     assert torch.equal(guard[:small], ref["edges"][:small]) and (guard[small:] == -5).all()
 
 
-@pytest.mark.parametrize("B,N", [(3, 5), (7, 64), (70, 64), (2, 200)])
+@pytest.mark.parametrize("B,N", [(3, 5), (7, 64), (70, 64), (2, 200), (257, 65), (520, 64)])
 def test_egnn_radius_graph_from_relative_coordinates(cuda, B, N):
     """mdx_egnn_radius_graph (relative coordinates + lattice parameters in, clip / diagonal cell / positions / scan inside: three
     launches) gives bit for bit what the score network built before from torch.clip, diag_embed, matmul, the two radius-graph
-    launches and torch.cumsum -- lengths below the clip, lists longer than one scan tile (70 x 64 > 4096) and ragged ones
-    included; a capacity that is too small is reported and respected."""
+    launches and torch.cumsum -- lengths below the clip, count lists of more than one scan tile of 16 384 entries (257 x 65 with a
+    ragged last thread, 520 x 64 with three tiles) and short ragged ones included; a capacity that is too small is reported and
+    respected."""
     from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
     g = torch.Generator().manual_seed(100 * B + N)
     rc = 3.2
