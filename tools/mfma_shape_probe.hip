@@ -263,6 +263,139 @@ __global__ __launch_bounds__(512, 2) void probe_kernel_8w(const char* image, int
     atomicAdd(&out[(size_t)blockIdx.x * 256 + (threadIdx.x & 255)], sum);
 }
 
+// SHAPE 3: 16x16x32 with EIGHT wavefronts per workgroup that split the REDUCTION dimension: wavefronts w and w + 4 (the same
+// SIMD) own the same 32 columns; w holds the operand k-steps 0..3 (of 8 x 32), w + 4 the k-steps 4..7, each reads only its half
+// of every fragment pair (the LDS port carries the same weight bytes as with four wavefronts), and the one that does NOT own the
+// chunk's output (chunk tp becomes operand k-step tp: owned by the low wavefront for tp < 4) hands its sixteen partial sums to
+// the owner through LDS (4 KB per wavefront and chunk, double-buffered; visible behind the next chunk's barrier), which adds its
+// own, runs the epilogue and rewrites its operand registers.  256 registers per wavefront.
+__global__ __launch_bounds__(512, 2) void probe_kernel_ksplit(const char* image, int image_chunks, const float* x0, int chunks, float* out,
+                                                              float neg_c, float k)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    lds_c* ring = (lds_c*)lds_raw;
+    lds_c* xbuf = ring + 4 * kChunk;                                    // [parity][pair][4 x 1 KB]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x % 64;
+    const int pair = wave & 3, half = wave >> 2;
+    const uint32_t lane16 = lane * 16u;
+    const uint32_t share = (uint32_t)(((unsigned)wave + blockIdx.x / 8u) & 7u) * (kChunk / 8);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    half8 xh[8], xl[8];                                                 // [cg][j]: column group cg, k-step 4 half + j
+    const float* px = x0 + ((size_t)blockIdx.x * 256 + pair * 64 + lane) * 128;
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int s = 8 * cg + 4 * half + j;
+            u32x4 h, l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t hh, ll;
+                split_pair(px[8 * s + 2 * q], px[8 * s + 2 * q + 1], hh, ll);
+                h[q] = hh;
+                l[q] = ll;
+            }
+            xh[4 * cg + j] = __builtin_bit_cast(half8, h);
+            xl[4 * cg + j] = __builtin_bit_cast(half8, l);
+        }
+    auto issue_chunk_piece = [&](int chunk, int slot, int piece) {      // piece 0..3 of this wavefront's eighth (4 KB)
+        const uint32_t src_off = __builtin_amdgcn_readfirstlane((uint32_t)(chunk % image_chunks) * (uint32_t)kChunk + share);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ring + (uint32_t)(slot * kChunk) + share);
+        request(image, src_off, dst, lane16, piece);
+    };
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_chunk_piece(c, c, i);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) issue_chunk_piece(2, 2, i);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x16 pend = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 bias;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = half == 0 ? px[r] * 104857.6f : 0.0f;
+    for (int c0 = 0; c0 + 8 <= chunks; c0 += 8) {
+#pragma unroll
+      for (int tp = 0; tp < 8; ++tp) {
+        const int c = c0 + tp;
+        const lds_c* w = ring + (tp & 3) * kChunk;
+        constexpr int kDummy = 0;
+        const int prev = (tp + 7) & 7;                                  // the chunk whose epilogue is outstanding
+        const bool owns_prev = half == (prev >= 4 ? 1 : 0);
+        lds_c* recv = xbuf + ((prev & 1) * 4 + pair) * 4096;
+        f32x16 acc = bias;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s == 4) {
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (owns_prev) {                                        // the partner's partial sums of the previous chunk
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = *(const __attribute__((address_space(3))) f32x4*)(recv + q * 1024 + lane * 16);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pend[4 * q + i] += v[i];
+                    }
+                }
+            }
+            if ((s & 1) == 0) {
+                const int i = s >> 1;                                   // 4 requests per chunk per wavefront
+                if (i < 2) issue_chunk_piece(c + 2, (c + 2) & 3, 2 + i);
+                else issue_chunk_piece(c + 3, (c + 3) & 3, i - 2);
+            }
+            const int j = s >> 1, rt = s & 1, g = 8 * half + s;         // g: the fragment's step in the chunk (k-step 4 half + j)
+            const half8 ah = *(const __attribute__((address_space(3))) half8*)(w + g * 2048 + lane * 16);
+            const half8 al = *(const __attribute__((address_space(3))) half8*)(w + g * 2048 + 1024 + lane * 16);
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                f32x4 a4 = {acc[4 * (2 * rt + cg)], acc[4 * (2 * rt + cg) + 1], acc[4 * (2 * rt + cg) + 2], acc[4 * (2 * rt + cg) + 3]};
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[4 * cg + j], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[4 * cg + j], a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[4 * cg + j], a4, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[4 * (2 * rt + cg) + i] = a4[i];
+            }
+            // epilogue of the previous chunk (owner only), behind the barrier: two pairs per step in steps 4..7
+            if (s >= 4 && owns_prev) {
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int r = 4 * (s - 4) + 2 * e2;
+                    uint32_t h, l;
+                    split_pair(act(pend[r], neg_c, k), act(pend[r + 1], neg_c, k), h, l);
+                    const int slot = 4 * (r >> 3) + (prev & 3);
+                    u32x4 vh = __builtin_bit_cast(u32x4, xh[slot]), vl = __builtin_bit_cast(u32x4, xl[slot]);
+                    vh[(r & 7) >> 1] = h;
+                    vl[(r & 7) >> 1] = l;
+                    xh[slot] = __builtin_bit_cast(half8, vh);
+                    xl[slot] = __builtin_bit_cast(half8, vl);
+                }
+            }
+        }
+        // hand over / keep this chunk's partial sums
+        const bool owns = half == (tp >= 4 ? 1 : 0);
+        if (owns) {
+            pend = acc;
+        } else {
+            lds_c* send = xbuf + ((tp & 1) * 4 + pair) * 4096;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                *(__attribute__((address_space(3))) f32x4*)(send + q * 1024 + lane * 16) = v;
+            }
+        }
+        (void)kDummy;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += pend[r];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) sum += (float)xh[s][0] + (float)xl[s][1];
+    atomicAdd(&out[(size_t)blockIdx.x * 256 + (threadIdx.x & 255)], sum);
+}
+
 template <int SHAPE, int ORDER>
 static int launch_one(const void* image, int image_chunks, const float* x0, int chunks, float* out, int grid, float neg_c, float k,
                       hipStream_t st)
@@ -292,6 +425,15 @@ extern "C" int probe_launch(int shape, const void* image, int image_chunks, cons
                 granted = true;
             }
             hipLaunchKernelGGL(probe_kernel_8w, dim3(grid), dim3(512), 4 * (size_t)kChunk, st, (const char*)image, image_chunks, x0, chunks, out, neg_c, k);
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
+        case 3: {
+            static bool granted = false;
+            if (!granted) {
+                if (hipFuncSetAttribute((const void*)probe_kernel_ksplit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+                granted = true;
+            }
+            hipLaunchKernelGGL(probe_kernel_ksplit, dim3(grid), dim3(512), 4 * (size_t)kChunk + 32 * 1024, st, (const char*)image, image_chunks, x0, chunks, out, neg_c, k);
             return hipGetLastError() == hipSuccess ? 0 : -2;
         }
     }

@@ -33,7 +33,7 @@ def launch(shape):
     assert rc == 0, rc
 
 
-SHAPES = (0, 1, 2)
+SHAPES = (0, 1, 2, 3)
 times = {k: [] for k in SHAPES}
 for shape in SHAPES:
     launch(shape)
@@ -56,7 +56,8 @@ for r in range(9):
         times[shape].append(a.elapsed_time(b) * 1000 / 3)
 flops = 2.0 * grid * 128 * 32 * 256 * chunks * 3
 res = {"grid": grid, "chunks": chunks}
-for shape, name in ((0, "32x32x16"), (1, "16x16x32"), (2, "16x16x32, 8 wavefronts x 16 columns")):
+for shape, name in ((0, "32x32x16"), (1, "16x16x32"), (2, "16x16x32, 8 wavefronts x 16 columns"),
+                    (3, "16x16x32, 8 wavefronts, reduction dimension split per SIMD pair")):
     med = statistics.median(times[shape])
     res[name] = {"median_us": round(med, 1), "min_us": round(min(times[shape]), 1), "executed_tflops": round(flops / med / 1e6, 1)}
 print(json.dumps(res))
