@@ -1487,7 +1487,12 @@ __global__ __launch_bounds__(256) void egnn_chain_pack_kernel(PackArgs p)
                                            : 32 * (s >> 1) + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
             const float v = weight(n, k) * pow2_bits(p.exps[l]);      // exact (a power of two; |v| < 2^14)
             const _Float16 hi = (_Float16)v;
+#ifdef MDX_CHAIN_LO_MASK         // (timing experiment: the low MDX_CHAIN_LO_MASK bits of the weight image's lo halves cleared)
+            const _Float16 lo = __builtin_bit_cast(_Float16, (uint16_t)(__builtin_bit_cast(uint16_t, (_Float16)(v - (float)hi)) &
+                                                                          (uint16_t)~((1u << MDX_CHAIN_LO_MASK) - 1u)));
+#else
             const _Float16 lo = (_Float16)(v - (float)hi);
+#endif
             _Float16* chunk = (_Float16*)((char*)p.image + ((int64_t)l * (H / 32) + t) * ((int64_t)H * 32 * 4));
             chunk[s * 1024 + lane * 8 + j] = hi;
             chunk[s * 1024 + 512 + lane * 8 + j] = lo;
