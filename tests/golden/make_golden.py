@@ -426,6 +426,39 @@ def golden_noisers():
     save("noisers.npz", **out)
 
 
+def golden_d3pm_utils():
+    """The five callables of utils/d3pm_utils.py on random operands: one-hot and soft distributions, matrices shared by the
+    batch (the sampler's expand of one time index) and matrices that differ per atom."""
+    from diffusion_for_multi_scale_molecular_dynamics.utils import d3pm_utils as D
+    g = torch.Generator().manual_seed(909)
+    B, N, C = 4, 6, 4
+    out = {}
+    index = torch.randint(0, C, (B, N), generator=g)
+    onehot = D.class_index_to_onehot(index, C)
+    soft = torch.softmax(torch.randn(B, N, C, generator=g), dim=-1)
+    logits = torch.randn(B, N, C, generator=g) * 3.0
+    logits[..., -1] = -torch.inf
+
+    def stochastic(*lead):
+        m = torch.rand(*lead, C, C, generator=g) + 0.05
+        return m / m.sum(dim=-1, keepdim=True)
+    q_one, qb_one, qbm_one = stochastic(), stochastic(), stochastic()
+    shared = [m.expand(B, N, C, C) for m in (q_one, qb_one, qbm_one)]
+    per_atom = [stochastic(B, N) for _ in range(3)]
+    out.update(index=_np(index), onehot=_np(onehot), soft=_np(soft), logits=_np(logits), q=_np(q_one), q_bar=_np(qb_one),
+               q_bar_tm1=_np(qbm_one), q_atoms=_np(per_atom[0]), q_bar_atoms=_np(per_atom[1]), q_bar_tm1_atoms=_np(per_atom[2]))
+    out["q_at_given_a0"] = _np(D.compute_q_at_given_a0(onehot, per_atom[1]))
+    out["q_at_given_a0_soft"] = _np(D.compute_q_at_given_a0(soft, shared[1]))
+    out["q_at_given_atm1"] = _np(D.compute_q_at_given_atm1(onehot, per_atom[0]))
+    out["probability_from_logits"] = _np(D.get_probability_from_logits(logits, 1e-8))
+    out["previous_logits_shared"] = _np(D.get_probability_at_previous_time_step(logits, onehot, *shared, small_epsilon=1e-8,
+                                                                                probability_at_zeroth_timestep_are_logits=True))
+    out["previous_logits_atoms"] = _np(D.get_probability_at_previous_time_step(logits, onehot, *per_atom, small_epsilon=1e-8,
+                                                                               probability_at_zeroth_timestep_are_logits=True))
+    out["previous_soft_shared"] = _np(D.get_probability_at_previous_time_step(soft, onehot, *shared, small_epsilon=1e-8))
+    save("d3pm_utils.npz", **out)
+
+
 # --------------------------------------------------------------------------------------------------------------
 # N1
 # --------------------------------------------------------------------------------------------------------------
@@ -856,6 +889,8 @@ if __name__ == "__main__":
         golden_networks()
     if which in ("noisers",):
         golden_noisers()
+    if which in ("all", "d3pm"):
+        golden_d3pm_utils()
     if which in ("all", "next"):
         golden_next()
     if which in ("all", "distances"):

@@ -182,6 +182,32 @@ def test_noisers_golden(K, cuda):
         assert np.array_equal(got.cpu().numpy(), g[f"{nm}/at"]), nm
 
 
+def test_d3pm_utils_on_the_gpu_against_reference_golden(K, cuda):
+    """utils/d3pm_utils.py on device tensors against the reference's outputs: the sampler's operands (logits, one-hot a_t, one
+    matrix triple expanded over the batch) go through mdx_atom_types_update (<= 4 ulp: the exp inside the softmax), everything
+    else through the reference's contractions."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.utils import d3pm_utils as D
+    g = load_golden("d3pm_utils.npz")
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).to(cuda)          # noqa: E731
+    B, N, C = g["onehot"].shape
+    onehot = D.class_index_to_onehot(t("index"), C)
+    assert onehot.is_cuda and np.array_equal(onehot.cpu().numpy(), g["onehot"])
+    shared = [t(k).expand(B, N, C, C) for k in ("q", "q_bar", "q_bar_tm1")]
+    atoms = [t(k) for k in ("q_atoms", "q_bar_atoms", "q_bar_tm1_atoms")]
+    close = lambda a, k: np.testing.assert_allclose(a.cpu().numpy(), g[k], rtol=2e-6, atol=1e-9)      # noqa: E731
+    close(D.compute_q_at_given_a0(onehot, atoms[1]), "q_at_given_a0")
+    close(D.compute_q_at_given_a0(t("soft"), shared[1]), "q_at_given_a0_soft")
+    close(D.compute_q_at_given_atm1(onehot, atoms[0]), "q_at_given_atm1")
+    close(D.get_probability_from_logits(t("logits"), 1e-8), "probability_from_logits")
+    with torch.no_grad():
+        fused = D.get_probability_at_previous_time_step(t("logits"), onehot, *shared, small_epsilon=1e-8,
+                                                        probability_at_zeroth_timestep_are_logits=True)
+    assert ulp_diff(fused.cpu().numpy(), g["previous_logits_shared"]).max() <= 4
+    close(D.get_probability_at_previous_time_step(t("logits"), onehot, *atoms, small_epsilon=1e-8,
+                                                  probability_at_zeroth_timestep_are_logits=True), "previous_logits_atoms")
+    close(D.get_probability_at_previous_time_step(t("soft"), onehot, *shared, small_epsilon=1e-8), "previous_soft_shared")
+
+
 def test_noiser_classes_with_the_reference_operands(K, cuda, monkeypatch):
     """RelativeCoordinatesNoiser / AtomTypesNoiser / LatticeNoiser called the way the reference's training transform calls them
     (data/diffusion/noising_transform.py:140-195: sigmas of the coordinates' shape, one-hot atom types with a cumulative
