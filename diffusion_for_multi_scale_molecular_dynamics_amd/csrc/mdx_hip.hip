@@ -1748,70 +1748,82 @@ __global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __res
     }
 }
 
-// offsets[i] = counts[0] + ... + counts[i-1], *total = the sum: ONE workgroup walks the list in tiles of kScanItems x kScanBlock
-// entries (the list is the per-atom edge count of a batch -- 32 768 entries, two tiles, at C3; a launch of its own between the
-// two radius-graph passes costs less than the three library launches of cumsum + subtraction it replaces).  Each thread owns
-// kScanItems consecutive entries (read and written as 16-byte pairs); the sums inside a tile are 32-bit (an entry is an edge
-// count of ONE atom: < 2^15 at the largest structure the radius graph takes), the carry between tiles 64-bit.
-constexpr int kScanBlock = 1024, kScanItems = 16;
+// offsets[i] = counts[0] + ... + counts[i-1], *total = the sum: ONE workgroup walks the list in tiles of 16 384 entries (the list is
+// the per-atom edge count of a batch -- 32 768 entries, two tiles, at C3; a launch of its own between the two radius-graph passes
+// costs less than the three library launches of cumsum + subtraction it replaces).  A tile is kScanRows rows of 2 x kScanBlock
+// entries; thread t owns entries 2t, 2t + 1 of every row, so each of its loads and stores is one coalesced 16-byte lane access
+// (a thread owning 16 CONSECUTIVE entries made every wavefront-wide access touch 64 cache lines: 18 us instead of 6).  The sums
+// inside a tile are 32-bit (an entry is the edge count of ONE atom: < 2^13 at the largest structure the radius graph takes,
+// 16 384 of them < 2^27), the carry between tiles 64-bit.
+constexpr int kScanBlock = 1024, kScanRows = 8, kScanWaves = kScanBlock / kWave;
+
+// inclusive prefix sum over the 64 lanes with DPP adds (no LDS): within rows of 16 lanes, then lane 15 of rows 0 / 2 into rows
+// 1 / 3, then lane 31 into the upper half
+__device__ __forceinline__ int wave_inclusive_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return x;
+}
 
 __global__ __launch_bounds__(kScanBlock) void offsets_scan_kernel(const int64_t* __restrict__ counts, int64_t n,
                                                                   int64_t* __restrict__ offsets, int64_t* __restrict__ total)
 {
-    __shared__ int wave_sums[kScanBlock / kWave];
+    // per (row, wavefront) sums of a tile, then their exclusive prefix in row-major order; [parity of the tile] so that a
+    // wavefront one barrier ahead does not write what a slower one still reads
+    __shared__ int sums[2][kScanRows * kScanWaves + 1];
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
     int64_t carry = 0;
-    for (int64_t base = 0; base < n; base += (int64_t)kScanItems * kScanBlock) {
-        const int64_t i0 = base + (int64_t)kScanItems * threadIdx.x;
-        int v[kScanItems];
-        if (i0 + kScanItems <= n) {
+    int parity = 0;
+    for (int64_t base = 0; base < n; base += (int64_t)kScanRows * 2 * kScanBlock, parity ^= 1) {
+        int* tile_sums = sums[parity];
+        int v0[kScanRows], v1[kScanRows], incl[kScanRows];
 #pragma unroll
-            for (int k = 0; k < kScanItems; k += 2) {
-                const longlong2 pair = reinterpret_cast<const longlong2*>(counts + i0)[k >> 1];
-                v[k] = (int)pair.x;
-                v[k + 1] = (int)pair.y;
+        for (int r = 0; r < kScanRows; ++r) {
+            const int64_t i = base + ((int64_t)r * kScanBlock + threadIdx.x) * 2;
+            if (i + 1 < n) {
+                const longlong2 pair = *reinterpret_cast<const longlong2*>(counts + i);
+                v0[r] = (int)pair.x;
+                v1[r] = (int)pair.y;
+            } else {
+                v0[r] = i < n ? (int)counts[i] : 0;
+                v1[r] = 0;
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < kScanItems; ++k) v[k] = i0 + k < n ? (int)counts[i0 + k] : 0;
         }
-        int s = 0;
 #pragma unroll
-        for (int k = 0; k < kScanItems; ++k) s += v[k];
-        int incl = s;
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const int t = __shfl_up(incl, o, kWave);
-            if (lane >= o) incl += t;
+        for (int r = 0; r < kScanRows; ++r) {
+            incl[r] = wave_inclusive_scan(v0[r] + v1[r]);
+            if (lane == kWave - 1) tile_sums[r * kScanWaves + wave] = incl[r];
         }
-        if (lane == kWave - 1) wave_sums[wave] = incl;
         __syncthreads();
-        int before = 0, tile = 0;
-#pragma unroll
-        for (int w = 0; w < kScanBlock / kWave; ++w) {
-            const int x = wave_sums[w];
-            if (w < wave) before += x;
-            tile += x;
+        if (wave == 0) {
+            // 128 sums, two per lane, in row-major order -> what lies before each of them in the tile; the tile's total behind
+            static_assert(kScanRows * kScanWaves == 2 * kWave, "one wavefront scans the tile's sums two per lane");
+            const int a = tile_sums[2 * lane], b = tile_sums[2 * lane + 1];
+            const int through = wave_inclusive_scan(a + b);
+            tile_sums[2 * lane] = through - a - b;
+            tile_sums[2 * lane + 1] = through - b;
+            if (lane == kWave - 1) tile_sums[kScanRows * kScanWaves] = through;
         }
-        int64_t run = carry + (int64_t)(before + (incl - s));
-        if (i0 + kScanItems <= n) {
+        __syncthreads();
 #pragma unroll
-            for (int k = 0; k < kScanItems; k += 2) {
+        for (int r = 0; r < kScanRows; ++r) {
+            const int64_t i = base + ((int64_t)r * kScanBlock + threadIdx.x) * 2;
+            const int64_t first = carry + (tile_sums[r * kScanWaves + wave] + (incl[r] - v0[r] - v1[r]));
+            if (i + 1 < n) {
                 longlong2 pair;
-                pair.x = run;
-                pair.y = run + v[k];
-                run += v[k] + v[k + 1];
-                reinterpret_cast<longlong2*>(offsets + i0)[k >> 1] = pair;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < kScanItems; ++k) {
-                if (i0 + k < n) offsets[i0 + k] = run;
-                run += v[k];
+                pair.x = first;
+                pair.y = first + v0[r];
+                *reinterpret_cast<longlong2*>(offsets + i) = pair;
+            } else if (i < n) {
+                offsets[i] = first;
             }
         }
-        carry += tile;
-        __syncthreads();
+        carry += tile_sums[kScanRows * kScanWaves];
     }
     if (threadIdx.x == 0) *total = carry;
 }
