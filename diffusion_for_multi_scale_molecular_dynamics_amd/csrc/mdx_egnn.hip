@@ -203,43 +203,57 @@ __global__ __launch_bounds__(kBlock) void egnn_outputs_kernel(const float* __res
     for (int64_t t = tid; t < n_zero; t += n_threads) zero_out[t] = 0.0f;
     const int lane = threadIdx.x % kWaveSize;
     const int quads = H >> 2;
-    for (int64_t node = tid / kWaveSize; node < n_nodes; node += n_threads / kWaveSize) {
-        // the three score lanes fetch their operands while the others are busy with the row of h
+    // kNodesPerWave nodes per wavefront and pass: their rows of h, and the score operands of 3 lanes per node, are all
+    // requested before anything is reduced (one row per pass left most of the launch waiting on a single 1 KB read)
+    constexpr int kNodesPerWave = 4;
+    const int64_t n_waves = n_threads / kWaveSize;
+    for (int64_t node0 = (tid / kWaveSize) * kNodesPerWave; node0 < n_nodes; node0 += n_waves * kNodesPerWave) {
         float acc = 0.0f;
-        if (lane >= kWaveSize - 3) {
-            const int alpha = lane - (kWaveSize - 3);
-            const float* zi = z + node * 2 * n_k;
-            const float* xi = x_hat + node * 2 * n_k;
+        const int score_node = (lane - (kWaveSize - 3 * kNodesPerWave)) / 3, alpha = (lane - (kWaveSize - 3 * kNodesPerWave)) % 3;
+        const bool scores_lane = lane >= kWaveSize - 3 * kNodesPerWave && node0 + score_node < n_nodes;
+        if (scores_lane) {
+            const float* zi = z + (node0 + score_node) * 2 * n_k;
+            const float* xi = x_hat + (node0 + score_node) * 2 * n_k;
             for (int k = 0; k < n_k; ++k) {
                 const float kk = k_vectors[3 * k + alpha];
                 acc = acc + ((zi[2 * k] * -kk) * xi[2 * k + 1] + (zi[2 * k + 1] * kk) * xi[2 * k]);
             }
         }
-        float part[kMaxClasses];
+        float part[kNodesPerWave][kMaxClasses];
 #pragma unroll
-        for (int c = 0; c < kMaxClasses; ++c) part[c] = 0.0f;
+        for (int m = 0; m < kNodesPerWave; ++m)
+#pragma unroll
+            for (int c = 0; c < kMaxClasses; ++c) part[m][c] = 0.0f;
         for (int q = lane; q < quads; q += kWaveSize) {
-            const float4 hv = reinterpret_cast<const float4*>(h + node * H)[q];
+            float4 hv[kNodesPerWave];
+#pragma unroll
+            for (int m = 0; m < kNodesPerWave; ++m)
+                hv[m] = node0 + m < n_nodes ? reinterpret_cast<const float4*>(h + (node0 + m) * H)[q] : float4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int c = 0; c < kMaxClasses; ++c) {
                 if (c < C && c != mask_class) {
                     const float4 wv = reinterpret_cast<const float4*>(cw + (int64_t)c * H)[q];
-                    part[c] += (hv.x * wv.x + hv.y * wv.y) + (hv.z * wv.z + hv.w * wv.w);
+#pragma unroll
+                    for (int m = 0; m < kNodesPerWave; ++m)
+                        part[m][c] += (hv[m].x * wv.x + hv[m].y * wv.y) + (hv[m].z * wv.z + hv[m].w * wv.w);
                 }
             }
         }
 #pragma unroll
         for (int c = 0; c < kMaxClasses; ++c) {
             if (c < C) {
-                float v = part[c];
-                if (c != mask_class) {
 #pragma unroll
-                    for (int o = kWaveSize / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWaveSize);
+                for (int m = 0; m < kNodesPerWave; ++m) {
+                    float v = part[m][c];
+                    if (c != mask_class) {
+#pragma unroll
+                        for (int o = kWaveSize / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWaveSize);
+                    }
+                    if (lane == 0 && node0 + m < n_nodes) logits[(node0 + m) * C + c] = (c == mask_class) ? -__builtin_inff() : v + cb[c];
                 }
-                if (lane == 0) logits[node * C + c] = (c == mask_class) ? -__builtin_inff() : v + cb[c];
             }
         }
-        if (lane >= kWaveSize - 3) scores[node * 3 + lane - (kWaveSize - 3)] = acc;
+        if (scores_lane) scores[(node0 + score_node) * 3 + alpha] = acc;
     }
 }
 
@@ -462,7 +476,7 @@ int mdx_egnn_outputs(const float* z, const float* x_hat, const float* k_vectors,
     if (n_nodes == 0 && n_zero == 0) return MDX_OK;
     if (n_nodes > 0 && (!z || !x_hat || !k_vectors || !h || !class_weight || !class_bias || !scores_out || !logits_out))
         return MDX_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(egnn_outputs_kernel, dim3(node_grid(n_nodes)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), z,
+    hipLaunchKernelGGL(egnn_outputs_kernel, dim3(node_grid((n_nodes + 3) / 4)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), z,
                        x_hat, k_vectors, n_k, h, class_weight, class_bias, H, num_classes, mask_class, n_nodes, scores_out,
                        logits_out, zero_out, n_zero);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
