@@ -16,6 +16,11 @@ import nets
 from conftest import load_golden, torus_rel_l2
 from oracle import reference_sampler as RS
 
+# MDX_FUZZ=k multiplies the number of seeds of the random-configuration tests below (a one-off wider sweep: MDX_FUZZ=10
+# python -m pytest tests/test_generator_gpu.py -m gpu -k random); the suite runs with 1.
+import os
+FUZZ = max(1, int(os.environ.get("MDX_FUZZ", "1")))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -864,7 +869,7 @@ def _random_config(seed):
     return noise_kw, sampling_kw, int(rng.choice([1, 3, 17]))
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(32 * FUZZ))
 def test_random_configurations_device_rng_bitwise(cuda, seed):
     """Seeded random sampler configurations (atoms 1..216, 2..6 classes, 1..3 spatial dimensions, 0..3 correctors, all
     flag combinations, fixed and free lattice) with the echo network, whose forward is exact on both sides: the GPU
@@ -890,7 +895,7 @@ def test_random_configurations_device_rng_bitwise(cuda, seed):
         assert np.array_equal(out.L.view(np.int32), ora.L.view(np.int32)), (noise_kw, sampling_kw, batch)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * FUZZ))
 def test_fused_sampler_random_shapes_predrawn_equals_in_kernel(cuda, seed):
     """Generic instantiations of the persistent sampler on random network / structure shapes (records longer than one
     64-lane fetch included): the noise pre-pass and the in-kernel draws give the same bits, and one launch equals two."""
@@ -932,7 +937,7 @@ def test_fused_sampler_random_shapes_predrawn_equals_in_kernel(cuda, seed):
     assert torch.isfinite(outs[0].X).all() and (outs[0].A != nat).all()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * FUZZ))
 def test_random_repaint_configurations_bitwise(cuda, seed):
     """Random repaint set-ups (constraint count / rows, resampling passes 0..2, correctors, flags) with the echo network:
     GPU device-RNG generator -- eager and graph replay -- equals the oracle bit for bit; constrained rows are pinned."""
