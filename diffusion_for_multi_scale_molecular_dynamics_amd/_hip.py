@@ -21,7 +21,7 @@ MAX_CLASSES = 8
 TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
     TAG_INIT_LATTICE, TAG_RESAMPLE_Z, TAG_RESAMPLE_U = range(11)
 
-ABI_VERSION = 10         # MDX_ABI_VERSION of include/mdx_hip.h
+ABI_VERSION = 11         # MDX_ABI_VERSION of include/mdx_hip.h
 ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
@@ -60,7 +60,7 @@ class Schedule(C.Structure):
 class Rng(C.Structure):
     """mdx_rng_t"""
     _fields_ = [("seed", C.c_uint64), ("call", C.c_uint32), ("draw_stride", C.c_uint32),
-                ("draw_offset", C.c_uint32)]
+                ("draw_offset", C.c_uint32), ("reserved", C.c_uint32), ("call_dev", C.c_void_p)]
 
 
 class PcFlags(C.Structure):

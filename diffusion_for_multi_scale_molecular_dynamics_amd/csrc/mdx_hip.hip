@@ -29,6 +29,10 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 
+// the call index of a counter-based RNG request: the device word when the request names one (launches captured into a hipGraph)
+__device__ __forceinline__ uint32_t rng_call(const mdx_rng_t& r) { return r.call_dev ? *r.call_dev : r.call; }
+
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP; }
 inline hipStream_t as_stream(mdx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -464,7 +468,7 @@ __device__ __forceinline__ PcStep make_step(const PcArgs& p, int mode, int index
     }
     st.k0 = (uint32_t)p.rng.seed;
     st.k1 = (uint32_t)(p.rng.seed >> 32);
-    st.call8 = p.rng.call << 8;
+    st.call8 = rng_call(p.rng) << 8;
     st.fixed_c2 = FixedSoftmaxC2{0.0f, 0.0f, 0};
     return st;
 }
@@ -1232,7 +1236,7 @@ __global__ __launch_bounds__(kBlock) void pc_noise_fill_kernel(NoiseFillArgs p)
     const int64_t n_records = p.B * (int64_t)p.n_iterations;      // (iteration, structure) pairs
     const int rec_total = p.rec0 + p.M * p.rec1;                  // predictor part | M corrector parts
     const uint32_t k0 = (uint32_t)p.rng.seed, k1 = (uint32_t)(p.rng.seed >> 32);
-    const uint32_t call8 = p.rng.call << 8;
+    const uint32_t call8 = rng_call(p.rng) << 8;
     // whole records per workgroup pass: as many as the lanes cover (one lane per atom) and the stage holds
     int R = kBlock / N;
     if (R > kStageFloats / rec_total) R = kStageFloats / rec_total;
@@ -1496,7 +1500,7 @@ __global__ __launch_bounds__(kBlock) void repaint_rows_kernel(RepaintArgs p)
     const int index = (p.d_index ? *p.d_index : 0) + p.index_i;
     const int C = p.C, d = p.d;
     const uint32_t k0 = (uint32_t)p.rng.seed, k1 = (uint32_t)(p.rng.seed >> 32);
-    const uint32_t call8 = p.rng.call << 8;
+    const uint32_t call8 = rng_call(p.rng) << 8;
     const uint32_t draw = (uint32_t)index * p.rng.draw_stride + p.rng.draw_offset;
     const int64_t total = p.B * p.K;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -1554,7 +1558,7 @@ __global__ __launch_bounds__(kBlock) void forward_step_kernel(ForwardStepArgs p)
     if (index < 1 || index >= p.sched.T) return;          // nothing to re-noise at the ends of the trajectory
     const int C = p.C, d = p.d;
     const uint32_t k0 = (uint32_t)p.rng.seed, k1 = (uint32_t)(p.rng.seed >> 32);
-    const uint32_t call8 = p.rng.call << 8;
+    const uint32_t call8 = rng_call(p.rng) << 8;
     const uint32_t draw = (uint32_t)index * p.rng.draw_stride + p.rng.draw_offset;
     const float g = p.sched.g[index];
     const float* q = p.sched.q + (int64_t)index * C * C;

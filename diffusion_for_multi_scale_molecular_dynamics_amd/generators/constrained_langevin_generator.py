@@ -66,7 +66,7 @@ class ConstrainedLangevinGenerator(LangevinGenerator):
         rng = self._rng(0)
         rng_index = index_i
         kernels.repaint_constrained_rows(sched, rng_index, d_index, cx, ca, cidx, z, u,
-                                         Rng(rng.seed, rng.call, rng.draw_stride, rng.draw_stride + rng.draw_offset),
+                                         Rng(rng.seed, rng.call, rng.draw_stride, rng.draw_stride + rng.draw_offset, 0, rng.call_dev),
                                          x, a)
         return AXL(A=a, X=x, L=composition.L)
 

@@ -80,6 +80,7 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
 
         self._scheduler = None       # device tables, built on first use for the sampling device
         self._status = None
+        self._call_word = None       # int32 [1] on the device: the Philox call index of the current sample() call (_rng)
         self._buffers = {}
         if self.record:
             self.sample_trajectory_recorder = SampleTrajectory()
@@ -122,10 +123,14 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         return (self.number_of_corrector_steps + 1) * (self.resampling_steps + 1)
 
     def _rng(self, draw_offset: int) -> Rng:
+        """The counter-based request of one launch.  The call index travels as a DEVICE word (`_call_word`, written by
+        _begin_call) as well as by value: a launch captured into a hipGraph reads the word, so the same graph serves every
+        later sample() call of that shape."""
         src = self.noise_source
         seed, call = (src.seed, src.call) if getattr(src, "device_rng", False) else (0, 0)
+        word = self._call_word.data_ptr() if getattr(src, "device_rng", False) and self._call_word is not None else None
         return Rng(seed, call, self._draw_stride(),
-                   self._visit * (self.number_of_corrector_steps + 1) + draw_offset)
+                   self._visit * (self.number_of_corrector_steps + 1) + draw_offset, 0, word)
 
     def _begin_call(self, device):
         """One sample() call = one Philox `call` index; the trajectory initialiser shares the noise source."""
@@ -134,6 +139,9 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
             rank = torch.distributed.get_rank() if torch.distributed.is_available() and \
                 torch.distributed.is_initialized() else 0
             self.noise_source = DevicePhiloxNoise(seed + rank, self._call_counter)
+            if self._call_word is None or self._call_word.device != torch.device(device):
+                self._call_word = torch.zeros(1, dtype=torch.int32, device=device)
+            kernels.index_set(self._call_word, self._call_counter)
             self._call_counter += 1
         if hasattr(self.trajectory_initializer, "noise_source"):
             self.trajectory_initializer.noise_source = self.noise_source
@@ -508,11 +516,30 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
                               options=self.fused_sampler_options)
         return comp
 
+    def _graph_key(self, start: AXL):
+        """What a captured iteration depends on besides the tensors it reads: the batch's shape and device, the network's
+        parameters (their storage and version: the packed weight images are rebuilt when a parameter changes) and its
+        arithmetic mode."""
+        net = self.axl_network
+        return (tuple(start.X.shape), tuple(start.L.shape), str(start.X.device), getattr(net, "edge_chain_precision", None),
+                tuple((p.data_ptr(), p._version) for p in net.parameters()))
+
     def _sample_with_graph(self, start: AXL, starting_step_index: int, ending_step_index: int) -> AXL:
-        loop = IterationLoop(self, start, starting_step_index, use_graph=True)
+        """The iteration is captured ONCE per (shape, network state) and kept: later sample() calls copy their starting
+        composition into the graph's buffers, rewrite the step index and the Philox call index on the device and replay it
+        (a capture costs about five iterations' time).  The result is a copy: the buffers belong to the graph."""
+        key = self._graph_key(start)
+        kept = self._buffers.get("graph_loop")
+        if kept is not None and getattr(kept, "key", None) == key:
+            loop = kept
+            loop.reset(start, starting_step_index)
+        else:
+            loop = IterationLoop(self, start, starting_step_index, use_graph=True)
+            loop.key = key
+            self._buffers["graph_loop"] = loop
         loop.advance(starting_step_index - max(ending_step_index, 0))
-        self._buffers["graph_loop"] = loop      # keep the graph alive until the next call
-        return loop.composition
+        comp = loop.composition
+        return AXL(A=comp.A.clone(), X=comp.X.clone(), L=comp.L.clone())
 
     def check_status(self):
         """Read the device status word once (the only host synchronisation of a sample() call)."""
@@ -602,6 +629,14 @@ class IterationLoop:
                 if was_enabled:
                     gc.enable()
         kernels.index_set(self.d_index, starting_step_index - 1)
+
+    def reset(self, start: AXL, starting_step_index: int):
+        """Start another trajectory in the same buffers (the captured graph is reused)."""
+        self.composition.A.copy_(start.A)
+        self.composition.X.copy_(start.X)
+        self.composition.L.copy_(start.L)
+        kernels.index_set(self.d_index, starting_step_index - 1)
+        self.remaining = starting_step_index
 
     def advance(self, iterations: int):
         """Run `iterations` sampler iterations (asynchronously on the current stream)."""

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 10
+#define MDX_ABI_VERSION 11
 
 /* status codes */
 #define MDX_OK 0
@@ -92,6 +92,10 @@ typedef struct mdx_rng {
     uint32_t call;          /* index of the sample() call (sub-batch) */
     uint32_t draw_stride;   /* number_of_corrector_steps + 1 */
     uint32_t draw_offset;   /* 0 predictor, 1+m for corrector m */
+    uint32_t reserved;      /* 0 */
+    const uint32_t* call_dev;   /* nullable: device word that holds the call index instead of `call` -- a launch captured into a
+                                   hipGraph then serves every later sample() call of the same shape (the word is rewritten
+                                   between replays, like the step index) */
 } mdx_rng_t;
 
 /* Per-step flags of PredictorCorrectorSamplingParameters (generators/predictor_corrector_axl_generator.py:22-30). */

@@ -238,6 +238,45 @@ def test_graph_replay_equals_eager(cuda, name):
     assert np.array_equal(outs[0].X.view(np.int32), outs[1].X.view(np.int32))   # same kernels, same draws
 
 
+@pytest.mark.parametrize("name", ["traj_mlp_c3", "traj_egnn_rc", "traj_repaint_mlp"])
+def test_captured_iteration_is_reused_across_sample_calls(cuda, name):
+    """use_hip_graph: the iteration is captured by the FIRST sample() call of a shape and replayed by the later ones (the Philox
+    call index lives in a device word that _begin_call rewrites; the start composition is copied into the graph's buffers).
+    Three consecutive calls equal the eager generator's three calls bit for bit, differ from one another, do not share storage,
+    and run on ONE IterationLoop; a changed network parameter or batch size captures anew."""
+    P = _pkg()
+    table = cases.REPAINT if "repaint" in name else cases.TRAJECTORIES
+    constraint = None
+    if "repaint" in name:
+        constraint = P["Constraint"](elements=["Si"], constrained_relative_coordinates=torch.rand(3, 3),
+                                     constrained_atom_types=torch.zeros(3, dtype=torch.long))
+    extra = dict(repaint_resampling_steps=1) if "repaint" in name else {}
+    outs = {}
+    for use_graph in (False, True):
+        gen, *_ = _build(name, table, cuda, constraint=constraint, rng_mode="device", seed=41, use_hip_graph=use_graph, **extra)
+        with torch.no_grad():
+            calls = [gen.sample(7, cuda) for _ in range(3)]
+        if use_graph:
+            loop = gen._buffers["graph_loop"]
+            kept = [c.X.clone() for c in calls]
+            with torch.no_grad():
+                again = gen.sample(7, cuda)
+                assert gen._buffers["graph_loop"] is loop                        # a fourth call: still the first capture
+                assert all(torch.equal(c.X, k) for c, k in zip(calls, kept))    # earlier results are not the graph's buffers
+                assert len({c.X.data_ptr() for c in calls + [again]}) == 4
+                other = gen.sample(5, cuda)                                      # another batch size: a capture of its own
+                assert gen._buffers["graph_loop"] is not loop and other.X.shape[0] == 5
+                loop = gen._buffers["graph_loop"]
+                p0 = next(gen.axl_network.parameters())
+                p0.mul_(1.0)                                                     # in-place: bumps the parameter's version
+                gen.sample(5, cuda)
+                assert gen._buffers["graph_loop"] is not loop
+        outs[use_graph] = [_np(c) for c in calls]
+    for a, b in zip(outs[False], outs[True]):
+        assert np.array_equal(a.A, b.A) and np.array_equal(a.X.view(np.int32), b.X.view(np.int32))
+    assert not np.array_equal(outs[True][0].X, outs[True][1].X) and not np.array_equal(outs[True][1].X, outs[True][2].X)
+
+
 def test_graph_replay_repaint(cuda):
     P = _pkg()
     constraint = P["Constraint"](elements=["Si"], constrained_relative_coordinates=torch.rand(3, 3),
