@@ -188,6 +188,19 @@ __global__ __launch_bounds__(kBlock) void egnn_scores_kernel(const float* __rest
 //   scores[i, :]                            as egnn_scores_kernel
 //   zero_out[0 .. n_zero)                   the all-zero lattice output of the network (egnn_score_network.py:299-303)
 // A row of h is read once as 16-byte lane loads; the C <= kMaxClasses dot products share it and end in a butterfly.
+// sum over the 64 lanes with DPP adds (rows of 16, then lane 15 / 31 of the rows below; the total is lane 63's), handed to every
+// lane through a scalar register: no LDS permutes, a fixed order
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 constexpr int kMaxClasses = 8;
 constexpr int kWaveSize = 64;
 
@@ -245,10 +258,7 @@ __global__ __launch_bounds__(kBlock) void egnn_outputs_kernel(const float* __res
 #pragma unroll
                 for (int m = 0; m < kNodesPerWave; ++m) {
                     float v = part[m][c];
-                    if (c != mask_class) {
-#pragma unroll
-                        for (int o = kWaveSize / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWaveSize);
-                    }
+                    if (c != mask_class) v = wave_sum(v);
                     if (lane == 0 && node0 + m < n_nodes) logits[(node0 + m) * C + c] = (c == mask_class) ? -__builtin_inff() : v + cb[c];
                 }
             }

@@ -1597,11 +1597,19 @@ __global__ __launch_bounds__(256) void egnn_node_gather_kernel(const float* __re
                 reinterpret_cast<f32x4*>(out + node * H)[q] = acc;
             }
         }
+        // sum over the wavefront with DPP adds (rows of 16, then lane 15 / 31 of the rows below: the total is lane 63's), read
+        // back through a scalar register -- no LDS permutes; a fixed order
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (k < D) {
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) part[k] += __shfl_xor(part[k], d);
+                float v = part[k];
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, false));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
+                part[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
             }
         }
         if (lane < D) {
