@@ -517,12 +517,15 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         return comp
 
     def _graph_key(self, start: AXL):
-        """What a captured iteration depends on besides the tensors it reads: the batch's shape and device, the network's
-        parameters (their storage and version: the packed weight images are rebuilt when a parameter changes) and its
-        arithmetic mode."""
+        """What a captured iteration depends on besides the tensors it reads: the batch's shape and device, the generator's
+        settings that travel as kernel arguments, the network's parameters (their storage and version: the packed weight
+        images are rebuilt when a parameter changes) and its arithmetic mode."""
         net = self.axl_network
+        settings = (self.number_of_corrector_steps, self.resampling_steps, self.atom_type_greedy_sampling,
+                    self.one_atom_type_transition_per_step, self.atom_type_transition_in_corrector,
+                    self.use_fixed_lattice_parameters, self.small_epsilon, self.num_classes)     # kernel arguments of the capture
         return (tuple(start.X.shape), tuple(start.L.shape), str(start.X.device), getattr(net, "edge_chain_precision", None),
-                tuple((p.data_ptr(), p._version) for p in net.parameters()))
+                settings, tuple((p.data_ptr(), p._version) for p in net.parameters()))
 
     def _sample_with_graph(self, start: AXL, starting_step_index: int, ending_step_index: int) -> AXL:
         """The iteration is captured ONCE per (shape, network state) and kept: later sample() calls copy their starting
