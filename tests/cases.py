@@ -67,3 +67,19 @@ C3_SHAPE = (noise_ns(1000, **LIN), sampling_ns(64, 1, M=2, one=False, greedy=Fal
 # cell 11.084): tests/golden/traj_egnn_c4_{top,mid}.npz
 C4_SHAPE = (noise_ns(1000, **LIN), sampling_ns(64, 2, M=2, one=True, greedy=True, cell=[11.084] * 3),
             lambda eb: nets.egnn_c3_net(2, edge_builder=eb))
+
+
+def diamond_sites(n_cells):
+    """The 8 n^3 sites of the diamond structure in an n x n x n supercell, relative coordinates, cell-major order (the
+    constraint of BASELINE configs[4]: the first 108 of the 216 sites of Si 3x3x3 are pinned)."""
+    import torch
+    base = torch.tensor([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0],
+                         [.25, .25, .25], [.25, .75, .75], [.75, .25, .75], [.75, .75, .25]])
+    cells = torch.cartesian_prod(*[torch.arange(n_cells)] * 3).float()
+    return ((cells[:, None, :] + base[None]) / n_cells).reshape(-1, 3)
+
+
+# BASELINE configs[4] at the production network (tests/golden/net_egnn_c5.npz, traj_egnn_c5_{top,bottom}.npz): Si 3x3x3,
+# N = 216, cell 16.29, T = 2000 linear, M = 2, ConstrainedLangevinGenerator with K = 108 pinned diamond sites, B = 2
+C5_SHAPE = (noise_ns(2000, **LIN), sampling_ns(216, 1, M=2, one=False, greedy=False, cell=[16.29] * 3),
+            lambda eb: nets.egnn_c3_net(1, edge_builder=eb))

@@ -841,6 +841,89 @@ def golden_c3_shape(only=None):
         save(name + ".npz", **out)
 
 
+def _diamond_sites(n_cells):
+    """The 8 n^3 sites of the diamond structure in an n x n x n supercell, in relative coordinates (cell-major order)."""
+    base = torch.tensor([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0],
+                         [.25, .25, .25], [.25, .75, .75], [.75, .25, .75], [.75, .75, .25]])
+    cells = torch.cartesian_prod(*[torch.arange(n_cells)] * 3).float()
+    return ((cells[:, None, :] + base[None]) / n_cells).reshape(-1, 3)
+
+
+def golden_c5_shape():
+    """BASELINE configs[4] at the production network: Si 3x3x3 (N = 216, cell 16.29: experiments/.../Si_3x3x3/
+    config_diffusion_egnn.yaml:46-60,93-103), the 4 x 256 x 4 EGNN at rc 7.5 (~85 edges per atom in the 16.5 A clipped graph
+    cell), ConstrainedLangevinGenerator (generators/constrained_langevin_generator.py:94-163) with K = 108 diamond sites pinned
+    (constrained_indices = arange), T = 2000, sigma 1e-4 .. 0.2 linear, eps 2.5e-8, M = 2, B = 2, formula weights:
+      net_egnn_c5.npz          the network forward on two structures
+      traj_egnn_c5_top.npz     sample_from_noisy_composition(2000 -> 1998): predictor, repaint (noised known rows), 2 correctors
+      traj_egnn_c5_bottom.npz  the same 2 -> 0: the second predictor's repaint takes the i-1 == 0 branch (no noising, :120-123)
+    Every draw and every step's input / output composition recorded (the outputs as explicit copies taken when the step
+    returns, so the in-place repaint of the predictor's output is what is stored)."""
+    net = _egnn_c3(1)
+    g = torch.Generator().manual_seed(1216)
+    B, N, cell, K = 2, 216, 16.29, 108
+    batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.randint(0, 2, (B, N), generator=g), X=torch.rand(B, N, 3, generator=g),
+                                        L=torch.tensor([cell, cell, cell, 0, 0, 0.0]).repeat(B, 1)),
+             TIME: torch.rand(B, 1, generator=g), NOISE: torch.rand(B, 1, generator=g) * 0.2,
+             CARTESIAN_FORCES: torch.zeros(B, N, 3)}
+    with torch.no_grad():
+        o = net(batch, conditional=False)
+    save("net_egnn_c5.npz", A=_np(batch[NOISY_AXL_COMPOSITION].A), X=_np(batch[NOISY_AXL_COMPOSITION].X),
+         L=_np(batch[NOISY_AXL_COMPOSITION].L), time=_np(batch[TIME]), noise=_np(batch[NOISE]),
+         out_A=_np(o.A), out_X=_np(o.X), out_L=_np(o.L))
+
+    sites = _diamond_sites(3)[:K].clone()
+    kw = dict(T=2000, N=N, num_atom_types=1, M=2, one=False, greedy=False, cell=[cell] * 3,
+              noise_kw=dict(sigma_min=1e-4, sigma_max=0.2, schedule_type="linear", corrector_step_epsilon=2.5e-8))
+    for name, start, end, masked_fraction, spread in (("traj_egnn_c5_top", 2000, 1998, 1.0, None),
+                                                      ("traj_egnn_c5_bottom", 2, 0, 0.1, 2e-4)):
+        constraint = SamplingConstraint(elements=["Si"], constrained_relative_coordinates=sites.clone(),
+                                        constrained_atom_types=torch.zeros(K, dtype=torch.long))
+        gen, npar, spar = make_generator(record=False, net=net, constraint=constraint, **kw)
+        assert torch.equal(gen.constraint_indices, torch.arange(K))
+        X0 = torch.rand(B, N, 3, generator=g)
+        masked = torch.rand(B, N, generator=g) < masked_fraction
+        A0 = torch.where(masked, torch.ones(B, N, dtype=torch.long), torch.zeros(B, N, dtype=torch.long))
+        if spread is not None:      # near the end of a run the pinned atoms sit at their (slightly noised) sites, unmasked
+            X0[:, :K] = torch.remainder(sites[None] + spread * torch.randn(B, K, 3, generator=g), 1.0)
+            A0[:, :K] = 0
+        L0 = torch.tensor([cell, cell, cell, 0, 0, 0.0]).repeat(B, 1)
+        steps = dict(pred=[], corr=[])
+        pred0, corr0 = gen.predictor_step, gen.corrector_step
+
+        def copy(axl):
+            return AXL(A=axl.A.clone(), X=axl.X.clone(), L=axl.L.clone())
+
+        def predictor_step(composition_i, index_i, cartesian_forces):
+            before = copy(composition_i)
+            out = pred0(composition_i, index_i, cartesian_forces)
+            steps["pred"].append((index_i, before, copy(out)))
+            return out
+
+        def corrector_step(composition_i, index_i, cartesian_forces):
+            before = copy(composition_i)
+            out = corr0(composition_i, index_i, cartesian_forces)
+            steps["corr"].append((index_i, before, copy(out)))
+            return out
+
+        gen.predictor_step, gen.corrector_step = predictor_step, corrector_step
+        torch.manual_seed(1500 + start)
+        with torch.no_grad(), DrawRecorder() as rec:
+            axl = gen.sample_from_noisy_composition(AXL(A=A0.clone(), X=X0.clone(), L=L0.clone()), start, end)
+        out = dict(final_A=_np(axl.A), final_X=_np(axl.X), final_L=_np(axl.L), batch=np.array(B),
+                   start_A=_np(A0), start_X=_np(X0), start_L=_np(L0), start_index=np.array(start), end_index=np.array(end),
+                   constrained_relative_coordinates=_np(sites), constrained_atom_types=np.zeros(K, dtype=np.int64),
+                   constrained_indices=_np(gen.constraint_indices))
+        out.update(rec.pack())
+        for kind, key_in, key_out in (("pred", "pred_composition_i", "pred_composition_im1"),
+                                      ("corr", "corr_composition_i", "corr_corrected_composition_i")):
+            out[f"{kind}_index"] = np.array([s[0] for s in steps[kind]], dtype=np.int64)
+            for field in ("A", "X", "L"):
+                out[f"{key_in}_{field}"] = np.stack([_np(getattr(s[1], field)) for s in steps[kind]])
+                out[f"{key_out}_{field}"] = np.stack([_np(getattr(s[2], field)) for s in steps[kind]])
+        save(name + ".npz", **out)
+
+
 def golden_egnn_variants():
     """E_GCL options the BASELINE configurations do not use but the module accepts (models/egnn.py:36-66,128-131,157,234-264;
     models/egnn_utils.py:111-140): attention, normalize, tanh, sum aggregations, no residual, drop_duplicate_edges=False.
@@ -901,5 +984,7 @@ if __name__ == "__main__":
         golden_c3_shape()
     if which in ("all", "c4"):
         golden_c3_shape(only=("traj_egnn_c4_top", "traj_egnn_c4_mid"))
+    if which in ("all", "c5"):
+        golden_c5_shape()
     if which in ("all", "variants"):
         golden_egnn_variants()

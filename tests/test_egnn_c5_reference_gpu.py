@@ -1,0 +1,193 @@
+"""GPU parity of BASELINE configs[4] (Si 3x3x3 repaint) at the PRODUCTION network against the REFERENCE's own outputs.
+
+The reference's 3x3x3 configuration runs the same 4 x 256 x 4 EGNN as configs[2] (experiments/.../Si_3x3x3/
+config_diffusion_egnn.yaml:46-60,93-103) on N = 216 atoms in a 16.29 A cell (graph cell clipped to 16.5 A: ~85 edges per atom
+instead of ~25) through ConstrainedLangevinGenerator (generators/constrained_langevin_generator.py:94-163).  The fixtures
+net_egnn_c5 / traj_egnn_c5_{top,bottom} (tests/golden/make_golden.py::golden_c5_shape; formula weights) hold what the reference
+computed there with K = 108 diamond sites pinned, T = 2000, M = 2, B = 2.  Held against them, in both arithmetic modes of the
+MFMA kernels:
+
+  * the network forward (scores <= 1e-5 rel-L2, logits close);
+  * every predictor (+ repaint) and corrector step from the reference's recorded composition with the reference's draws: atom
+    types exact, coordinates <= 1e-5 on the torus, the pinned rows of each predictor output BIT FOR BIT (the noised known atoms;
+    at index 0 the un-noised sites: the i - 1 == 0 branch, :120-123);
+  * the same indices in free run;
+  * at the benchmarked size (256 structures x 216 atoms, ~4.7 M edges per forward): the reference's two structures scattered in
+    the batch come out as the reference computed them alone; the repaint sampler's captured iteration equals the eager one.
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import nets
+from conftest import load_golden, torus_rel_l2
+from oracle import reference_sampler as RS
+from test_egnn_c3_reference_gpu import _batch
+from test_generator_gpu import _pkg, _replayed
+
+pytestmark = pytest.mark.gpu
+
+K = 108
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", None])
+def test_c5_network_forward_against_reference(cuda, precision):
+    g = load_golden("net_egnn_c5.npz")
+    net = nets.egnn_c3_net(1).to(cuda)
+    net.edge_chain_precision = precision
+    with torch.no_grad():
+        out = net(_batch(g, cuda), conditional=False)
+    net.check_status()
+    assert torch.isinf(out.A[..., -1]).all() and (out.A[..., -1] < 0).all()
+    ref = g["out_X"].astype(np.float64)
+    err = np.linalg.norm(out.X.cpu().numpy() - ref) / np.linalg.norm(ref)
+    assert err < 1e-5, f"{precision}: scores rel-L2 {err:.2e} against the reference at ~85 edges per atom"
+    np.testing.assert_allclose(out.A.cpu().numpy()[..., :-1], g["out_A"][..., :-1], rtol=1e-4, atol=1e-5)
+    if precision is not None:
+        assert all(layer._chain[1] is not None and layer._chain[1].precision == precision
+                   for layer in net.egnn.graph_layers)
+
+
+def _constraint(P, g=None):
+    sites = cases.diamond_sites(3)[:K].clone() if g is None else torch.from_numpy(g["constrained_relative_coordinates"])
+    return P["Constraint"](elements=["Si"], constrained_relative_coordinates=sites,
+                           constrained_atom_types=torch.zeros(K, dtype=torch.long))
+
+
+def _generator(cuda, precision, g=None, noise_kw=None, **extra):
+    P = _pkg()
+    nkw, sampling_kw, netf = cases.C5_SHAPE
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar, spar = P["Noise"](**(noise_kw or nkw)), P["Sampling"](**dict(sampling_kw, **extra))
+    net = netf(None).to(cuda)
+    net.edge_chain_precision = precision
+    return P["Constrained"](npar, spar, net, _constraint(P, g)), spar
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("name", ["traj_egnn_c5_top", "traj_egnn_c5_bottom"])
+def test_c5_teacher_forced_steps(cuda, name, precision):
+    g = load_golden(name + ".npz")
+    assert np.array_equal(g["constrained_relative_coordinates"], cases.diamond_sites(3)[:K].numpy())
+    gen, spar = _generator(cuda, precision, g)
+    gen.noise_source = _replayed(g)
+    B, M = int(g["batch"]), spar.number_of_corrector_steps
+
+    def axl(prefix, k):
+        return RS.AXL(A=torch.from_numpy(g[prefix + "_A"][k]).to(cuda), X=torch.from_numpy(g[prefix + "_X"][k]).to(cuda),
+                      L=torch.from_numpy(g[prefix + "_L"][k]).to(cuda))
+
+    worst = 0.0
+    with torch.no_grad():
+        gen._prepare(cuda)
+        gen._begin_call(cuda)
+        forces = torch.zeros(B, spar.number_of_atoms, 3, device=cuda)
+        for k, index in enumerate(g["pred_index"]):
+            out = gen.predictor_step(axl("pred_composition_i", k), int(index), forces)
+            want = g["pred_composition_im1_X"][k]
+            assert np.array_equal(out.A.cpu().numpy(), g["pred_composition_im1_A"][k]), (name, "pred", k)
+            got = out.X.cpu().numpy()
+            assert np.array_equal(got[:, :K].view(np.int32), want[:, :K].view(np.int32)), "repainted rows differ in bits"
+            worst = max(worst, torus_rel_l2(got, want))
+            for m in range(M):
+                kk = k * M + m
+                out = gen.corrector_step(axl("corr_composition_i", kk), int(index) - 1, forces, m)
+                assert np.array_equal(out.A.cpu().numpy(), g["corr_corrected_composition_i_A"][kk]), (name, "corr", kk)
+                worst = max(worst, torus_rel_l2(out.X.cpu().numpy(), g["corr_corrected_composition_i_X"][kk]))
+    gen.check_status()
+    assert gen.noise_source.inner.exhausted()
+    assert worst < 1e-5, f"{name} / {precision}: worst per-step rel-L2 {worst:.2e}"
+    if int(g["end_index"]) == 0:
+        last = g["pred_composition_im1_X"][-1][:, :K]
+        assert np.array_equal(last, np.broadcast_to(g["constrained_relative_coordinates"], last.shape))
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("name", ["traj_egnn_c5_top", "traj_egnn_c5_bottom"])
+def test_c5_free_run_against_reference(cuda, name, precision):
+    g = load_golden(name + ".npz")
+    gen, spar = _generator(cuda, precision, g)
+    gen.noise_source = _replayed(g)
+    start = RS.AXL(A=torch.from_numpy(g["start_A"]).to(cuda), X=torch.from_numpy(g["start_X"]).to(cuda),
+                   L=torch.from_numpy(g["start_L"]).to(cuda))
+    with torch.no_grad():
+        out = gen.sample_from_noisy_composition(start, int(g["start_index"]), int(g["end_index"]))
+    gen.check_status()
+    assert gen.noise_source.inner.exhausted()
+    assert np.array_equal(out.A.cpu().numpy(), g["final_A"])
+    err = torus_rel_l2(out.X.cpu().numpy(), g["final_X"])
+    assert err < 1e-5, f"{name} / {precision}: final rel-L2 {err:.2e}"
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_c5_full_size_batch_properties(cuda, precision):
+    """configs[4] at its per-GPU batch (256 structures x 216 atoms, ~4.7 M edges: what `bench.py --workload C5` launches): the
+    reference's two structures of net_egnn_c5, scattered among 254 random ones, come out as the REFERENCE computed them alone
+    (<= 1e-5 rel-L2); the same two alone on the HIP path agree with their in-batch result; two forwards of the batch are
+    bit-identical; permuting the atoms of every structure permutes the outputs."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
+                                                                              NOISY_AXL_COMPOSITION, TIME)
+    g = load_golden("net_egnn_c5.npz")
+    net = nets.egnn_c3_net(1).to(cuda)
+    net.edge_chain_precision = precision
+    B, N = 256, 216
+    gen = torch.Generator().manual_seed(2160)
+    X = torch.rand(B, N, 3, generator=gen)
+    A = torch.randint(0, 2, (B, N), generator=gen)
+    L = torch.from_numpy(g["L"][:1]).repeat(B, 1)
+    noise = torch.rand(B, 1, generator=gen) * 0.4 + 0.01
+    time = torch.rand(B, 1, generator=gen)
+    where = torch.tensor([37, 255])
+    for k, b in enumerate(where.tolist()):
+        X[b], A[b], L[b] = torch.from_numpy(g["X"][k]), torch.from_numpy(g["A"][k]), torch.from_numpy(g["L"][k])
+        noise[b], time[b] = torch.from_numpy(g["noise"][k]), torch.from_numpy(g["time"][k])
+
+    def forward(X, A, L, time, noise):
+        batch = {NOISY_AXL_COMPOSITION: AXL(A=A.to(cuda), X=X.to(cuda), L=L.to(cuda)), TIME: time.to(cuda),
+                 NOISE: noise.to(cuda), CARTESIAN_FORCES: torch.zeros(X.shape, device=cuda)}
+        with torch.no_grad():
+            out = net(batch, conditional=False)
+        net.check_status()
+        return out
+
+    full = forward(X, A, L, time, noise)
+    ref = g["out_X"].astype(np.float64)
+    got = full.X[where.to(cuda)].cpu().numpy()
+    err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert err < 1e-5, f"{precision}: the reference's structures inside a 256-structure batch: scores rel-L2 {err:.2e}"
+    np.testing.assert_allclose(full.A[where.to(cuda)].cpu().numpy()[..., :-1], g["out_A"][..., :-1], rtol=1e-4, atol=1e-5)
+    alone = forward(X[where], A[where], L[where], time[where], noise[where])
+    assert float((alone.X - full.X[where.to(cuda)]).norm() / alone.X.norm()) < 1e-5
+    again = forward(X, A, L, time, noise)
+    assert torch.equal(again.X, full.X) and torch.equal(again.A, full.A)
+    perm = torch.stack([torch.randperm(N, generator=gen) for _ in range(B)])
+    rows = torch.arange(B)[:, None]
+    permuted = forward(X[rows, perm], A[rows, perm], L, time, noise)
+    want = full.X[rows.to(cuda), perm.to(cuda)]
+    assert float((permuted.X - want).norm() / want.norm()) < 1e-5
+
+
+@pytest.mark.parametrize("resampling", [0, 1])
+def test_c5_full_size_repaint_sampler_graph_replay_equals_eager(cuda, resampling):
+    """The benchmarked C5 iteration at full size and production width (256 structures, device RNG, M = 2, repaint of 108 rows,
+    without and with one resampling pass) over a three-index schedule, index 0 included: hipGraph replay == eager launches,
+    bit for bit; pinned rows exact, every atom unmasked and on the torus."""
+    nkw = dict(cases.C5_SHAPE[0], total_time_steps=3)
+    outs = {}
+    for mode in ("eager", "graph"):
+        gen, spar = _generator(cuda, "f16x3", noise_kw=nkw, rng_mode="device", seed=79, use_hip_graph=mode == "graph",
+                               repaint_resampling_steps=resampling)
+        with torch.no_grad():
+            out = gen.sample(256, cuda)
+        assert gen.f16_range_fallbacks == 0
+        outs[mode] = (out.A.cpu().numpy(), out.X.cpu().numpy())
+    assert np.array_equal(outs["eager"][0], outs["graph"][0])
+    assert np.array_equal(outs["eager"][1].view(np.int32), outs["graph"][1].view(np.int32))
+    A, X = outs["graph"]
+    sites = cases.diamond_sites(3)[:K].numpy()
+    assert np.array_equal(X[:, :K], np.broadcast_to(sites, (256, K, 3))) and (A[:, :K] == 0).all()
+    assert (A == 0).all() and np.isfinite(X).all() and (X >= 0).all() and (X < 1).all()

@@ -408,6 +408,55 @@ def test_c3_shape_trajectories(oracle, name):
         assert torus_rel_l2(r[3].X, g["pred_composition_im1_X"][k]) < 1e-5
 
 
+def test_c5_shape_network_against_reference_forward(oracle):
+    """BASELINE configs[4]'s structure size with the production EGNN (N = 216, cell 16.29 clipped to 16.5 for the graph, ~85
+    edges per atom): the product's torch module on the CPU (oracle edge list) against the REFERENCE's forward."""
+    import torch
+    g = load_golden("net_egnn_c5.npz")
+    net = nets.egnn_c3_net(1, edge_builder=nets.oracle_edge_builder)
+    with torch.no_grad():
+        out = net(_c3_batch(g), conditional=False)
+    ref = g["out_X"].astype(np.float64)
+    assert np.linalg.norm(out.X.numpy() - ref) / np.linalg.norm(ref) < 1e-5
+    np.testing.assert_allclose(out.A.numpy()[..., :-1], g["out_A"][..., :-1], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["traj_egnn_c5_top", "traj_egnn_c5_bottom"])
+def test_c5_shape_trajectories(oracle, name):
+    """The oracle's repaint sampler on the reference's draws at BASELINE configs[4]'s settings (T = 2000, M = 2, K = 108 of
+    216 atoms pinned, production EGNN), every step started from the composition the reference recorded: atom types exact,
+    coordinates within 1e-5, the pinned rows of each predictor output BIT FOR BIT (F1 / F2 of the known atoms; at index 0
+    the un-noised sites); then the same indices in free run."""
+    g = load_golden(name + ".npz")
+    noise_kw, sampling_kw, netf = cases.C5_SHAPE
+    npar, spar = cases.as_objects(noise_kw, sampling_kw)
+    constraint = dict(constrained_relative_coordinates=g["constrained_relative_coordinates"],
+                      constrained_atom_types=g["constrained_atom_types"], constrained_indices=g["constrained_indices"])
+    net = netf(nets.oracle_edge_builder)
+    K, M = len(g["constrained_indices"]), 2
+    replay = RS.ReplayNoise(g)
+    gen = RS.OracleLangevinGenerator(npar, spar, net, noise=replay, constraint=constraint)
+    worst = 0.0
+    for k, index in enumerate(g["pred_index"]):
+        comp = RS.AXL(A=g["pred_composition_i_A"][k].copy(), X=g["pred_composition_i_X"][k].copy(), L=g["pred_composition_i_L"][k])
+        out = gen.predictor_step(comp, int(index))
+        assert np.array_equal(out.A, g["pred_composition_im1_A"][k])
+        assert np.array_equal(out.X[:, :K].view(np.int32), g["pred_composition_im1_X"][k][:, :K].view(np.int32))
+        worst = max(worst, torus_rel_l2(out.X, g["pred_composition_im1_X"][k]))
+        for m in range(M):
+            kk = k * M + m
+            comp = RS.AXL(A=g["corr_composition_i_A"][kk].copy(), X=g["corr_composition_i_X"][kk].copy(),
+                          L=g["corr_composition_i_L"][kk])
+            out = gen.corrector_step(comp, int(index) - 1, m)
+            assert np.array_equal(out.A, g["corr_corrected_composition_i_A"][kk])
+            worst = max(worst, torus_rel_l2(out.X, g["corr_corrected_composition_i_X"][kk]))
+    assert replay.exhausted()
+    assert worst < 1e-5, worst
+    if int(g["end_index"]) == 0:          # the last repaint copies the known rows un-noised (constrained_langevin_generator.py:120-123);
+        last = g["pred_composition_im1_X"][-1][:, :K]        # the two correctors at index 0 then move them again (sample() re-pins)
+        assert np.array_equal(last, np.broadcast_to(g["constrained_relative_coordinates"], last.shape))
+
+
 def test_clipped_cell_has_no_duplicate_edges():
     """EGNNScoreNetwork builds its graph in a cell clipped to 2.2 x cutoff (egnn_score_network.py:236-240); there a pair of
     atoms is within the cutoff through at most one periodic image, so `drop_duplicate_edges` (models/egnn_utils.py:138-140)
