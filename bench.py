@@ -213,13 +213,15 @@ def time_launches(launch, device, launches):
     graph = torch.cuda.CUDAGraph()
     import gc
     gc.collect()                            # (torch >= 2.9 no longer does this on entry; no finaliser may call HIP in a capture)
+    was_enabled = gc.isenabled()
     gc.disable()
     try:
         with torch.cuda.graph(graph):
             for _ in range(launches):
                 launch()
     finally:
-        gc.enable()
+        if was_enabled:
+            gc.enable()
     graph.replay()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)
@@ -295,6 +297,7 @@ def time_edge_gemm(n_edges, device, hidden=256, launches=10):
                        "mdx_linear_act; 36 of these per network forward)", avg_launch_us=round(ms * 1e3, 2))
 
 
+TRAFFIC_FILE = "traffic_r03.json"      # the latest committed PMC record of the edge chain's HBM traffic
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 
 
@@ -319,11 +322,17 @@ def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
     shape16 = pack.precision == "f16x3"
     executed = flops * (3 if split else 1) / (ms * 1e-3) / 1e12
     peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
-    traffic = None              # HBM-side bytes per launch from separate PMC passes (profiles/traffic_r03.json), C3 shape only
+    # HBM-side bytes per launch: NOT measured by this run -- counters need their own rocprofv3 --pmc passes -- but read from
+    # the committed record of those passes (C3 shape only) and scaled by the edge count; `traffic_from` says so on the line
+    traffic = traffic_from = None
     try:
-        entry = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json")))[f"C3/edge_chain/{pack.precision}"]
-        if abs(edges.shape[0] - 819200) < 0.06 * 819200 and H == 256 and n_layers == 9:
-            traffic = entry["bytes_per_launch"]
+        entry = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))[f"C3/edge_chain/{pack.precision}"]
+        pmc_edges = int(entry.get("edges_per_launch", 819200))
+        if abs(edges.shape[0] - pmc_edges) < 0.06 * pmc_edges and H == 256 and n_layers == 9:
+            traffic = int(round(entry["bytes_per_launch"] * edges.shape[0] / pmc_edges))
+            traffic_from = (f"profiles/{TRAFFIC_FILE}: rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, corrected per MI355X_MICROARCH.md) "
+                            f"of this kernel at {pmc_edges} edges per launch = {entry['bytes_per_launch']} B, scaled to the "
+                            f"{edges.shape[0]} edges of the launch timed here; not a measurement of this run")
     except (OSError, KeyError, ValueError):
         pass
     prec_index = {"f32": 0, "f16x3_32x32": 1, "f16x3": 2}[pack.precision]
@@ -338,7 +347,8 @@ def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
                  if shape16 else "1.80-1.82 GHz on the 32x32x16 shape: power-bound") +
                 " (profiles/r03_chain_ablation.md)")
     return dict(bound="mfma", achieved=round(executed, 2), peak=peak, unit="TFLOP/s", frac=round(executed / peak, 4),
-                traffic=traffic, kernel=f"egnn_edge_chain_kernel<{H},{prec_index},{2 if pieces else 0}> ({mfma}"
+                traffic=traffic, traffic_from=traffic_from,
+                kernel=f"egnn_edge_chain_kernel<{H},{prec_index},{2 if pieces else 0}> ({mfma}"
                 f" per product; {n_layers} fused H->H layers + per-node message sums, {edges.shape[0]} edges per launch; 4 launches per "
                 f"network forward)",
                 avg_launch_us=round(ms * 1e3, 2), algorithmic_flops_per_launch=flops,
@@ -497,7 +507,9 @@ def main():
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
+        # (under torchrun the process group is initialised at ANY world size: `torchrun --nproc-per-node 1 bench.py` runs the
+        # job's RCCL calls -- group set-up, the packed all-gather, the MAX all-reduce, barriers, teardown -- on one GPU)
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)      # RCCL over xGMI
@@ -681,6 +693,7 @@ def main():
                    "score_network_forward": "fused HIP (one persistent kernel per launch of K iterations)"
                    if forward == "fused" else "PyTorch-ROCm module (plugin API)", "gather_ms": round(gather_ms, 4),
                    "parallelism": f"independent batches x{world}, one all-gather at the end",
+                   "collective_backend": args.backend if dist is not None else None,
                    # every switch of the library is an explicit argument; MDX_* variables are not read by the product
                    # and are listed only so that a stray one is visible
                    "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MDX_")},

@@ -92,8 +92,17 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
     # ---------------------------------------------------------------------------------------------------------
     # device state
     # ---------------------------------------------------------------------------------------------------------
-    def _prepare(self, device: torch.device):
+    @staticmethod
+    def _device(device) -> torch.device:
+        """`cuda` -> `cuda:<current>`: torch.device("cuda") != torch.device("cuda:0"), and everything this generator keeps per
+        device (tables, status and call words, the captured iteration) is compared by device."""
         device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        return device
+
+    def _prepare(self, device: torch.device):
+        device = self._device(device)
         if device.type != "cuda":
             raise MdxError(f"LangevinGenerator runs on the GPU hot path only; got device '{device}' "
                            "(there is no CPU fallback -- use the reference implementation on CPU)")
@@ -139,7 +148,11 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
             rank = torch.distributed.get_rank() if torch.distributed.is_available() and \
                 torch.distributed.is_initialized() else 0
             self.noise_source = DevicePhiloxNoise(seed + rank, self._call_counter)
-            if self._call_word is None or self._call_word.device != torch.device(device):
+            device = self._device(device)
+            if self._call_word is None or self._call_word.device != device:
+                # (a captured iteration reads this word: it is replaced only together with the kept graph, whose key holds
+                # its address)
+                self._buffers.pop("graph_loop", None)
                 self._call_word = torch.zeros(1, dtype=torch.int32, device=device)
             kernels.index_set(self._call_word, self._call_counter)
             self._call_counter += 1
@@ -210,6 +223,22 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
     _lattice_parameters_update_predictor_step = _lattice_parameters_update           # (:492-534)
     _lattice_parameters_update_corrector_step = _lattice_parameters_update
 
+    @staticmethod
+    def _shared_matrix(m: torch.Tensor, name: str) -> torch.Tensor:
+        """The one [C, C] matrix behind the reference's [number_of_samples, number_of_atoms, C, C] operand.  An expand() of one
+        matrix (what the sampler builds) is recognised by its strides; a materialised copy is compared entry by entry (one host
+        read, in this stand-alone method only); matrices that really differ per sample or atom are refused, not ignored."""
+        from ..utils.d3pm_utils import _one_matrix
+        one = _one_matrix(m)
+        if one is None:
+            flat = m.reshape(-1, m.shape[-2], m.shape[-1])
+            one = flat[0]
+            if not bool((flat == one).all()):
+                raise MdxError(f"{name}: the transition matrices differ between samples / atoms; the sampler's atom-type update "
+                               "takes ONE time index per call (use utils.d3pm_utils.get_probability_at_previous_time_step for "
+                               "per-atom matrices)")
+        return one
+
     def _atom_types_update(self, predicted_logits: torch.Tensor, atom_types_i: torch.LongTensor, q_matrices_i: torch.Tensor,
                            q_bar_matrices_i: torch.Tensor, q_bar_tm1_matrices_i: torch.Tensor,
                            atom_type_greedy_sampling: bool, one_atom_type_transition_per_step: bool) -> torch.LongTensor:
@@ -222,8 +251,9 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         u = None
         if atom_type_greedy_sampling:                           # drawn inside _adjust_..._for_greedy_sampling (:417)
             u = self._draw_binary_sample(batch).to(device=logits.device, dtype=torch.float32).contiguous()
-        q, q_bar, q_bar_tm1 = [m.reshape(-1, m.shape[-2], m.shape[-1])[0].to(logits).contiguous()
-                               for m in (q_matrices_i, q_bar_matrices_i, q_bar_tm1_matrices_i)]
+        q, q_bar, q_bar_tm1 = [self._shared_matrix(m, name).to(logits).contiguous()
+                               for m, name in ((q_matrices_i, "q_matrices_i"), (q_bar_matrices_i, "q_bar_matrices_i"),
+                                               (q_bar_tm1_matrices_i, "q_bar_tm1_matrices_i"))]
         a_in = atom_types_i.to(logits.device).contiguous()
         a_out, probs = kernels.atom_types_update(logits.contiguous(), a_in, q, q_bar, q_bar_tm1, gumbel, u, self.small_epsilon,
                                                  atom_type_greedy_sampling, one_atom_type_transition_per_step,
@@ -524,8 +554,9 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         settings = (self.number_of_corrector_steps, self.resampling_steps, self.atom_type_greedy_sampling,
                     self.one_atom_type_transition_per_step, self.atom_type_transition_in_corrector,
                     self.use_fixed_lattice_parameters, self.small_epsilon, self.num_classes)     # kernel arguments of the capture
+        words = tuple(None if w is None else w.data_ptr() for w in (self._call_word, self._status))   # read by the captured kernels
         return (tuple(start.X.shape), tuple(start.L.shape), str(start.X.device), getattr(net, "edge_chain_precision", None),
-                settings, tuple((p.data_ptr(), p._version) for p in net.parameters()))
+                settings, words, tuple((p.data_ptr(), p._version) for p in net.parameters()))
 
     def _sample_with_graph(self, start: AXL, starting_step_index: int, ending_step_index: int) -> AXL:
         """The iteration is captured ONCE per (shape, network state) and kept: later sample() calls copy their starting
@@ -550,21 +581,25 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
             return
         word = int(self._status.item())
         self._status.zero_()
+        net_status = getattr(self.axl_network, "graph_status", None)
+        if net_status is not None:
+            # The network's report comes FIRST: an activation beyond the f16 range gives non-finite logits, which can leave
+            # atoms MASKED -- that call must reach _guarded as an EdgeChainRangeError (and be recomputed), not as the
+            # "there must be a bug" assertion below.  Both words are read and zeroed before anything is raised, so a stale
+            # bit never leaks into the next call.
+            from ..utils.neighbors import _raise_if_cutoff_too_large
+            held = net_status.clone()
+            net_status.zero_()
+            _raise_if_cutoff_too_large(held)
         if word & STATUS_MASK_AT_LAST_STEP:
             # the reference asserts inside the last predictor step (langevin_generator.py:616-620)
             raise AssertionError("There remains MASKED atoms at the last time step: review code, there must be a "
                                  "bug or invalid input.")
-        net_status = getattr(self.axl_network, "graph_status", None)
-        if net_status is not None:
-            from ..utils.neighbors import _raise_if_cutoff_too_large
-            try:
-                _raise_if_cutoff_too_large(net_status)
-            finally:
-                net_status.zero_()
 
     def sample(self, number_of_samples: int, device: torch.device) -> AXL:
+        device = self._device(device)
         self._prepare(device)
-        self._begin_call(torch.device(device))
+        self._begin_call(device)
         composition = super().sample(number_of_samples, device)      # -> sample_from_noisy_composition (status read there)
         if self.rng_mode == "device":
             self.noise_source = None

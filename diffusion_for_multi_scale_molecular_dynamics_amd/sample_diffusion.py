@@ -7,7 +7,7 @@ Differences, all additive:
     network under the prefix `axl_network.`) together with the `model: score_network:` block of the config, or is
     randomly initialised with `--random_init_seed` (synthetic benchmarks);
   * under `torchrun` (one process per GPU) the sub-batches are sharded over the ranks and gathered once (RCCL);
-    rank 0 writes the files;
+    rank 0 writes the files (`trajectories.pt` holds every rank's recorded sub-batches, in sub-batch order);
   * LAMMPS energies (`oracle:`) and Orion reporting are outside the hot path and are not evaluated.
 """
 import argparse
@@ -55,7 +55,7 @@ def get_axl_network(checkpoint_path, hyper_params: Dict[AnyStr, Any]) -> ScoreNe
 
 
 def _init_distributed(device: torch.device):
-    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    if "RANK" not in os.environ:            # (under torchrun the group is set up at any world size, 1 included)
         return 0, 1, device
     import torch.distributed as dist
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -133,14 +133,38 @@ def create_samples_and_write_to_disk(generator, sampling_parameters, device, out
         logger.warning("%d sampling call(s) were recomputed with the exact-f32 MFMA kernels: the split-f16 edge chain met "
                        "values beyond the f16 range (set edge_chain_precision='f32' on the network to avoid the retries)",
                        fallbacks)
+    output_directory = Path(output_path)
+    if sampling_parameters.record_samples:
+        write_trajectories(generator.sample_trajectory_recorder, sampling_parameters, output_directory)
     if rank != 0:
         return
-    output_directory = Path(output_path)
     with open(output_directory / "samples.pt", "wb") as fd:
         torch.save(samples_batch, fd)
-    if sampling_parameters.record_samples:
-        generator.sample_trajectory_recorder.write_to_pickle(output_directory / "trajectories.pt")
     logger.info("Done!")
+
+
+def write_trajectories(recorder, sampling_parameters, output_directory: Path):
+    """`trajectories.pt` of the WHOLE run (src/sample_diffusion.py:253-257).  Under several ranks every rank has recorded its own
+    sub-batches: each writes `trajectories.rank{r}.pt` into the (shared, single-node) output directory, and after a barrier
+    rank 0 puts the entries back in sub-batch order -- the file a single process would have written -- and removes the
+    per-rank files.  No collective carries the records: they are T x (1 + M) compositions per sub-batch."""
+    import torch.distributed as dist
+    from .sampling.diffusion_sampling import split_sizes
+    from .utils.sample_trajectory import merge_sharded_entries
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        recorder.write_to_pickle(output_directory / "trajectories.pt")
+        return
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.save(recorder.entries(), output_directory / f"trajectories.rank{rank}.pt")
+    dist.barrier()
+    if rank == 0:
+        paths = [output_directory / f"trajectories.rank{r}.pt" for r in range(world)]
+        per_rank = [torch.load(path, weights_only=False) for path in paths]
+        sizes = split_sizes(sampling_parameters.number_of_samples, sampling_parameters.sample_batchsize)
+        merge_sharded_entries(per_rank, sizes, world).write_to_pickle(output_directory / "trajectories.pt")
+        for path in paths:
+            os.remove(path)
+    dist.barrier()
 
 
 if __name__ == "__main__":

@@ -12,8 +12,7 @@ import torch
 
 def global_means(a: torch.Tensor, b: torch.Tensor, across_ranks: bool) -> Tuple[torch.Tensor, torch.Tensor]:
     """(mean(a), mean(b)) over the local tensors, or over the concatenation of every rank's tensors."""
-    if not (across_ranks and torch.distributed.is_available() and torch.distributed.is_initialized()
-            and torch.distributed.get_world_size() > 1):
+    if not (across_ranks and torch.distributed.is_available() and torch.distributed.is_initialized()):
         return a.mean(), b.mean()
     packed = torch.stack([a.sum(dtype=torch.float64), b.sum(dtype=torch.float64),
                           torch.tensor(float(a.numel()), dtype=torch.float64, device=a.device),

@@ -61,9 +61,49 @@ class SampleTrajectory:
             torch.cuda.synchronize()          # the recorder's asynchronous device-to-host copies (PinnedStaging)
         data = dict(self._internal_data)
         for key, value in data.items():
-            if len(value) == 1:
+            if isinstance(value, list) and len(value) == 1:
                 data[key] = value[0]
         data = _compact(data)                 # views into the staging chunks -> tensors that own exactly their bytes
         self._internal_data = data
         with open(path_to_pickle, "wb") as fd:
             torch.save(data, fd)
+
+    def entries(self) -> Dict[str, list]:
+        """The recorded lists as they are (no unwrapping of single entries), owning their bytes: what one rank contributes
+        to the run's trajectory file."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        return _compact({key: list(value) if isinstance(value, list) else [value]
+                         for key, value in self._internal_data.items()})
+
+
+# keys that grow by a fixed number of entries per generator.sample() call (one sub-batch); everything else is a description
+# of the run, recorded once and equal on every rank
+PER_CALL_KEYS = ("predictor_step", "corrector_step", "atom_type_update")
+
+
+def merge_sharded_entries(per_rank: list, sizes: list, world_size: int) -> SampleTrajectory:
+    """One recorder for a run whose sub-batches were dealt round-robin to `world_size` ranks (sampling/diffusion_sampling.py):
+    the per-call entries of every rank, put back in SUB-BATCH order -- what a single process looping over the sub-batches
+    (the reference: src/.../sampling/diffusion_sampling.py:44-50 with src/.../sample_diffusion.py:253-257) would have recorded."""
+    merged = SampleTrajectory()
+    for key, value in per_rank[0].items():
+        if key not in PER_CALL_KEYS:
+            merged._internal_data[key] = list(value)
+    owners = [[k for k in range(len(sizes)) if k % world_size == r] for r in range(world_size)]
+    for key in PER_CALL_KEYS:
+        if not any(key in data for data in per_rank):
+            continue
+        chunks = {}
+        for r, data in enumerate(per_rank):
+            entries, calls = data.get(key, []), len(owners[r])
+            if calls == 0:
+                assert not entries
+                continue
+            assert len(entries) % calls == 0, f"rank {r}: {len(entries)} '{key}' entries for {calls} sample() calls"
+            per_call = len(entries) // calls
+            for c, k in enumerate(owners[r]):
+                chunks[k] = entries[c * per_call:(c + 1) * per_call]
+        for k in range(len(sizes)):
+            merged._internal_data[key].extend(chunks.get(k, []))
+    return merged

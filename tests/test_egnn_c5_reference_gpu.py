@@ -7,7 +7,8 @@ net_egnn_c5 / traj_egnn_c5_{top,bottom} (tests/golden/make_golden.py::golden_c5_
 computed there with K = 108 diamond sites pinned, T = 2000, M = 2, B = 2.  Held against them, in both arithmetic modes of the
 MFMA kernels:
 
-  * the network forward (scores <= 1e-5 rel-L2, logits close);
+  * the network forward (scores within max(1e-5, the reference's own binary32 noise floor at this size = 2.3e-5) rel-L2 AND at
+    least as close to the reference's binary64 evaluation as the reference's binary32 output is; logits close);
   * every predictor (+ repaint) and corrector step from the reference's recorded composition with the reference's draws: atom
     types exact, coordinates <= 1e-5 on the torus, the pinned rows of each predictor output BIT FOR BIT (the noised known atoms;
     at index 0 the un-noised sites: the i - 1 == 0 branch, :120-123);
@@ -42,13 +43,26 @@ def test_c5_network_forward_against_reference(cuda, precision):
         out = net(_batch(g, cuda), conditional=False)
     net.check_status()
     assert torch.isinf(out.A[..., -1]).all() and (out.A[..., -1] < 0).all()
-    ref = g["out_X"].astype(np.float64)
-    err = np.linalg.norm(out.X.cpu().numpy() - ref) / np.linalg.norm(ref)
-    assert err < 1e-5, f"{precision}: scores rel-L2 {err:.2e} against the reference at ~85 edges per atom"
+    err, exact, floor = _score_errors(out.X.cpu().numpy(), g)
+    assert err < max(1e-5, floor), f"{precision}: scores rel-L2 {err:.2e} against the reference at ~85 edges per atom"
+    assert exact < 1.05 * floor, f"{precision}: {exact:.2e} from the exact evaluation (the reference itself: {floor:.2e})"
     np.testing.assert_allclose(out.A.cpu().numpy()[..., :-1], g["out_A"][..., :-1], rtol=1e-4, atol=1e-5)
     if precision is not None:
         assert all(layer._chain[1] is not None and layer._chain[1].precision == precision
                    for layer in net.egnn.graph_layers)
+
+
+def _score_errors(scores, g):
+    """(rel-L2 against the reference's binary32 output, against the reference's module evaluated in binary64, and the distance
+    between those two).  At N = 216 in a 16.5 A graph cell the reference's own binary32 output is 2.3e-5 from its binary64
+    evaluation (`out_X_fp64`, made by the reference in tests/golden/make_golden.py): the coordinate update x + trans of every
+    graph layer rounds at the magnitude of x while the score is the small difference, so two binary32 evaluations with
+    different summation orders cannot be held closer to each other than that floor (the product's own torch module on the CPU,
+    same op order as the reference, is 5.9e-6 from it; the exact-f32 MFMA path 1.4e-5).  The bar is therefore
+    max(1e-5, floor) against the reference AND no further from the exact answer than the reference itself is."""
+    ref32, ref64 = g["out_X"].astype(np.float64), g["out_X_fp64"].astype(np.float64)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))       # noqa: E731
+    return rel(scores.astype(np.float64), ref32), rel(scores.astype(np.float64), ref64), rel(ref32, ref64)
 
 
 def _constraint(P, g=None):
@@ -155,10 +169,9 @@ def test_c5_full_size_batch_properties(cuda, precision):
         return out
 
     full = forward(X, A, L, time, noise)
-    ref = g["out_X"].astype(np.float64)
-    got = full.X[where.to(cuda)].cpu().numpy()
-    err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
-    assert err < 1e-5, f"{precision}: the reference's structures inside a 256-structure batch: scores rel-L2 {err:.2e}"
+    err, exact, floor = _score_errors(full.X[where.to(cuda)].cpu().numpy(), g)
+    assert err < max(1e-5, floor), f"{precision}: the reference's structures inside a 256-structure batch: scores rel-L2 {err:.2e}"
+    assert exact < 1.05 * floor, f"{precision}: {exact:.2e} from the exact evaluation (the reference itself: {floor:.2e})"
     np.testing.assert_allclose(full.A[where.to(cuda)].cpu().numpy()[..., :-1], g["out_A"][..., :-1], rtol=1e-4, atol=1e-5)
     alone = forward(X[where], A[where], L[where], time[where], noise[where])
     assert float((alone.X - full.X[where.to(cuda)]).norm() / alone.X.norm()) < 1e-5

@@ -277,6 +277,25 @@ def test_captured_iteration_is_reused_across_sample_calls(cuda, name):
     assert not np.array_equal(outs[True][0].X, outs[True][1].X) and not np.array_equal(outs[True][1].X, outs[True][2].X)
 
 
+def test_captured_iteration_is_reused_with_an_unindexed_device(cuda):
+    """`--device cuda` (the CLI's default) hands the generator torch.device("cuda"), which does not compare equal to cuda:0: the
+    device is normalised once, so the tables, the status / call words and the captured iteration are kept across calls, and the
+    results equal those of the same calls with cuda:0."""
+    plain = torch.device("cuda")
+    outs = {}
+    for device in (plain, cuda):
+        gen, *_ = _build("traj_mlp_c3", cases.TRAJECTORIES, cuda, rng_mode="device", seed=43, use_hip_graph=True)
+        with torch.no_grad():
+            first = gen.sample(6, device)
+            loop, word, tables = gen._buffers["graph_loop"], gen._call_word, gen._scheduler
+            second = gen.sample(6, device)
+        assert gen._buffers["graph_loop"] is loop and gen._call_word is word and gen._scheduler is tables
+        outs[device] = (_np(first), _np(second))
+    for a, b in zip(outs[plain], outs[cuda]):
+        assert np.array_equal(a.A, b.A) and np.array_equal(a.X.view(np.int32), b.X.view(np.int32))
+    assert not np.array_equal(outs[plain][0].X, outs[plain][1].X)
+
+
 def test_graph_replay_repaint(cuda):
     P = _pkg()
     constraint = P["Constraint"](elements=["Si"], constrained_relative_coordinates=torch.rand(3, 3),

@@ -223,6 +223,42 @@ ma, mb = global_means(full_a[lo:hi], full_b[lo:hi], across_ranks=True)
 assert torch.allclose(ma, full_a.mean(), rtol=1e-6) and torch.allclose(mb, full_b.mean(), rtol=1e-6)
 la, lb = global_means(full_a[lo:hi], full_b[lo:hi], across_ranks=False)
 assert torch.equal(la, full_a[lo:hi].mean()) and torch.equal(lb, full_b[lo:hi].mean())
+# trajectories.pt of a sharded run == the file a single process writes (every rank's sub-batches, in sub-batch order)
+from pathlib import Path
+from diffusion_for_multi_scale_molecular_dynamics_amd.sample_diffusion import write_trajectories
+from diffusion_for_multi_scale_molecular_dynamics_amd.utils.sample_trajectory import SampleTrajectory
+
+class RecordingGenerator(DummyGenerator):
+    def __init__(self):
+        super().__init__()
+        self.sample_trajectory_recorder = SampleTrajectory()
+        self.sample_trajectory_recorder.record(key="noise_parameters", entry=dict(total_time_steps=3))
+    def sample(self, n, device):
+        out = super().sample(n, device)
+        for i in (3, 2, 1):
+            self.sample_trajectory_recorder.record(key="predictor_step", entry=dict(time_step_index=i, composition_i=out))
+            for m in range(2):
+                self.sample_trajectory_recorder.record(key="corrector_step", entry=dict(time_step_index=i - 1, composition_i=out))
+        return out
+
+sp = SimpleNamespace(number_of_samples=9, sample_batchsize=2, number_of_atoms=4, spatial_dimension=3, record_samples=True)
+out_dir = Path({out!r})
+gen = RecordingGenerator()
+create_batch_of_samples_sharded(gen, sp, torch.device("cpu"))
+write_trajectories(gen.sample_trajectory_recorder, sp, out_dir)
+if rank == 0:
+    single = RecordingGenerator()
+    create_batch_of_samples(single, sp, torch.device("cpu"))
+    single.sample_trajectory_recorder.write_to_pickle(out_dir / "single.pt")
+    got = torch.load(out_dir / "trajectories.pt", weights_only=False)
+    want = torch.load(out_dir / "single.pt", weights_only=False)
+    assert sorted(got) == sorted(want) and got["noise_parameters"] == want["noise_parameters"]
+    for key in ("predictor_step", "corrector_step"):
+        assert len(got[key]) == len(want[key]) == 5 * (3 if key == "predictor_step" else 6)
+        for a, b in zip(got[key], want[key]):
+            assert a["time_step_index"] == b["time_step_index"]
+            assert all(torch.equal(x, y) for x, y in zip(a["composition_i"], b["composition_i"]))
+    assert not list(out_dir.glob("trajectories.rank*.pt"))
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
@@ -230,7 +266,7 @@ print("rank", rank, "ok")
 
 def test_sharded_driver_gloo_world_size_2(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT))
+    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]

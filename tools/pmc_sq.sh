@@ -10,7 +10,7 @@ for GROUP in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_INSTS_SA
   i=$((i+1))
   OUT=$O/pmc_sq_$i
   rm -rf $OUT
-  rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d $OUT -- timeout -k 10 300 python3 $R/bench.py --workload C2 --no-cpu-baseline > $O/pmc_sq_$i.log 2>&1 || { echo "group $i failed: $GROUP" >> $O/pmc_sq_summary.txt; tail -3 $O/pmc_sq_$i.log >> $O/pmc_sq_summary.txt; continue; }
+  timeout -k 10 300 rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --workload C2 --no-cpu-baseline > $O/pmc_sq_$i.log 2>&1 || { echo "group $i failed: $GROUP" >> $O/pmc_sq_summary.txt; tail -3 $O/pmc_sq_$i.log >> $O/pmc_sq_summary.txt; continue; }
   F=$(find $OUT -name '*counter_collection.csv' | head -1)
   python3 - "$F" <<'PY' >> $O/pmc_sq_summary.txt
 import csv, sys, collections
