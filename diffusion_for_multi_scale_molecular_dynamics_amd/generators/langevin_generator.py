@@ -420,6 +420,7 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         self._prepare(starting_noisy_composition.X.device)
         if self.noise_source is None:
             self._begin_call(starting_noisy_composition.X.device)
+        self._share_noise_source()       # (a caller's own noise_source also serves the initialiser: the repaint step draws from it)
         return self._guarded(lambda: self._run_loop(starting_noisy_composition, starting_step_index, ending_step_index))
 
     def _guarded(self, run):
