@@ -56,6 +56,7 @@ typedef __attribute__((address_space(1))) const char gbl_c;
 constexpr int kWave = 64;
 constexpr int kWaves = 4;                 // wavefronts per workgroup = SIMDs per CU
 constexpr int kTileEdges = 32 * kWaves;   // edges per workgroup tile
+constexpr int kFastD = 6;                 // coordinate components per node with an unrolled tile top (the EGNN in three dimensions)
 constexpr int kRing = 4;                  // LDS ring slots for weight chunks: being read | readable next | two in flight
 constexpr int kScaleSlots = MDX_EGNN_CHAIN_MAX_LAYERS + 3;   // struct Scale per packed layer (+ the head / two projection layers)
 
@@ -100,14 +101,8 @@ __device__ __forceinline__ float silu_scaled(float z)
 
 // Split-f16: the carried activations are 2^kActExp u (see the header comment).  2^6: full 22 bits for |u| >= 2^-8, an
 // absolute floor of 2^-31 below that; the f16 range is left at |u| > 1023 (|SiLU| > 709), which the status word reports.
-// (-DMDX_CHAIN_NO_SCALE: timing experiment only -- the round-2 arithmetic: no scaling, four-instruction epilogue)
-#ifdef MDX_CHAIN_NO_SCALE
-constexpr bool kScaled = false;
-#else
-constexpr bool kScaled = true;
-#endif
 template <int PREC>
-constexpr int kActExp = PREC >= 1 && kScaled ? 6 : 0;
+constexpr int kActExp = PREC >= 1 ? 6 : 0;
 constexpr float pow2_const(int e) { float v = 1.0f; for (int i = 0; i < (e < 0 ? -e : e); ++i) v = e < 0 ? v * 0.5f : v * 2.0f; return v; }
 __device__ __forceinline__ float pow2_bits(int e) { return __builtin_bit_cast(float, (uint32_t)(127 + e) << 23); }   // |e| <= 126
 
@@ -183,17 +178,10 @@ __device__ __forceinline__ void put_pair(Act<H, 0>& a, int t, int r, float y0, f
 __device__ __forceinline__ void split_f16_pair(float y0, float y1, uint32_t& hi, uint32_t& lo)
 {
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(y0), "v"(y1));
-#ifdef MDX_CHAIN_MIXLO
-    // lo = f16(y - hi), each half written by one instruction: the difference is formed exactly (f16 operand x -1 + f32 operand)
-    // and rounded to f16 once -- the same value as rounding the exact binary32 difference -- three instructions per pair
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(y0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(y1));
-#else
     float l0, l1;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(y0));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(y1));
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(l0), "v"(l1));
-#endif
 }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int H>
@@ -334,22 +322,13 @@ struct Chain {
 #endif
     uint32_t issue_src;     // byte offset of (chunk, share) in the image   (SGPR; the image is a few megabytes)
     uint32_t issue_dst;     // LDS byte address of slot + share           (SGPR)
-#if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
-    unsigned long long dma_cycles = 0, dma_count = 0;
-#endif
 
     // A request is ordered against the compiler's own memory instructions ("memory"): the counted vmcnt waits of acquire_next
     // assume the message / piece-row stores and the requests are issued in program order.  (m0 is written and read inside
     // one statement: the compiler reserves it and keeps nothing in it across statements; naming it as a clobber only draws
-    // "clobber list contains reserved registers".)  -DMDX_CHAIN_NO_REQUEST_CLOBBER: the round-2 form, for timing.
-#ifdef MDX_CHAIN_NO_REQUEST_CLOBBER
-#define MDX_REQUEST_CLOBBER
-#else
-#define MDX_REQUEST_CLOBBER : "memory"
-#endif
+    // "clobber list contains reserved registers".)
     __device__ __forceinline__ void issue_piece(int i)
     {
-#if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 4))
         // Written as assembly ON PURPOSE.  The compiler's wait-count pass files the builtin (a FLAT-encoded instruction
         // with an LDS operand) as an access that may complete out of order on BOTH counters; with one always in flight,
         // every wait for a weight fragment became `s_waitcnt lgkmcnt(0)` -- the fragments just requested for the steps
@@ -361,11 +340,6 @@ struct Chain {
         // to BOTH the global and the LDS address (tools/dma_probe.hip): no vector instruction per request.
         const uint64_t src = (uint64_t)(uintptr_t)image + (uint64_t)(issue_src + (uint32_t)((i >> 2) * 4096));
         const uint32_t dst = issue_dst + (uint32_t)((i >> 2) * 4096);
-#if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
-        // issue cost of one request: shader clock before and behind it, summed per wavefront (read at the end of the kernel)
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
 #ifdef MDX_CHAIN_VERIFY
         {
             // debugging aid: the addresses a request is about to use against the plain formula; a mismatch is reported in the
@@ -384,23 +358,16 @@ struct Chain {
             // it enforces for its own instructions only.)
             if constexpr (GUARD)
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane16), "s"(src), "s"(dst),
-                             "n"((i & 3) * 1024) MDX_REQUEST_CLOBBER);
+                             "n"((i & 3) * 1024) : "memory");
             else
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lane16), "s"(src), "s"(dst),
-                             "n"((i & 3) * 1024) MDX_REQUEST_CLOBBER);
+                             "n"((i & 3) * 1024) : "memory");
         } else {
             // (the burst form of the exact-f32 chain: the per-lane address as a vector-register pair -- with eight scalar-base
             // requests in a row the row-chain instantiation at H = 256 spills 3.6 KB per lane)
             const uint64_t lane_src = src + lane16;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" ::"v"(lane_src), "s"(dst), "n"((i & 3) * 1024) MDX_REQUEST_CLOBBER);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" ::"v"(lane_src), "s"(dst), "n"((i & 3) * 1024) : "memory");
         }
-#endif
-#if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        dma_cycles += t1 - t0;
-        ++dma_count;
-#endif
 #endif
     }
     // the next chunk of the stream becomes the one being requested
@@ -418,11 +385,7 @@ struct Chain {
     // every edge tile: a value carried around the tile loop may be moved to vector registers again.
     __device__ __forceinline__ void scalar_addresses()
     {
-#if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 64)
-        const uint32_t src = (uint32_t)share;       // (timing experiment: every chunk from the first 32 KB of the image)
-#else
         const uint32_t src = (uint32_t)issue_id * (uint32_t)CHUNK + (uint32_t)share;
-#endif
         const uint32_t dst = (uint32_t)(uintptr_t)ring + (uint32_t)(issue_slot * CHUNK + share);
         if constexpr (!SPREAD) {
             // the burst form (exact-f32 chain) uses them at once, the source as part of a vector address: no assembly needed
@@ -487,9 +450,7 @@ struct Chain {
             else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         }
         MDX_STAMP(2);
-#if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 8))
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
         MDX_STAMP(3);
         begin_chunk();
@@ -539,10 +500,10 @@ __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const 
 {
     // split-f16: the accumulator is 2^(a+b) z (struct Scale): -z, then 2^b z / (1 + 2^-z) with the divisor pre-scaled
     auto act = [&](float A) -> float {
-        if constexpr (PREC == 0 || !kScaled) return silu_scaled(A);
+        if constexpr (PREC == 0) return silu_scaled(A);
         else return A * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(A * sc.neg_c), sc.k, sc.k));
     };
-    auto lin = [&](float A) -> float { return PREC == 0 || !kScaled ? A : A * sc.inv_a; };
+    auto lin = [&](float A) -> float { return PREC == 0 ? A : A * sc.inv_a; };
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         if (r < r0 || r >= r1) continue;
@@ -568,26 +529,9 @@ __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const 
 // sixteen as one k-step of 32 in both; the 32x32 shape: eight in each).
 // The six operations of a value -- 0: A from the accumulator, t = A c   1: e = 2^t   2: d = k + k e   3: r = 1 / d   4: y = A r
 // 5: split into the operand registers -- are dealt to the steps by kOpStep (step offset of each operation from the pair's
-// first step); MDX_CHAIN_EPI_STAGES picks the dealing (timing experiments; 3 = the form described above).
-#ifndef MDX_CHAIN_EPI_STAGES
-#define MDX_CHAIN_EPI_STAGES 3
-#endif
-#if MDX_CHAIN_EPI_STAGES == 3
+// first step).
 constexpr int kPairStart[8] = {0, 1, 3, 4, 6, 8, 9, 11};
 constexpr int kOpStep[6] = {0, 0, 1, 1, 1, 2};
-#elif MDX_CHAIN_EPI_STAGES == 4
-constexpr int kPairStart[8] = {0, 1, 3, 4, 6, 7, 9, 10};
-constexpr int kOpStep[6] = {0, 0, 1, 1, 2, 3};
-#elif MDX_CHAIN_EPI_STAGES == 5
-constexpr int kPairStart[8] = {0, 1, 2, 4, 5, 6, 8, 9};
-constexpr int kOpStep[6] = {0, 1, 2, 2, 3, 4};
-#elif MDX_CHAIN_EPI_STAGES == 6
-constexpr int kPairStart[8] = {0, 1, 2, 3, 4, 5, 6, 8};
-constexpr int kOpStep[6] = {0, 1, 2, 3, 4, 5};
-#elif MDX_CHAIN_EPI_STAGES == 44          // exp and rcp each alone in a step, their neighbours paired
-constexpr int kPairStart[8] = {0, 1, 3, 4, 6, 7, 9, 10};
-constexpr int kOpStep[6] = {0, 1, 2, 2, 3, 3};
-#endif
 template <int H>
 struct EpiloguePipe {
     float a[8][2], e[8][2];
@@ -609,19 +553,11 @@ struct EpiloguePipe {
                         a[j][i] = pend[2 * j + i];
                         e[j][i] = a[j][i] * sc.neg_c;
                     } else if (op == 1) {
-#if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 128)      // (timing only: a plain instruction in place of v_exp_f32)
-                        e[j][i] = __builtin_fmaf(e[j][i], 0.0f, 1.0f);
-#else
                         e[j][i] = __builtin_amdgcn_exp2f(e[j][i]);
-#endif
                     } else if (op == 2) {
                         e[j][i] = __builtin_fmaf(e[j][i], sc.k, sc.k);
                     } else if (op == 3) {
-#if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 256)      // (timing only: a plain instruction in place of v_rcp_f32)
-                        e[j][i] = __builtin_fmaf(e[j][i], 0.0f, 0.5f * sc.inv_a);
-#else
                         e[j][i] = __builtin_amdgcn_rcpf(e[j][i]);
-#endif
                     } else {
                         e[j][i] = linear ? a[j][i] * sc.inv_a : a[j][i] * e[j][i];
                     }
@@ -631,28 +567,30 @@ struct EpiloguePipe {
     }
 };
 
-// One step of the segmented scan over a DPP row of 16 lanes: x[r] += (the value D lanes down the row; 0 beyond the row's
-// first lane) * gate, gate = 1.0 where that lane belongs to this lane's piece, else 0.0.
+// One step of the segmented scan over a DPP row of 16 lanes, for the sixteen values of a tile slice: x[r] += (the value D lanes
+// down the row; 0 beyond the row's first lane) * gate, gate = 1.0 where that lane belongs to this lane's piece, else 0.0.
+// ONE instruction per value: v_fmac_f32 with the DPP row shift on its first source (bound_ctrl: a lane without a source in its
+// row reads 0).  Written as ONE assembly block per step: the compiler selects `update_dpp` + `fmaf` as v_mov_b32_dpp + a VOP3
+// v_fma_f32 (which cannot carry the modifier) -- 128 instead of 64 instructions per slice and step set -- and a DPP source
+// must not have been written by the vector ALU within the two preceding wait states, a hazard the compiler pads for its own
+// instructions only: the block opens with `s_nop 1` and reads, in each instruction, a register last written sixteen
+// instructions earlier (or before the block); no reload can come between them.  Registers 4 q .. 4 q + 3 take gate_a for even
+// q and gate_b for odd q (16x16 shape: the two edges of a lane; the 32x32 shapes pass the same gate twice).  Same arithmetic
+// as the two-instruction form: one fused multiply-add per value.
+#define MDX_FMAC_DPP(R, G) "v_fmac_f32_dpp %" #R ", %" #R ", %" #G " row_shr:%18 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 template <int D>
-__device__ __forceinline__ void segmented_step(float (&x)[16], float gate)
+__device__ __forceinline__ void segmented_step(float (&x)[16], float gate_a, float gate_b)
 {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float below = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[r]), 0x110 + D, 0xf, 0xf, true));
-        x[r] = __builtin_fmaf(below, gate, x[r]);
-    }
+    asm volatile("s_nop 1\n\t"
+                 MDX_FMAC_DPP(0, 16) MDX_FMAC_DPP(1, 16) MDX_FMAC_DPP(2, 16) MDX_FMAC_DPP(3, 16)
+                 MDX_FMAC_DPP(4, 17) MDX_FMAC_DPP(5, 17) MDX_FMAC_DPP(6, 17) MDX_FMAC_DPP(7, 17)
+                 MDX_FMAC_DPP(8, 16) MDX_FMAC_DPP(9, 16) MDX_FMAC_DPP(10, 16) MDX_FMAC_DPP(11, 16)
+                 MDX_FMAC_DPP(12, 17) MDX_FMAC_DPP(13, 17) MDX_FMAC_DPP(14, 17) MDX_FMAC_DPP(15, 17)
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
+                   "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])
+                 : "v"(gate_a), "v"(gate_b), "n"(D));
 }
-
-// The same with a gate per register (16x16 shape: the sixteen registers of a tile belong to two different edges).
-template <int D>
-__device__ __forceinline__ void segmented_step_gates(float (&x)[16], const float (&gate)[16])
-{
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float below = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[r]), 0x110 + D, 0xf, 0xf, true));
-        x[r] = __builtin_fmaf(below, gate[r], x[r]);
-    }
-}
+#undef MDX_FMAC_DPP
 
 // Raw accumulators of tile t parked in / taken from the sixteen registers that tile occupies in an operand set (MODE 3).
 template <int H>
@@ -739,10 +677,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     using L = Lay<PREC>;
     constexpr bool W16 = L::W16;
     constexpr int NS = L::NS;                                // edges (rows) per lane: 1 | 2 (16x16 shape)
-#ifndef MDX_CHAIN_PFD
-#define MDX_CHAIN_PFD 2
-#endif
-    constexpr int PFD = STEPS >= 2 * MDX_CHAIN_PFD ? MDX_CHAIN_PFD : 1;     // weight fragments are read from LDS this many steps ahead
+    constexpr int PFD = STEPS >= 4 ? 2 : 1;                  // weight fragments are read from LDS this many steps ahead
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
     // 32x32 shapes: the lane's edge is column lane & 31 and it holds the feature quads of half h = lane >> 5;
     // 16x16 shape: edges 16 cg + (lane & 15), cg = 0, 1, and the feature quads of quarter g = lane >> 4
@@ -775,11 +710,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     // XCD gathers at any moment belong to two or three structures (the edges are sorted by source) and stay in its L2
     // beside the 2.4-MB weight image; dealing tile b + k gridDim to workgroup b instead spreads every structure over all
     // eight L2s (6x the unique bytes fetched, PMC of round 2) and pushes the weight image out.
-#ifndef MDX_CHAIN_LINEAR_TILES
     const int n_xcd = gridDim.x >= 8 ? 8 : 1;
-#else
-    const int n_xcd = 1;
-#endif
     const int xcd = blockIdx.x % n_xcd, xcd_slot = blockIdx.x / n_xcd;
     const int xcd_wgs = (gridDim.x - xcd + n_xcd - 1) / n_xcd;               // workgroups on this XCD
     const int64_t xcd_tiles = (n_tiles + n_xcd - 1) / n_xcd;
@@ -902,44 +833,82 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         // float4 group q8 = 4 t + q of the lane's H / 2 values: registers 4 q .. 4 q + 3 of tile t = features
         // 32 t + fb(q) .. + 3 of edge es(q)  (struct Lay)
         if constexpr (!ROWS) {
+            // The top of a tile is a chain of dependent memory latencies with nothing else for the wavefront to do (one per
+            // SIMD): edge -> (src, dst) -> rows of the node table.  Everything that depends only on (src, dst) is therefore
+            // requested AT ONCE -- both edge slots' pairs as one 16-byte load each; then the first gather batches and every
+            // coordinate (the D <= kMaxD loads of a node unrolled, none under a branch) -- and waited for once.  The first form
+            // of this block walked the coordinates in a run-time loop with a full wait per component and handled the edge
+            // slots one after the other: fourteen latencies in a row per tile (ISA of round 3), ~4 % of the launch.
+            typedef int64_t i64x2 __attribute__((ext_vector_type(2)));
             float radial[NS];
             const float *ps[NS], *pd[NS];
+            int64_t src[NS], dst[NS];
 #pragma unroll
             for (int es = 0; es < NS; ++es) {
-                const int64_t src = p.edges[2 * e[es]], dst = p.edges[2 * e[es] + 1];
-                if (MODE == 2 && h == 0) seg_src[(W16 ? 16 * es : 0) + col] = (int)src;      // (node indices fit 31 bits: checked on the host)
-                float r2 = 0.0f;
-                for (int k = 0; k < p.D; ++k) {
-                    const float dlt = p.coord[src * p.D + k] - p.coord[dst * p.D + k];
-                    r2 += dlt * dlt;
-                }
-                radial[es] = r2;
-                ps[es] = p.node_proj + src * 2 * H;
-                pd[es] = p.node_proj + dst * 2 * H + H;
+                const i64x2 pair = *(const i64x2*)(p.edges + 2 * e[es]);
+                src[es] = pair[0];
+                dst[es] = pair[1];
+                ps[es] = p.node_proj + src[es] * 2 * H;
+                pd[es] = p.node_proj + dst[es] * 2 * H + H;
             }
             // first message layer, straight into B-operand registers.
             // The gathers are software-pipelined by hand: batches of QB float4 pairs, requested DEPTH batches before they are
             // used, with scheduling pins between "request" and "compute" (left to itself the compiler keeps six to ten of
             // the 64 loads in flight -- the operand sets fill the register file -- and the phase is a chain of L2 latencies:
             // 25 k cycles per tile against 7 k of arithmetic).
-            constexpr int NQ = H / 8, QB = NQ >= 8 ? 4 : NQ, NB = NQ / QB, DEPTH = 2;
+            constexpr int NQ = H / 8, QB = NQ >= 8 ? 4 : NQ, NB = NQ / QB, DEPTH = 4;
             f32x4 ga[NB][QB], gb[NB][QB];
             auto request = [&](int batch) {
 #pragma unroll
                 for (int k = 0; k < QB; ++k) {
                     const int q8 = batch * QB + k, es = L::es(q8 & 3), off = 32 * (q8 >> 2) + L::fb(q8 & 3, h);
-#if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 2)
-                    ga[batch][k] = f32x4{radial[es], 1.0f, 2.0f, radial[es]};
-                    gb[batch][k] = f32x4{0.5f, radial[es], 0.25f, 1.0f};
-                    (void)off;
-#else
                     ga[batch][k] = *(const f32x4*)(ps[es] + off);
                     gb[batch][k] = *(const f32x4*)(pd[es] + off);
-#endif
                 }
             };
 #pragma unroll
             for (int batch = 0; batch < DEPTH && batch < NB; ++batch) request(batch);
+            // the squared distance of the edge's end points: sum over k < D of (c_src[k] - c_dst[k])^2, in that order.  D = 6 (the
+            // EGNN's torus uplift of three dimensions) is the unrolled form: twelve loads per edge slot at immediate offsets
+            // from the two row pointers, all in flight together; any other D walks the components (a latency per component).
+            if (p.D == kFastD) {
+                float cs[NS][kFastD], cd[NS][kFastD];
+#pragma unroll
+                for (int es = 0; es < NS; ++es) {
+                    const float *rs = p.coord + src[es] * kFastD, *rd = p.coord + dst[es] * kFastD;
+#pragma unroll
+                    for (int k = 0; k < kFastD; ++k) {
+                        cs[es][k] = rs[k];
+                        cd[es][k] = rd[k];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int es = 0; es < NS; ++es) {
+                    float r2 = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < kFastD; ++k) {
+                        const float dlt = cs[es][k] - cd[es][k];
+                        r2 += dlt * dlt;
+                    }
+                    radial[es] = r2;
+                }
+            } else {
+#pragma unroll
+                for (int es = 0; es < NS; ++es) {
+                    float r2 = 0.0f;
+                    for (int k = 0; k < p.D; ++k) {
+                        const float dlt = p.coord[src[es] * p.D + k] - p.coord[dst[es] * p.D + k];
+                        r2 += dlt * dlt;
+                    }
+                    radial[es] = r2;
+                }
+            }
+            if constexpr (MODE == 2) {
+#pragma unroll
+                for (int es = 0; es < NS; ++es)
+                    if (h == 0) seg_src[(W16 ? 16 * es : 0) + col] = (int)src[es];           // (node indices fit 31 bits: checked on the host)
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int batch = 0; batch < NB; ++batch) {
@@ -988,11 +957,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                             const Scale& epi_sc, bool linear = false) -> f32x16 {
             MDX_STAMP(4);
             f32x16 acc = acc_next;
-#ifndef MDX_CHAIN_NO_STAGED      // (-DMDX_CHAIN_NO_STAGED: the plain per-step epilogue everywhere, for A/B timing)
-            constexpr bool STAGED = SPLIT && kScaled && STEPS == 16;
-#else
-            constexpr bool STAGED = false;
-#endif
+            constexpr bool STAGED = SPLIT && STEPS == 16;
             EpiloguePipe<H> pipe;
             Frag fr[STEPS + PFD];
 #pragma unroll
@@ -1001,14 +966,9 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 if (s == STEPS / 2) w_next = ch.acquire_next();
-#if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 32)
-                fr[s + PFD] = fr[s];
-#else
                 if (s + PFD < STEPS) fr[s + PFD] = read_frag(w_cur, s + PFD);
                 else fr[s + PFD] = read_frag(w_next, s + PFD - STEPS);
-#endif
                 if (s == STEPS - 1) acc_next = read_bias(next_bias);
-#if !(defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 16))
                 if constexpr (STAGED) {
                     if (have) pipe.template step<PREC>(s, tp, pend, epi_dst, epi_sc, ROWS && linear);
                 } else if constexpr (W16) {
@@ -1019,9 +979,6 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 } else {
                     if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, epi_sc, ROWS && linear);
                 }
-#else
-                if (have && s == 0) asm volatile("" ::"v"(pend));      // keep the MFMAs alive without their epilogue
-#endif
                 // one weight-stream request per STEPS / LPW k-steps, behind the step's first MFMA; g = steps since the acquire
                 constexpr int PERIOD = STEPS / C::LPW;
                 const int g = (s + STEPS - STEPS / 2) % STEPS;
@@ -1037,35 +994,13 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     const int ks = s >> 1, rho = s & 1;
                     f32x4 a0 = {acc[8 * rho], acc[8 * rho + 1], acc[8 * rho + 2], acc[8 * rho + 3]};
                     f32x4 a1 = {acc[8 * rho + 4], acc[8 * rho + 5], acc[8 * rho + 6], acc[8 * rho + 7]};
-#ifndef MDX_CHAIN_DMA_POS
-#define MDX_CHAIN_DMA_POS 1          // (timing experiments: the request behind the step's 1st / 3rd / 6th MFMA)
-#endif
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.hi[0][ks], a0, 0, 0, 0);
-                    if (MDX_CHAIN_DMA_POS == 1 && C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
+                    if (C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.hi[1][ks], a1, 0, 0, 0);
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.lo[0][ks], a0, 0, 0, 0);
-                    if (MDX_CHAIN_DMA_POS == 3 && C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].hi, in.lo[1][ks], a1, 0, 0, 0);
-#ifdef MDX_CHAIN_DUMMY_VALU      // (calibration: MDX_CHAIN_DUMMY_VALU more independent vector instructions per k-step)
-#pragma unroll
-                    for (int dv = 0; dv < MDX_CHAIN_DUMMY_VALU + 0; ++dv) { float dummy_; asm volatile("v_mov_b32 %0, 0" : "=v"(dummy_)); }
-#endif
-#ifdef MDX_CHAIN_DUMMY_READS     // (the same with instructions that READ two / three live vector registers: operand-port contention?)
-#pragma unroll
-                    for (int dv = 0; dv < MDX_CHAIN_DUMMY_READS % 100; ++dv) {
-                        float dummy_;
-                        const f32x4 lv_ = __builtin_bit_cast(f32x4, in.hi[0][(ks + dv) % (H / 32)]);
-                        if (MDX_CHAIN_DUMMY_READS >= 100) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(dummy_) : "v"(lv_[0]), "v"(lv_[1]), "v"(lv_[2]));
-                        else asm volatile("v_add_f32 %0, %1, %2" : "=v"(dummy_) : "v"(lv_[0]), "v"(lv_[1]));
-                    }
-#endif
-#ifdef MDX_CHAIN_DUMMY_TRANS     // (the same with a transcendental)
-#pragma unroll
-                    for (int dv = 0; dv < MDX_CHAIN_DUMMY_TRANS + 0; ++dv) { float dummy_; asm volatile("v_exp_f32 %0, 1.0" : "=v"(dummy_)); }
-#endif
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].lo, in.hi[0][ks], a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[s].lo, in.hi[1][ks], a1, 0, 0, 0);
-                    if (MDX_CHAIN_DMA_POS == 6 && C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         acc[8 * rho + i] = a0[i];
@@ -1075,42 +1010,17 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].hi, in.hi[s], acc, 0, 0, 0);
                     if (C::SPREAD && g % PERIOD == 0) ch.issue_piece(g / PERIOD);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].hi, in.lo[s], acc, 0, 0, 0);
-#ifdef MDX_CHAIN_DUMMY_VALU      // (calibration experiment: what one more independent vector instruction per k-step costs)
-                    { float dummy_; asm volatile("v_mov_b32 %0, 0" : "=v"(dummy_)); }
-#endif
-#ifdef MDX_CHAIN_DUMMY_SNOP      // (the same for an instruction that only takes an issue slot)
-                    asm volatile("s_nop 0");
-#endif
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s].lo, in.hi[s], acc, 0, 0, 0);
                 }
-#ifdef MDX_CHAIN_PIN_STEPS
-                __builtin_amdgcn_sched_barrier(0);      // keep each k-step's share of vector work beside ITS MFMAs
-#elif !defined(MDX_CHAIN_STAGED_UNPINNED)
                 if constexpr (STAGED) __builtin_amdgcn_sched_barrier(0);
-#endif
             }
 #pragma unroll
             for (int s = 0; s < PFD; ++s) pre[s] = fr[STEPS + s];
             w_cur = w_next;
-#ifdef MDX_CHAIN_GROUPS
-            // The interleave of the tile's scheduling region, stated: per MFMA, MDX_CHAIN_GROUPS vector instructions (and a
-            // fragment read behind two MFMAs of three).  Left to itself the scheduler issues the first half of a tile's
-            // MFMAs bare and packs the whole epilogue beside the second half, which is then bound by vector issue.
-            if constexpr (PREC == 1) {
-#pragma unroll
-                for (int i = 0; i < 3 * STEPS; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, MDX_CHAIN_GROUPS, 0);
-                    if (i % 3 != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            }
-#endif
-#ifndef MDX_CHAIN_NO_TILE_PIN
             // keep every tile's share of vector work beside ITS MFMAs: left free, the scheduler sinks the epilogues of the
             // first tiles of a layer into its last ones (their results are not needed before the next layer), which then
             // carry twice the vector work and are bound by instruction issue
             __builtin_amdgcn_sched_barrier(0);
-#endif
             asm volatile("; MDX_TILE_END" ::);          // (a comment in the assembly: what tools/tile_stats.py cuts the listing at)
             return acc;
         };
@@ -1135,9 +1045,6 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         };
         // messages = the operand registers of the first coordinate layer, complete once its first tile has run
         auto store_messages = [&](const Act<H, PREC>& m) {
-#if defined(MDX_CHAIN_ABLATE) && (MDX_CHAIN_ABLATE & 1)
-            if (e_raw[0] >= 0) return;
-#endif
             // every wavefront issues exactly H / 8 store instructions (lanes beyond the edge count masked off, the address
             // clamped; an edge slot without a live lane issues none): the next chunk wait counts on them (Chain::stores_count)
 #pragma unroll
@@ -1196,24 +1103,11 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #pragma unroll
                     for (int i = 0; i < 4; ++i) x[4 * q + i] = y[i] * kOut;
                 }
-                if constexpr (NS == 1) {
-                    segmented_step<1>(x, gate[0][0]);
-                    segmented_step<2>(x, gate[0][1]);
-                    segmented_step<4>(x, gate[0][2]);
-                    segmented_step<8>(x, gate[0][3]);
-                } else {
-                    // (registers 4 q .. 4 q + 3 belong to edge es(q) = q & 1: the gates of that edge)
-                    float g2[16];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) g2[r] = gate[L::es(r >> 2)][k];
-                        if (k == 0) segmented_step_gates<1>(x, g2);
-                        else if (k == 1) segmented_step_gates<2>(x, g2);
-                        else if (k == 2) segmented_step_gates<4>(x, g2);
-                        else segmented_step_gates<8>(x, g2);
-                    }
-                }
+                // (registers 4 q .. 4 q + 3 belong to edge es(q): q & 1 on the 16x16 shape, the lane's one edge otherwise)
+                segmented_step<1>(x, gate[0][0], gate[NS - 1][0]);
+                segmented_step<2>(x, gate[0][1], gate[NS - 1][1]);
+                segmented_step<4>(x, gate[0][2], gate[NS - 1][2]);
+                segmented_step<8>(x, gate[0][3], gate[NS - 1][3]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     // (split-f16: no range check here -- a message beyond the f16 range is an infinity or a NaN in
@@ -1392,10 +1286,6 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MDX_STAMP_ALWAYS(22);
     MDX_STAMP_REALTIME(23);
-#if defined(MDX_CHAIN_STAMPS) && MDX_CHAIN_STAMPS == 3
-    MDX_STAMP_WRITE(24, ch.dma_cycles);
-    MDX_STAMP_WRITE(25, ch.dma_count);
-#endif
     if constexpr (SPLIT) {
         if (p.status && out_of_range) atomicOr(p.status, MDX_STATUS_EGNN_F16_RANGE);
     }
@@ -1438,7 +1328,7 @@ __global__ void egnn_chain_exponents_kernel(PackArgs p)
     for (int l = 0; l <= p.layers; ++l) {
         const uint32_t b = ((const uint32_t*)p.exps)[l];
         int a = 0;
-        if (b && kScaled) {
+        if (b) {
             const int e = (int)(b >> 23) - 127;     // floor(log2 m) for a normal m; subnormal maxima: treated as 2^-126
             a = 13 - (e < -126 ? -126 : e);
             a = a > 40 ? 40 : (a < -40 ? -40 : a);
@@ -1487,12 +1377,7 @@ __global__ __launch_bounds__(256) void egnn_chain_pack_kernel(PackArgs p)
                                            : 32 * (s >> 1) + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
             const float v = weight(n, k) * pow2_bits(p.exps[l]);      // exact (a power of two; |v| < 2^14)
             const _Float16 hi = (_Float16)v;
-#ifdef MDX_CHAIN_LO_MASK         // (timing experiment: the low MDX_CHAIN_LO_MASK bits of the weight image's lo halves cleared)
-            const _Float16 lo = __builtin_bit_cast(_Float16, (uint16_t)(__builtin_bit_cast(uint16_t, (_Float16)(v - (float)hi)) &
-                                                                          (uint16_t)~((1u << MDX_CHAIN_LO_MASK) - 1u)));
-#else
             const _Float16 lo = (_Float16)(v - (float)hi);
-#endif
             _Float16* chunk = (_Float16*)((char*)p.image + ((int64_t)l * (H / 32) + t) * ((int64_t)H * 32 * 4));
             chunk[s * 1024 + lane * 8 + j] = hi;
             chunk[s * 1024 + 512 + lane * 8 + j] = lo;
@@ -1644,9 +1529,6 @@ int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
     int64_t tiles = (a.n_edges + kTileEdges - 1) / kTileEdges;
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-#ifdef MDX_CHAIN_MAX_GRID
-    cus = MDX_CHAIN_MAX_GRID;          // (experiment: fewer CUs share the L2s)
-#endif
     const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);       // persistent: one workgroup per CU
     hipLaunchKernelGGL((egnn_edge_chain_kernel<H, PREC, MODE>), dim3(grid), dim3(kWaves * kWave), lds, st, a);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;

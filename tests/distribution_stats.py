@@ -58,6 +58,7 @@ def ks_two_sample(a, b):
 def ks_to_table(values, table):
     """sup |F_values - F_table|, F_table = the piecewise-linear CDF through the quantile table's knots."""
     v = np.sort(np.asarray(values, np.float64))
+    table = np.asarray(table, np.float64)
     p = np.linspace(0.0, 1.0, table.size)
     # strictly increasing knots for the interpolation (ties in the table: keep the last probability at a repeated value)
     keep = np.concatenate([table[1:] > table[:-1], [True]])

@@ -60,14 +60,15 @@ def run(make, seeds, batch, per_atom, name, probes, extra=None):
     out = {"seeds": np.array(seeds), "batch": np.array(batch), "scalars": np.array(keys)}
     for key in keys:
         pool = np.concatenate([s[key] for s in per_seed])
-        out[f"table/{key}"] = DS.quantile_table(pool)
+        # (2049 knots for the pooled scalars, 513 for the per-atom marginals, whose samples are B values per seed; binary32)
+        out[f"table/{key}"] = DS.quantile_table(pool, knots=513 if key.startswith("atom") else 2049).astype(np.float32)
         # calibration: every seed against the pool of the OTHER seeds, and every pair of seeds
         out[f"leave_one_out/{key}"] = np.array([DS.ks_two_sample(s[key], np.concatenate(
             [t[key] for j, t in enumerate(per_seed) if j != i])) for i, s in enumerate(per_seed)])
         out[f"pairwise/{key}"] = np.array([DS.ks_two_sample(per_seed[i][key], per_seed[j][key])
                                            for i in range(len(seeds)) for j in range(i + 1, len(seeds))])
         # the table's own resolution: a seed against the table vs against the exact pool (all seeds)
-        out[f"seed_vs_table/{key}"] = np.array([DS.ks_to_table(s[key], out[f"table/{key}"]) for s in per_seed])
+        out[f"seed_vs_table/{key}"] = np.array([DS.ks_to_table(s[key], out[f"table/{key}"].astype(np.float64)) for s in per_seed])
         # pooled halves against each other (20 random splits of the seeds): what two POOLED samples of the same
         # distribution look like -- the calibration for a pooled sample of the product against the table
         rng = np.random.default_rng(2024)
@@ -85,7 +86,7 @@ def run(make, seeds, batch, per_atom, name, probes, extra=None):
             axl = gen.sample(batch, torch.device("cpu"))
         stats = DS.statistics(axl.X.numpy(), per_atom=per_atom)
         for key in keys:
-            out[f"probe/{probe}/{key}"] = np.array(DS.ks_to_table(stats[key], out[f"table/{key}"]))
+            out[f"probe/{probe}/{key}"] = np.array(DS.ks_to_table(stats[key], out[f"table/{key}"].astype(np.float64)))
         print(f"{name}: probe {probe}: " + ", ".join(f"{k} {float(out[f'probe/{probe}/{k}']):.3f}" for k in keys[:5]), flush=True)
     for key in keys[:5]:
         print(f"{name}: {key}: leave-one-out {out[f'leave_one_out/{key}'].round(4)}  pairwise max {out[f'pairwise/{key}'].max():.4f}")

@@ -69,3 +69,30 @@ def oracle_edge_builder(relative_coordinates, unit_cell, radial_cutoff):
     dev = relative_coordinates.device
     return (torch.from_numpy(np.stack([r["src"], r["dst"]], 1)).to(dev),
             torch.from_numpy(r["counts"].reshape(-1)).to(dev))
+
+
+class ScaledScore(torch.nn.Module):
+    """A plugin around a score network: the coordinate score times a factor (tests/golden/make_distributions.py wraps the
+    reference's EGNN the same way, so that the distribution the sampler ends in depends on the score).  What the generators look
+    for on a network -- the status word of its HIP kernels, the arithmetic of its MFMA kernels -- is passed through, as
+    ForceFieldAugmentedScoreNetwork does."""
+
+    def __init__(self, net, factor):
+        super().__init__()
+        self.net, self.factor = net, float(factor)
+
+    @property
+    def graph_status(self):
+        return getattr(self.net, "graph_status", None)
+
+    @property
+    def edge_chain_precision(self):
+        return getattr(self.net, "edge_chain_precision", None)
+
+    @edge_chain_precision.setter
+    def edge_chain_precision(self, value):
+        self.net.edge_chain_precision = value
+
+    def forward(self, batch, conditional=None):
+        out = self.net(batch, conditional)
+        return AXL(A=out.A, X=out.X * self.factor, L=out.L)

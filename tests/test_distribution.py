@@ -1,0 +1,182 @@
+"""Whole trajectories, held to the reference DISTRIBUTIONALLY.
+
+Bit parity over a whole job is impossible between any two implementations (the MLP template's map is
+chaotic, the radial cutoff makes the EGNN discontinuous), and the mode `value` is measured in -- device Philox, hardware exp2 /
+sin / cos in the persistent MLP kernel, split-f16 MFMA products and a hipGraph loop for the EGNN -- is pinned to the oracle over
+4 .. 24 iterations only.  The missing link is statistical: do complete jobs in that mode sample the distribution the REFERENCE
+samples?  The reference's own measure for that question is the two-sample Kolmogorov-Smirnov distance
+(src/.../metrics/kolmogorov_smirnov_metrics.py:7-75).
+
+tests/golden/dist_mlp_c2.npz / dist_egnn_rc.npz (tests/golden/make_distributions.py, reference runs in the build container)
+hold, per scalar of tests/distribution_stats.py, the quantile table of the reference's pooled final structures, the
+reference-vs-reference KS distances (every seed against the pool of the others; pooled halves against each other) and the KS
+distance of deliberately WRONG samplers (score zeroed or scaled, correctors dropped) to the pool.  A sampler passes when
+
+  * every one of its calls (the reference's batch per seed) is within MARGIN x the largest leave-one-out distance of the
+    reference's own seeds, for every scalar;
+  * its pooled sample is within MARGIN x the largest pooled-halves distance;
+  * (networks that are not permutation equivariant) the same for the per-atom coordinate marginals: the largest and the mean
+    over the 3 N marginals against the reference's largest and largest-mean;
+  * no atom is left MASKED.
+
+CPU part: the fixtures themselves (the wrong samplers FAIL the criterion: the check has teeth) and the CPU oracle in its Philox
+mode on the MLP job.  GPU part (-m gpu): the product's fast paths.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import distribution_stats as DS
+import nets
+from conftest import load_golden
+from oracle import reference_sampler as RS
+
+MARGIN = 1.5          # x the reference's own largest seed-to-seed distance (16 / 6 seeds: the largest of a few draws)
+POOLED = ("pair", "nn", "x", "y", "z")
+
+
+def thresholds(g):
+    """Per scalar: (limit for one call, limit for the pooled sample); per-atom marginals: (limit of the largest, of the mean)."""
+    scalars = [str(k) for k in g["scalars"]]
+    atoms = [k for k in scalars if k.startswith("atom")]
+    lim = {k: (MARGIN * g[f"leave_one_out/{k}"].max(), MARGIN * g[f"half_split/{k}"].max()) for k in POOLED}
+    if atoms:
+        loo = np.stack([g[f"leave_one_out/{k}"] for k in atoms])          # [marginals, seeds]
+        lim["atoms"] = (MARGIN * loo.max(), MARGIN * loo.mean(0).max())
+    return lim, atoms
+
+
+def judge(g, calls):
+    """calls: list of X [B, N, 3] (one per sample() call).  Returns the list of violated criteria (empty = passes)."""
+    lim, atoms = thresholds(g)
+    table = {k: g[f"table/{k}"] for k in list(POOLED) + atoms}
+    failures = []
+    per_call = [DS.statistics(x, per_atom=bool(atoms)) for x in calls]
+    for c, st in enumerate(per_call):
+        for k in POOLED:
+            d = DS.ks_to_table(st[k], table[k])
+            if d > lim[k][0]:
+                failures.append(f"call {c}: {k} {d:.4f} > {lim[k][0]:.4f}")
+        if atoms:
+            d = np.array([DS.ks_to_table(st[k], table[k]) for k in atoms])
+            if d.max() > lim["atoms"][0]:
+                failures.append(f"call {c}: largest per-atom marginal {d.max():.4f} > {lim['atoms'][0]:.4f}")
+            if d.mean() > lim["atoms"][1]:
+                failures.append(f"call {c}: mean per-atom marginal {d.mean():.4f} > {lim['atoms'][1]:.4f}")
+    if len(calls) > 1:
+        for k in POOLED:
+            d = DS.ks_to_table(np.concatenate([st[k] for st in per_call]), table[k])
+            if d > lim[k][1]:
+                failures.append(f"pooled: {k} {d:.4f} > {lim[k][1]:.4f}")
+    return failures
+
+
+def probe_fails(g, probe):
+    """Would the recorded wrong sampler `probe` (one call) have failed the per-call criterion?"""
+    lim, atoms = thresholds(g)
+    bad = any(float(g[f"probe/{probe}/{k}"]) > lim[k][0] for k in POOLED)
+    if atoms:
+        d = np.array([float(g[f"probe/{probe}/{k}"]) for k in atoms])
+        bad = bad or d.max() > lim["atoms"][0] or d.mean() > lim["atoms"][1]
+    return bad
+
+
+@pytest.mark.parametrize("fixture,caught,missed", [
+    ("dist_mlp_c2.npz", ["zero_score", "no_corrector"], ["score_x0.9", "sigma_max_0.2"]),
+    ("dist_egnn_rc.npz", ["zero_score", "score_x0.5", "no_corrector"], [])])
+def test_the_criterion_has_teeth(fixture, caught, missed):
+    """The reference's own wrong samplers against the criterion: a zeroed score, a halved score and a run without correctors
+    are rejected; what the criterion cannot see at this sample size is listed too (a 10 % error of the MLP's score, a 20 %
+    smaller sigma_max: inside the seed-to-seed spread of 1024 structures) -- the check guards against gross errors of the fast
+    mode, not against percent-level ones.  And the tables' own resolution is fine: a seed against the table is no further than
+    against the exact pool of the other seeds."""
+    g = load_golden(fixture)
+    for probe in caught:
+        assert probe_fails(g, probe), probe
+    for probe in missed:
+        assert not probe_fails(g, probe), probe
+    for k in POOLED:
+        assert g[f"seed_vs_table/{k}"].max() <= g[f"leave_one_out/{k}"].max() * 1.05 + 1.0 / 2048
+
+
+def mlp_c2_parameters():
+    noise_kw = cases.noise_ns(1000, sigma_min=1e-4, sigma_max=0.25)
+    return noise_kw, cases.sampling_ns(8, 1)
+
+
+def test_oracle_philox_mode_samples_the_reference_distribution(oracle):
+    """The CPU oracle with the DEVICE random-number specification (Philox) on BASELINE configs[1]'s whole job (MLP template,
+    T = 1000, 1024 structures): same distribution as the reference's torch-CPU draws."""
+    g = load_golden("dist_mlp_c2.npz")
+    noise_kw, sampling_kw = mlp_c2_parameters()
+    npar, spar = cases.as_objects(noise_kw, sampling_kw)
+    net = nets.load_fixture_weights(nets.mlp_net(8, 1), load_golden("net_mlp_c1.npz"))
+    torch.set_num_threads(8)
+    out = RS.OracleLangevinGenerator(npar, spar, net, noise=RS.PhiloxNoise(515, 0)).sample(int(g["batch"]))
+    assert (out.A == 0).all()
+    assert judge(g, [out.X]) == []
+
+
+@pytest.mark.gpu
+def test_fused_mlp_sampler_samples_the_reference_distribution(cuda):
+    """BASELINE configs[1] in the mode bench.py's C2 `value` is measured in: the persistent fused kernel (one launch per
+    trajectory, pre-drawn device Philox noise, hardware exp2 / sin / cos), 16 calls of 1024 structures."""
+    from test_generator_gpu import _pkg
+    import warnings
+    P = _pkg()
+    g = load_golden("dist_mlp_c2.npz")
+    noise_kw, sampling_kw = mlp_c2_parameters()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = P["Noise"](**noise_kw)
+        spar = P["Sampling"](**sampling_kw, rng_mode="device", seed=9090, fused_score_network=True)
+    net = nets.load_fixture_weights(nets.mlp_net(8, 1), load_golden("net_mlp_c1.npz")).to(cuda)
+    gen = P["Langevin"](npar, spar, net)
+    calls = []
+    with torch.no_grad():
+        for _ in range(len(g["seeds"])):
+            out = gen.sample(int(g["batch"]), cuda)
+            assert (out.A == 0).all()
+            calls.append(out.X.cpu().numpy())
+    assert judge(g, calls) == []
+    # and the per-step path with the PyTorch forward in a hipGraph (the plugin path), fewer calls
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        spar = P["Sampling"](**sampling_kw, rng_mode="device", seed=9191, use_hip_graph=True)
+    gen = P["Langevin"](npar, spar, net)
+    with torch.no_grad():
+        calls = [gen.sample(int(g["batch"]), cuda).X.cpu().numpy() for _ in range(2)]
+    assert judge(g, calls) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_egnn_graph_loop_samples_the_reference_distribution(cuda, precision):
+    """A small radial-cutoff EGNN (hidden 32, N = 64, T = 100 of configs[2]'s schedule, M = 2) whose coordinate score is
+    multiplied by 100 (a plugin around the network, on both sides: with the bare random-init network the final distribution is
+    uniform whatever the sampler does), in the mode bench.py's C3 `value` is measured in: device Philox, HIP radius graph,
+    MFMA edge chain, the iteration replayed from a hipGraph; 6 calls of 64 structures."""
+    from test_generator_gpu import _pkg
+    import warnings
+    P = _pkg()
+    g = load_golden("dist_egnn_rc.npz")
+    noise_kw = cases.noise_ns(100, **cases.LIN)
+    sampling_kw = cases.sampling_ns(64, 1, M=2, one=False, greedy=False, cell=[10.86] * 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = P["Noise"](**noise_kw)
+        spar = P["Sampling"](**sampling_kw, rng_mode="device", seed=777, use_hip_graph=True)
+    inner = nets.load_fixture_weights(nets.egnn_net(1, "radial_cutoff", 7.5), load_golden("traj_egnn_rc.npz"))
+    net = nets.ScaledScore(inner, float(g["score_factor"])).to(cuda)
+    net.edge_chain_precision = precision
+    gen = P["Langevin"](npar, spar, net)
+    calls = []
+    with torch.no_grad():
+        for _ in range(len(g["seeds"])):
+            out = gen.sample(int(g["batch"]), cuda)
+            assert (out.A == 0).all()
+            calls.append(out.X.cpu().numpy())
+    assert gen.f16_range_fallbacks == 0
+    assert all(layer._chain[1] is not None and layer._chain[1].precision == precision for layer in inner.egnn.graph_layers)
+    assert judge(g, calls) == []

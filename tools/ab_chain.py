@@ -80,7 +80,8 @@ with torch.no_grad():
         for k in range(1, len(handles)):
             dm = (outs[k][1] - outs[0][1]).abs().max().item()
             rel = ((outs[k][1] - outs[0][1]).norm() / outs[0][1].norm()).item()
-            print(f"check {names[k]} vs {names[0]}: head max abs diff {dm:.3e}, rel-L2 {rel:.3e}")
+            same = [bool(torch.equal(outs[k][i], outs[0][i])) for i in range(2)]
+            print(f"check {names[k]} vs {names[0]}: head max abs diff {dm:.3e}, rel-L2 {rel:.3e}; bit-identical messages / head: {same}")
     del outs
     import time
     t0 = time.time()
