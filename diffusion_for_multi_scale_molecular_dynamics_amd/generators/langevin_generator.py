@@ -72,8 +72,8 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         self._seed = getattr(sp, "seed", None)
         self._call_counter = 0
         self.noise_source = ReferenceOrderNoise() if rng_mode == "reference" else None
-        # calls recomputed with the exact-f32 MFMA kernels because the split-f16 ones met a value beyond the f16 range
-        # (_guarded); logged by sample_diffusion, printed by bench.py
+        # ITERATIONS recomputed with the exact-f32 MFMA kernels because the split-f16 ones met a value beyond the f16 range
+        # (_guarded_iteration, IterationLoop._advance_watched); logged by sample_diffusion, printed by bench.py
         self.f16_range_fallbacks = 0
         self.resampling_steps = 0     # set by ConstrainedLangevinGenerator (repaint_resampling_steps)
         self._visit = 0               # which of the 1 + resampling_steps passes through the current time index
@@ -421,48 +421,80 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         if self.noise_source is None:
             self._begin_call(starting_noisy_composition.X.device)
         self._share_noise_source()       # (a caller's own noise_source also serves the initialiser: the repaint step draws from it)
-        return self._guarded(lambda: self._run_loop(starting_noisy_composition, starting_step_index, ending_step_index))
+        out = self._run_loop(starting_noisy_composition, starting_step_index, ending_step_index)
+        self.check_status()
+        return out
 
-    def _guarded(self, run):
-        """run() + check_status(); if the score network's split-f16 MFMA kernels report a value beyond the f16 range, THIS
-        call -- and nothing else -- is recomputed with the exact-f32 kernels on the same draws: the network's precision is
-        put back afterwards, what the discarded attempt recorded is dropped, the event is counted in
-        `f16_range_fallbacks` and warned about.  Device RNG: a draw is a function of (seed, call, index), the same call
-        index gives the same numbers.  Reference-order RNG: the call's draws are kept while it runs and handed out again."""
-        from .._hip import EdgeChainRangeError
-        net = self.axl_network
-        switchable = getattr(net, "edge_chain_precision", None) == "f16x3"
-        source = self.noise_source
-        keeps = switchable and not getattr(source, "device_rng", False)
+    # ---------------------------------------------------------------------------------------------------------
+    # the f16 range of the score network's split-f16 MFMA kernels, handled per ITERATION
+    # ---------------------------------------------------------------------------------------------------------
+    SPLIT_F16_MODES = ("f16x3", "f16x3_32x32")
+
+    def _range_guarded(self) -> bool:
+        """Does the score network run split-f16 kernels that can report a value beyond the f16 range?"""
+        return getattr(self.axl_network, "edge_chain_precision", None) in self.SPLIT_F16_MODES
+
+    def _take_range_report(self) -> bool:
+        """Read the network's status word (a host synchronisation) and clear the f16-range bit; other bits stay for
+        check_status()."""
+        from .._hip import STATUS_EGNN_F16_RANGE
+        status = getattr(self.axl_network, "graph_status", None)
+        if status is None:
+            return False
+        word = int(status.item())
+        if word & STATUS_EGNN_F16_RANGE:
+            status.bitwise_and_(~STATUS_EGNN_F16_RANGE)
+            return True
+        return False
+
+    def _count_fallback(self, index_i: int):
+        import warnings
+        self.f16_range_fallbacks += 1
+        warnings.warn(f"EGNN edge chain: a value beyond the f16 range at time index {index_i}; this iteration is recomputed with "
+                      "edge_chain_precision='f32' on the same draws (the network's setting is restored afterwards)")
+
+    def _iteration(self, composition: AXL, i: int, forces: torch.Tensor) -> AXL:
+        """Time index i + 1 -> i: predictor, M correctors, and the resampling passes of the repaint generator."""
+        visits = self._visits_at(i)
+        for self._visit in range(visits):
+            composition = self.predictor_step(composition, i + 1, forces)
+            for m in range(self.number_of_corrector_steps):
+                composition = self.corrector_step(composition, i, forces, m)
+            if self._visit < visits - 1:
+                composition = self._forward_step(composition, i)
+        self._visit = 0
+        return composition
+
+    def _guarded_iteration(self, composition: AXL, i: int, forces: torch.Tensor) -> AXL:
+        """_iteration(); if the score network's split-f16 kernels report a value beyond the f16 range, THAT iteration -- and
+        nothing else -- is recomputed from the same composition with the exact-f32 kernels on the same draws: the network's
+        precision is put back afterwards, what the discarded attempt recorded is dropped, the event is counted in
+        `f16_range_fallbacks` and warned about.  Device RNG: a draw is a function of (seed, call, index).  Reference-order RNG:
+        the iteration's draws are kept while it runs and handed out again (one iteration's worth, not the trajectory's)."""
+        if not self._range_guarded():
+            return self._iteration(composition, i, forces)
+        net, source = self.axl_network, self.noise_source
+        keeps = not getattr(source, "device_rng", False)
         if keeps:
             self.noise_source = RecordingNoise(source)
             self._share_noise_source()
         marks = self._recorder_marks() if self.record else None
         try:
+            out = self._iteration(composition, i, forces)
+            if not self._take_range_report():
+                return out
+            self._count_fallback(i)
+            if marks is not None:
+                self._recorder_truncate(marks)
+            if keeps:
+                self.noise_source = self.noise_source.replay()
+                self._share_noise_source()
+            precision = net.edge_chain_precision
+            net.edge_chain_precision = "f32"
             try:
-                out = run()
-                self.check_status()
-                return out
-            except EdgeChainRangeError:
-                if not switchable:
-                    raise
-                import warnings
-                self.f16_range_fallbacks += 1
-                warnings.warn("EGNN edge chain: a value beyond the f16 range; this call is recomputed with "
-                              "edge_chain_precision='f32' (the network's setting is restored afterwards)")
-                if marks is not None:
-                    self._recorder_truncate(marks)
-                self._buffers.pop("graph_loop", None)
-                if keeps:
-                    self.noise_source = self.noise_source.replay()
-                    self._share_noise_source()
-                net.edge_chain_precision = "f32"
-                try:
-                    out = run()
-                    self.check_status()
-                finally:
-                    net.edge_chain_precision = "f16x3"
-                return out
+                return self._iteration(composition, i, forces)
+            finally:
+                net.edge_chain_precision = precision
         finally:
             if keeps:
                 self.noise_source = source
@@ -490,14 +522,7 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         composition = starting_noisy_composition
         forces = torch.zeros_like(composition.X)
         for i in range(starting_step_index - 1, max(ending_step_index, 0) - 1, -1):
-            visits = self._visits_at(i)
-            for self._visit in range(visits):
-                composition = self.predictor_step(composition, i + 1, forces)
-                for m in range(self.number_of_corrector_steps):
-                    composition = self.corrector_step(composition, i, forces, m)
-                if self._visit < visits - 1:
-                    composition = self._forward_step(composition, i)
-            self._visit = 0
+            composition = self._guarded_iteration(composition, i, forces)
         return composition
 
     def _visits_at(self, index_i: int) -> int:
@@ -585,8 +610,8 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         net_status = getattr(self.axl_network, "graph_status", None)
         if net_status is not None:
             # The network's report comes FIRST: an activation beyond the f16 range gives non-finite logits, which can leave
-            # atoms MASKED -- that call must reach _guarded as an EdgeChainRangeError (and be recomputed), not as the
-            # "there must be a bug" assertion below.  Both words are read and zeroed before anything is raised, so a stale
+            # atoms MASKED -- a report that reaches this point (a caller stepping by hand: the loops handle it per iteration)
+            # must surface as an EdgeChainRangeError, not as the "there must be a bug" assertion below.  Both words are read and zeroed before anything is raised, so a stale
             # bit never leaks into the next call.
             from ..utils.neighbors import _raise_if_cutoff_too_large
             held = net_status.clone()
@@ -677,15 +702,85 @@ class IterationLoop:
         kernels.index_set(self.d_index, starting_step_index - 1)
         self.remaining = starting_step_index
 
-    def advance(self, iterations: int):
-        """Run `iterations` sampler iterations (asynchronously on the current stream)."""
-        assert iterations <= self.remaining, "cannot step past time index 0"
+    def _one(self, visits=None):
         gen = self.generator
+        if self.remaining == 1 and gen.resampling_steps > 0:     # time index 0: never resampled
+            gen._iteration_on_device_index(self.composition, self.forces, self.d_index, visits=1)
+        elif self.graph is not None and visits is None:
+            self.graph.replay()
+        else:
+            gen._iteration_on_device_index(self.composition, self.forces, self.d_index)
+        self.remaining -= 1
+
+    def advance(self, iterations: int):
+        """Run `iterations` sampler iterations on the current stream.  Asynchronous -- except when the score network runs
+        split-f16 kernels (see _advance_watched): then the call returns once the last iteration's range report has been read."""
+        assert iterations <= self.remaining, "cannot step past time index 0"
+        if self.generator._range_guarded():
+            return self._advance_watched(iterations)
         for _ in range(iterations):
-            if self.remaining == 1 and gen.resampling_steps > 0:     # time index 0: never resampled
-                gen._iteration_on_device_index(self.composition, self.forces, self.d_index, visits=1)
-            elif self.graph is not None:
-                self.graph.replay()
-            else:
-                gen._iteration_on_device_index(self.composition, self.forces, self.d_index)
-            self.remaining -= 1
+            self._one()
+
+    # The f16-range report of the score network, watched per iteration WITHOUT stalling the device: behind every iteration the
+    # network's status word is copied to page-locked memory (4 bytes, asynchronous) and an event is recorded; the host looks at
+    # the report of iteration k - LAG after it has queued iteration k, so the device always has work queued.  Before an
+    # iteration the composition is copied into a ring of LAG + 1 snapshots (three device copies of a few hundred kilobytes).
+    # When a report shows the range bit, the loop goes back to that iteration's snapshot, runs THAT iteration with the
+    # exact-f32 kernels (eagerly: the captured graph holds the split-f16 launches; the draws are functions of the time index,
+    # so they are the same) and continues with graph replays: one f32 iteration and at most LAG repeated ones per event
+    # instead of the whole call.
+    LAG = 2
+
+    def _watch_buffers(self):
+        if getattr(self, "_watch", None) is None:
+            comp, slots = self.composition, self.LAG + 1
+            self._watch = dict(
+                snapshots=[AXL(A=torch.empty_like(comp.A), X=torch.empty_like(comp.X), L=torch.empty_like(comp.L))
+                           for _ in range(slots)],
+                words=torch.zeros(slots, dtype=torch.int32).pin_memory(),
+                events=[torch.cuda.Event() for _ in range(slots)], remaining=[0] * slots)
+        return self._watch
+
+    def _advance_watched(self, iterations: int):
+        from .._hip import STATUS_EGNN_F16_RANGE
+        gen, w = self.generator, self._watch_buffers()
+        net, slots = gen.axl_network, self.LAG + 1
+        first = self.remaining                          # iteration k of this call starts with `first - k` indices remaining
+        k = checked = 0                                 # iterations queued / iterations whose report has been read
+        while checked < iterations:
+            if k < iterations and k - checked <= self.LAG:
+                slot = k % slots
+                for dst, src in zip(w["snapshots"][slot], self.composition):
+                    dst.copy_(src)
+                assert self.remaining == first - k
+                self._one()
+                status = getattr(net, "graph_status", None)      # (the network creates its status word in its first forward)
+                if status is None:
+                    w["words"][slot] = 0
+                else:
+                    w["words"][slot:slot + 1].copy_(status, non_blocking=True)
+                w["events"][slot].record()
+                k += 1
+                continue
+            slot = checked % slots
+            w["events"][slot].synchronize()
+            if not int(w["words"][slot]) & STATUS_EGNN_F16_RANGE:
+                checked += 1
+                continue
+            # iteration `checked` left the f16 range: everything queued behind it worked on its output -- drop it
+            torch.cuda.synchronize(self.composition.X.device)
+            for dst, src in zip(self.composition, w["snapshots"][slot]):
+                dst.copy_(src)
+            self.remaining = first - checked
+            kernels.index_set(self.d_index, self.remaining - 1)
+            status.bitwise_and_(~STATUS_EGNN_F16_RANGE)
+            gen._status.zero_()                         # (bits the dropped iterations may have raised)
+            gen._count_fallback(self.remaining - 1)
+            precision = net.edge_chain_precision
+            net.edge_chain_precision = "f32"
+            try:
+                self._one(visits=1 + gen.resampling_steps)      # eager launches of the same iteration, exact-f32 kernels
+            finally:
+                net.edge_chain_precision = precision
+            checked += 1
+            k = checked

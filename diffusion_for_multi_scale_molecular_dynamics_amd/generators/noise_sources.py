@@ -45,10 +45,12 @@ class DevicePhiloxNoise:
 
 
 class RecordingNoise(ReferenceOrderNoise):
-    """Reference-order draws passed through and KEPT, so that a call which has to be recomputed (the score network's
-    split-f16 kernels met a value beyond the f16 range: LangevinGenerator._guarded) sees the very same numbers again:
-    a CPU generator cannot be rewound, a list can.  replay() returns a source that hands the kept draws out again, in
-    order, and continues with `inner` once they are used up."""
+    """Reference-order draws passed through and KEPT, so that an ITERATION which has to be recomputed (the score network's
+    split-f16 kernels met a value beyond the f16 range: LangevinGenerator._guarded_iteration) sees the very same numbers
+    again: a CPU generator cannot be rewound, a list can -- and it works for any source a caller plugs in (a replayed fixture,
+    a generator of its own), which saving torch's global RNG state would not.  One iteration's draws are held at a time
+    ((1 + M) steps), not the trajectory's.  replay() returns a source that hands the kept draws out again, in order, and
+    continues with `inner` once they are used up."""
 
     def __init__(self, inner):
         self.inner = inner

@@ -130,7 +130,7 @@ def create_samples_and_write_to_disk(generator, sampling_parameters, device, out
     logger.info("Done Generating Samples.")
     fallbacks = getattr(generator, "f16_range_fallbacks", 0)
     if fallbacks:
-        logger.warning("%d sampling call(s) were recomputed with the exact-f32 MFMA kernels: the split-f16 edge chain met "
+        logger.warning("%d sampler iteration(s) were recomputed with the exact-f32 MFMA kernels: the split-f16 edge chain met "
                        "values beyond the f16 range (set edge_chain_precision='f32' on the network to avoid the retries)",
                        fallbacks)
     output_directory = Path(output_path)

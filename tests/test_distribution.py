@@ -47,29 +47,28 @@ def thresholds(g):
     return lim, atoms
 
 
-def judge(g, calls):
-    """calls: list of X [B, N, 3] (one per sample() call).  Returns the list of violated criteria (empty = passes)."""
+def measure(g, calls):
+    """calls: list of X [B, N, 3] (one per sample() call) -> rows (what, measured KS distance, limit)."""
     lim, atoms = thresholds(g)
     table = {k: g[f"table/{k}"] for k in list(POOLED) + atoms}
-    failures = []
+    rows = []
     per_call = [DS.statistics(x, per_atom=bool(atoms)) for x in calls]
     for c, st in enumerate(per_call):
         for k in POOLED:
-            d = DS.ks_to_table(st[k], table[k])
-            if d > lim[k][0]:
-                failures.append(f"call {c}: {k} {d:.4f} > {lim[k][0]:.4f}")
+            rows.append((f"call {c}: {k}", DS.ks_to_table(st[k], table[k]), lim[k][0]))
         if atoms:
             d = np.array([DS.ks_to_table(st[k], table[k]) for k in atoms])
-            if d.max() > lim["atoms"][0]:
-                failures.append(f"call {c}: largest per-atom marginal {d.max():.4f} > {lim['atoms'][0]:.4f}")
-            if d.mean() > lim["atoms"][1]:
-                failures.append(f"call {c}: mean per-atom marginal {d.mean():.4f} > {lim['atoms'][1]:.4f}")
+            rows.append((f"call {c}: largest per-atom marginal", float(d.max()), lim["atoms"][0]))
+            rows.append((f"call {c}: mean per-atom marginal", float(d.mean()), lim["atoms"][1]))
     if len(calls) > 1:
         for k in POOLED:
-            d = DS.ks_to_table(np.concatenate([st[k] for st in per_call]), table[k])
-            if d > lim[k][1]:
-                failures.append(f"pooled: {k} {d:.4f} > {lim[k][1]:.4f}")
-    return failures
+            rows.append((f"pooled: {k}", DS.ks_to_table(np.concatenate([st[k] for st in per_call]), table[k]), lim[k][1]))
+    return rows
+
+
+def judge(g, calls):
+    """The violated criteria (empty = passes)."""
+    return [f"{what} {d:.4f} > {limit:.4f}" for what, d, limit in measure(g, calls) if d > limit]
 
 
 def probe_fails(g, probe):

@@ -1,0 +1,74 @@
+"""KS distances of the product's fast modes to the reference-made statistics, next to the limits the tests apply
+(tests/test_distribution.py; fixtures tests/golden/dist_*.npz).  Run on the GPU box:
+
+    python tools/distribution_report.py > gpurun_out/distribution_report.txt
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases  # noqa: E402
+import nets  # noqa: E402
+import test_distribution as T  # noqa: E402
+from conftest import load_golden  # noqa: E402
+from test_generator_gpu import _pkg  # noqa: E402
+
+cuda = torch.device("cuda:0")
+P = _pkg()
+
+
+def summary(title, g, calls):
+    rows = T.measure(g, calls)
+    print(f"== {title}: {len(calls)} calls of {calls[0].shape[0]} structures")
+    groups = {}
+    for what, d, limit in rows:
+        key = what.split(": ", 1)[1] if what.startswith("call") else what
+        groups.setdefault(key, []).append((d, limit))
+    for key, vals in groups.items():
+        d = np.array([v[0] for v in vals])
+        print(f"   {key:38s} largest {d.max():.4f}  mean {d.mean():.4f}  limit {vals[0][1]:.4f}  "
+              f"(reference seeds, leave-one-out: {reference_spread(g, key)})")
+    print("   verdict:", "passes" if not T.judge(g, calls) else T.judge(g, calls))
+
+
+def reference_spread(g, key):
+    k = key.replace("pooled: ", "")
+    if f"leave_one_out/{k}" in g.files:
+        v = g[f"half_split/{k}"] if key.startswith("pooled") else g[f"leave_one_out/{k}"]
+        return f"largest {v.max():.4f} mean {v.mean():.4f}"
+    return "-"
+
+
+with torch.no_grad(), warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    g = load_golden("dist_mlp_c2.npz")
+    noise_kw, sampling_kw = T.mlp_c2_parameters()
+    net = nets.load_fixture_weights(nets.mlp_net(8, 1), load_golden("net_mlp_c1.npz")).to(cuda)
+    gen = P["Langevin"](P["Noise"](**noise_kw), P["Sampling"](**sampling_kw, rng_mode="device", seed=9090, fused_score_network=True), net)
+    summary("C2 MLP, persistent fused kernel (device Philox)", g,
+            [gen.sample(int(g["batch"]), cuda).X.cpu().numpy() for _ in range(len(g["seeds"]))])
+    for probe in ("zero_score", "score_x0.9", "no_corrector", "sigma_max_0.2"):
+        atoms = [str(k) for k in g["scalars"] if str(k).startswith("atom")]
+        d = np.array([float(g[f"probe/{probe}/{k}"]) for k in atoms])
+        print(f"   reference-side wrong sampler {probe:14s}: " + ", ".join(f"{k} {float(g[f'probe/{probe}/{k}']):.4f}" for k in T.POOLED) +
+              f", largest / mean per-atom marginal {d.max():.4f} / {d.mean():.4f}  -> {'rejected' if T.probe_fails(g, probe) else 'not seen'}")
+
+    g = load_golden("dist_egnn_rc.npz")
+    for precision in ("f16x3", "f32"):
+        inner = nets.load_fixture_weights(nets.egnn_net(1, "radial_cutoff", 7.5), load_golden("traj_egnn_rc.npz"))
+        net = nets.ScaledScore(inner, float(g["score_factor"])).to(cuda)
+        net.edge_chain_precision = precision
+        gen = P["Langevin"](P["Noise"](**cases.noise_ns(100, **cases.LIN)),
+                            P["Sampling"](**cases.sampling_ns(64, 1, M=2, one=False, greedy=False, cell=[10.86] * 3),
+                                          rng_mode="device", seed=777, use_hip_graph=True), net)
+        summary(f"EGNN hidden 32, N = 64, T = 100, score x {float(g['score_factor']):.0f}, hipGraph loop, edge chain {precision}", g,
+                [gen.sample(int(g["batch"]), cuda).X.cpu().numpy() for _ in range(len(g["seeds"]))])
+    for probe in ("zero_score", "score_x0.5", "score_x0.9", "no_corrector"):
+        print(f"   reference-side wrong sampler {probe:14s}: " + ", ".join(f"{k} {float(g[f'probe/{probe}/{k}']):.4f}" for k in T.POOLED) +
+              f"  -> {'rejected' if T.probe_fails(g, probe) else 'not seen'}")
