@@ -21,7 +21,7 @@ MAX_CLASSES = 8
 TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
     TAG_INIT_LATTICE, TAG_RESAMPLE_Z, TAG_RESAMPLE_U = range(11)
 
-ABI_VERSION = 11         # MDX_ABI_VERSION of include/mdx_hip.h
+ABI_VERSION = 12         # MDX_ABI_VERSION of include/mdx_hip.h
 ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "mdx_noise_lattice_parameters",
     "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_radius_graph_fill_capped", "mdx_egnn_radius_graph", "mdx_mlp_forward",
     "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_variant", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
-    "mdx_egnn_chain_image_bytes", "mdx_egnn_chain_pack", "mdx_egnn_edge_chain", "mdx_egnn_piece_rows", "mdx_segment_combine", "mdx_egnn_node_gather", "mdx_mlp_chain_rows", "mdx_egnn_coord_aggregate",
+    "mdx_egnn_chain_image_bytes", "mdx_egnn_chain_pack", "mdx_egnn_chain_adapt_activation_exponents", "mdx_egnn_edge_chain", "mdx_egnn_piece_rows", "mdx_segment_combine", "mdx_egnn_node_gather", "mdx_mlp_chain_rows", "mdx_egnn_coord_aggregate",
     "mdx_egnn_node_inputs", "mdx_egnn_scores", "mdx_egnn_outputs", "mdx_node_mlp_rows", "mdx_node_mlp_rows_split",
     "mdx_rng_fill", "mdx_math_probe",
 )
@@ -85,7 +85,8 @@ class EgnnChain(C.Structure):
     """mdx_egnn_chain_t"""
     _fields_ = [(n, C.c_int32) for n in ("hidden", "n_message_layers", "n_coord_layers", "precision", "message_mode",
                                          "reserved")] + \
-        [(n, C.c_void_p) for n in ("weight_image", "biases", "bias_in", "w_radial", "weight_exponents")]
+        [(n, C.c_void_p) for n in ("weight_image", "biases", "bias_in", "w_radial", "weight_exponents",
+                                   "activation_exponents", "activation_maxima")]
 
 
 def build(force=False):
@@ -211,6 +212,8 @@ def _declare(L):
     L.mdx_segment_combine.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp, vp]
     L.mdx_egnn_node_gather.restype = i32
     L.mdx_egnn_node_gather.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp]
+    L.mdx_egnn_chain_adapt_activation_exponents.restype = i32
+    L.mdx_egnn_chain_adapt_activation_exponents.argtypes = [vp, i32, vp, vp]
     L.mdx_egnn_piece_rows.restype = i64
     L.mdx_egnn_piece_rows.argtypes = [i64, i64]
     L.mdx_mlp_chain_rows.restype = i32

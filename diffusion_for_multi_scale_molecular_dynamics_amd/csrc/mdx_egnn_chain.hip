@@ -58,7 +58,10 @@ constexpr int kWaves = 4;                 // wavefronts per workgroup = SIMDs pe
 constexpr int kTileEdges = 32 * kWaves;   // edges per workgroup tile
 constexpr int kFastD = 6;                 // coordinate components per node with an unrolled tile top (the EGNN in three dimensions)
 constexpr int kRing = 4;                  // LDS ring slots for weight chunks: being read | readable next | two in flight
-constexpr int kScaleSlots = MDX_EGNN_CHAIN_MAX_LAYERS + 3;   // struct Scale per packed layer (+ the head / two projection layers)
+constexpr int kScaleSlots = MDX_EGNN_CHAIN_MAX_LAYERS + 4;   // struct Scale per packed layer (+ the head / two projection layers) + the
+                                                             // four factors at the chain's ends (kEnds below)
+constexpr int kMaxPositions = MDX_EGNN_CHAIN_MAX_LAYERS + 2; // places where a chain carries activations (see kActExp)
+constexpr int kEnds = kScaleSlots - 1;                       // slot of {2^-c0, log2(e) 2^c0, ln 2 2^-c_out, log2(e) 2^c_reread}
 
 struct ChainArgs {
     const char* image;          // [layers][H/32 chunks][chunk bytes]
@@ -66,6 +69,8 @@ struct ChainArgs {
     const float* bias_in;       // [H]
     const float* w_radial;      // [H]
     const int32_t* exps;        // [packed layers + 1] split-f16: the image holds 2^exps[l] W_l (last: the head row); else null
+    const int32_t* act_exps;    // [layers + 2] split-f16, nullable: position q carries 2^act_exps[q] u (null: kActExp everywhere)
+    uint32_t* act_max;          // [layers + 2] exact-f32 kernels, nullable: running maximum (float bits) of |u| per position
     const float* node_proj;     // [n_nodes][2H]
     const float* coord;         // [n_nodes][D]
     const int64_t* edges;       // [E][2]
@@ -99,28 +104,36 @@ __device__ __forceinline__ float silu_scaled(float z)
     return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-z));
 }
 
-// Split-f16: the carried activations are 2^kActExp u (see the header comment).  2^6: full 22 bits for |u| >= 2^-8, an
-// absolute floor of 2^-31 below that; the f16 range is left at |u| > 1023 (|SiLU| > 709), which the status word reports.
+// Split-f16: the carried activations are 2^c u (see the header comment), c = kActExp unless the caller hands over exponents
+// of its own.  2^6: full 22 bits for |u| >= 2^-8, an absolute floor of 2^-31 below that; the f16 range is left at |u| > 1023
+// (|SiLU| > 709), which the status word reports.
+// POSITIONS.  A chain of L layers has L + 2 places where activations are carried: position q (0 <= q <= L) = the operand
+// entering layer q (q = 0: the first layer's output of the edge chain / the rows of a row chain; q = L: what leaves the last
+// layer: the head's operand / the rows written out), position L + 1 = the rows read back in front of the projection layers
+// (MODE 3).  ChainArgs::act_exps gives one exponent per position (an activation beyond 65504 / 2^c sets the range bit), and
+// ChainArgs::act_max collects, in the exact-f32 kernels, the largest |u| seen at each position -- what the caller derives the
+// exponents from (mdx_egnn_chain_adapt_activation_exponents).  MODE 3: positions 0 and 1 are one (h and agg feed the two
+// halves of ONE layer whose accumulators continue one another): position 0 is used for both.
 template <int PREC>
 constexpr int kActExp = PREC >= 1 ? 6 : 0;
 constexpr float pow2_const(int e) { float v = 1.0f; for (int i = 0; i < (e < 0 ? -e : e); ++i) v = e < 0 ? v * 0.5f : v * 2.0f; return v; }
 __device__ __forceinline__ float pow2_bits(int e) { return __builtin_bit_cast(float, (uint32_t)(127 + e) << 23); }   // |e| <= 126
 
 // Exponent bookkeeping of one layer (wave-uniform; staged in LDS at kernel start, carried in scalar registers):
-// the accumulator of a tile of layer l holds A = 2^(a+b) z (a = the image's exponent, b = kActExp).
-//   neg_c = -2^-(a+b)   t = A neg_c = -z                         (the one instruction the scaling costs per value)
-//   k     =  2^a        u' = A / (k + k 2^t) = 2^b z / (1 + 2^-z)
-//   inv_a =  2^-a       a layer without activation: u' = A inv_a = 2^b z
+// the accumulator of a tile of layer l holds A = 2^(a+b) z (a = the image's exponent, b = the exponent of the layer's operand,
+// b' = that of its output: the next position).
+//   neg_c = -2^-(a+b)     t = A neg_c = -z                       (the one instruction the scaling costs per value)
+//   k     =  2^(a+b-b')   u' = A / (k + k 2^t) = 2^b' z / (1 + 2^-z)
+//   inv_a =  2^-(a+b-b')  a layer without activation: u' = A inv_a = 2^b' z
 //   out   =  ln 2 2^-(a+b)   a tile stored as it is (the head, the projections behind the node MLP): y = A out
 struct Scale {
     float neg_c, k, inv_a, out;
 };
-// u' = 2^b u for the first layer, computed on the vector ALU from z itself
+// u' = 2^b u for the first layer, computed on the vector ALU from z itself; kb = 2^-b
 template <int PREC>
-__device__ __forceinline__ float silu_first(float z)
+__device__ __forceinline__ float silu_first(float z, float kb)
 {
     if constexpr (PREC == 0) return silu_scaled(z);
-    constexpr float kb = pow2_const(-kActExp<PREC>);
     return z * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(-z), kb, kb));
 }
 
@@ -494,9 +507,10 @@ struct Chain {
 // and a NaN one layer later, in every feature of its edge: it reaches the kernel's outputs, where it is looked for.  Branch-free, so that it is one scheduling region with the MFMAs around
 // it.  tp, r0, r1 are constants after unrolling.
 // `linear` (wave-uniform): the tile belongs to a layer without activation (the last layer of a row chain): u = z, a select.
+// `amax` (exact-f32 kernels; nullable): running maximum of |u| over the values written (ChainArgs::act_max).
 template <int H, int PREC>
 __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const f32x16& pend, Act<H, PREC>& dst,
-                                                  const Scale& sc, bool linear = false)
+                                                  const Scale& sc, bool linear = false, float* amax = nullptr)
 {
     // split-f16: the accumulator is 2^(a+b) z (struct Scale): -z, then 2^b z / (1 + 2^-z) with the divisor pre-scaled
     auto act = [&](float A) -> float {
@@ -509,7 +523,9 @@ __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const 
         if (r < r0 || r >= r1) continue;
         if constexpr (PREC == 0) {
             // (one value at a time: in pairs this instantiation nearly doubles its run time -- 7.25 -> 12.9 ms at H = 256)
-            put<H>(dst, tp, r, linear ? lin(pend[r]) : act(pend[r]));
+            const float y = linear ? lin(pend[r]) : act(pend[r]);
+            if (amax) *amax = __builtin_fmaxf(*amax, __builtin_fabsf(y));
+            put<H>(dst, tp, r, y);
         } else if (!(r & 1)) {
             const float y0 = linear ? lin(pend[r]) : act(pend[r]), y1 = linear ? lin(pend[r + 1]) : act(pend[r + 1]);
             put_pair<H>(dst, tp, r, y0, y1);
@@ -691,9 +707,23 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     lds_f* par_sc = par_wr + H;                             // [kScaleSlots][4]: struct Scale of every packed layer
     // the source nodes of this wavefront's 32 edges (in-kernel message aggregation: where the pieces end)
     __attribute__((address_space(3))) int* seg_src = (__attribute__((address_space(3))) int*)(par_sc + 4 * kScaleSlots) + wave * 32;
+    // exact-f32 kernels: the workgroup's maxima of |u| per position (ChainArgs::act_max), behind the source ids
+    uint32_t* max_table = (uint32_t*)(lds_raw + kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H + 4 * kScaleSlots) +
+                                      sizeof(int) * kWaves * 32);
     constexpr int ACT = kActExp<PREC>;
-    constexpr float kIn = kLog2e * pow2_const(ACT);          // a caller's value x -> the carried 2^b log2(e) x
-    constexpr float kOut = kLn2 * pow2_const(-ACT);          // a carried value -> the caller's
+    // the exponent of the activations carried at position q (see kActExp): the caller's, else ACT; exact-f32 kernels: 0
+    auto act_exp = [&](int q) -> int {
+        if constexpr (!SPLIT) return 0;
+        if (MODE == 3 && q == 1) q = 0;
+        return p.act_exps ? p.act_exps[q] : ACT;
+    };
+    auto in_pos = [](int l) -> int { return l; };
+    auto out_pos = [](int l) -> int { return MODE == 3 && l == 0 ? 2 : l + 1; };
+    // the four factors at the chain's ends (slot kEnds of the scale table, read where they are used):
+    //   [0] 2^-c_0 (the first layer's SiLU)   [1] log2(e) 2^c_0 (a caller's row -> carried)
+    //   [2] ln 2 2^-c_out (carried -> the caller's: the messages, position n_message; the rows written out, position L)
+    //   [3] log2(e) 2^c_{L+1} (the rows read back in front of the projection layers)
+    auto end_factor = [&](int i) -> float { return par_sc[4 * kEnds + i]; };
 
     // (the device-side count arrives through a vector load: made scalar by hand, or every loop bound derived from it -- and
     // with them the whole ring state of the tile loop -- lives in vector registers and is updated by the vector ALU)
@@ -717,24 +747,38 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     const int64_t tile_lo = xcd * xcd_tiles, tile_hi = tile_lo + xcd_tiles < n_tiles ? tile_lo + xcd_tiles : n_tiles;
     if (tile_lo + xcd_slot >= tile_hi) return;              // uniform per workgroup
 
-    // a layer's bias in its accumulator's units: log2(e) 2^(a_l + b) b_l (exact: a power of two)
+    // a layer's bias in its accumulator's units: log2(e) 2^(a_l + b_l) bias_l (exact: a power of two)
     for (int i = threadIdx.x; i < layers * H; i += kWaves * kWave) {
-        const int a = SPLIT && p.exps ? p.exps[i / H] : 0;
-        par[i] = p.biases[i] * kLog2e * pow2_bits(a + ACT);
+        const int l = i / H;
+        const int a = SPLIT && p.exps ? p.exps[l] : 0;
+        par[i] = p.biases[i] * kLog2e * pow2_bits(a + act_exp(in_pos(l)));
     }
-    if (threadIdx.x < kScaleSlots) {
+    if (threadIdx.x < kEnds) {
+        const int l = threadIdx.x;
         const int packed = layers + (!ROWS ? 1 : (MODE == 3 && p.proj_out ? 2 : 0));
-        const int a = SPLIT && p.exps && (int)threadIdx.x < packed ? p.exps[threadIdx.x] : 0;
-        par_sc[4 * threadIdx.x + 0] = -pow2_bits(-(a + ACT));
-        par_sc[4 * threadIdx.x + 1] = pow2_bits(a);
-        par_sc[4 * threadIdx.x + 2] = pow2_bits(-a);
-        par_sc[4 * threadIdx.x + 3] = kLn2 * pow2_bits(-(a + ACT));
+        const int a = SPLIT && p.exps && l < packed ? p.exps[l] : 0;
+        // operand / output exponents of slot l: a chain layer; the head (its operand: position L); the projection layers
+        // behind a node MLP (their operand: position L + 1); unused slots
+        const int b = l < layers ? act_exp(in_pos(l)) : (l < packed ? act_exp(!ROWS ? layers : layers + 1) : 0);
+        const int b_out = l < layers ? act_exp(out_pos(l)) : 0;
+        par_sc[4 * l + 0] = -pow2_bits(-(a + b));
+        par_sc[4 * l + 1] = pow2_bits(a + b - b_out);
+        par_sc[4 * l + 2] = pow2_bits(-(a + b - b_out));
+        par_sc[4 * l + 3] = kLn2 * pow2_bits(-(a + b));
+    } else if (threadIdx.x == kEnds) {
+        par_sc[4 * kEnds + 0] = pow2_bits(-act_exp(0));
+        par_sc[4 * kEnds + 1] = kLog2e * pow2_bits(act_exp(0));
+        par_sc[4 * kEnds + 2] = kLn2 * pow2_bits(-act_exp(!ROWS ? p.n_message : layers));
+        par_sc[4 * kEnds + 3] = kLog2e * pow2_bits(act_exp(layers + 1));
     }
     if constexpr (!ROWS) {
         for (int i = threadIdx.x; i < H; i += kWaves * kWave) {
             par_in[i] = p.bias_in[i] * kLog2e;
             par_wr[i] = p.w_radial[i] * kLog2e;
         }
+    }
+    if constexpr (PREC == 0) {
+        if (threadIdx.x < kMaxPositions) max_table[threadIdx.x] = 0u;
     }
     __syncthreads();
 
@@ -830,6 +874,30 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             return __builtin_amdgcn_readfirstlane(count);
         };
         Act<H, PREC> xa, xb;
+        // exact-f32 kernels with ChainArgs::act_max: the largest |u| this lane has written since the last flush_max(); a flush
+        // reduces it over the wavefront and raises the position's word (float bits of non-negative values order like integers)
+        float amax = 0.0f;
+        float* const amax_p = PREC == 0 ? &amax : nullptr;
+        auto note4 = [&](float y0, float y1, float y2, float y3) {
+            if constexpr (PREC == 0)
+                amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(y0), __builtin_fabsf(y1))),
+                                       __builtin_fmaxf(__builtin_fabsf(y2), __builtin_fabsf(y3)));
+        };
+        auto flush_max = [&](int position) {
+            if constexpr (PREC == 0) {
+                // (into the workgroup's LDS table: one global atomic per position at the end of the kernel, and no global
+                // pointer kept in scalar registers through the tile loop)
+                float m = amax;
+                m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+                m = __builtin_fmaxf(m, __shfl_xor(m, 16));
+                m = __builtin_fmaxf(m, __shfl_xor(m, 8));
+                m = __builtin_fmaxf(m, __shfl_xor(m, 4));
+                m = __builtin_fmaxf(m, __shfl_xor(m, 2));
+                m = __builtin_fmaxf(m, __shfl_xor(m, 1));
+                if (lane == 0) atomicMax(max_table + position, __builtin_bit_cast(uint32_t, m));
+                amax = 0.0f;
+            }
+        };
         // float4 group q8 = 4 t + q of the lane's H / 2 values: registers 4 q .. 4 q + 3 of tile t = features
         // 32 t + fb(q) .. + 3 of edge es(q)  (struct Lay)
         if constexpr (!ROWS) {
@@ -910,6 +978,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     if (h == 0) seg_src[(W16 ? 16 * es : 0) + col] = (int)src[es];           // (node indices fit 31 bits: checked on the host)
             }
             __builtin_amdgcn_sched_barrier(0);
+            const float kb = end_factor(0);
 #pragma unroll
             for (int batch = 0; batch < NB; ++batch) {
                 if (batch + DEPTH < NB) request(batch + DEPTH);
@@ -923,7 +992,8 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     // z = log2(e) ((a + b) + b0 + radial wr): b0 and wr are staged pre-scaled, two fused multiply-adds per value
                     float y[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] = silu_first<PREC>(__builtin_fmaf(a[i] + b[i], kLog2e, __builtin_fmaf(radial[es], wr[i], b0[i])));
+                    for (int i = 0; i < 4; ++i) y[i] = silu_first<PREC>(__builtin_fmaf(a[i] + b[i], kLog2e, __builtin_fmaf(radial[es], wr[i], b0[i])), kb);
+                    note4(y[0], y[1], y[2], y[3]);
                     put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3), y[0], y[1]);
                     put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3) + 2, y[2], y[3]);
                 }
@@ -931,6 +1001,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             }
         } else {
             // the rows themselves (the caller's activations, carried as 2^b log2(e) x inside the chain)
+            const float kIn = end_factor(1);
 #pragma unroll
             for (int q8 = 0; q8 < H / 8; ++q8) {
                 const int es = L::es(q8 & 3), off = 32 * (q8 >> 2) + L::fb(q8 & 3, h);
@@ -939,12 +1010,14 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3), a[0] * kIn, a[1] * kIn);
                     put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3) + 2, a[2] * kIn, a[3] * kIn);
                 } else {
+                    note4(a[0] * kIn, a[1] * kIn, a[2] * kIn, a[3] * kIn);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) put<H>(xa, q8 >> 2, 4 * (q8 & 3) + i, a[i] * kIn);
                 }
                 if ((q8 & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        flush_max(0);
         MDX_STAMP_ALWAYS(10);
         if constexpr (C::SPREAD) ch.scalar_addresses();       // (the burst form sets them right before its requests)
         // ---- the chain ----------------------------------------------------------------------------------------------
@@ -975,9 +1048,9 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     // (16x16 shape: ALL sixteen values of the pending tile are elements of ONE k-step of the next layer, the one
                     // this tile reads in its last two steps when it is that layer's first tile: complete before those steps)
                     constexpr int D = STEPS > 2 ? STEPS - 2 : 1;
-                    if (have && s < D) epilogue_elements<H, PREC>(tp, 16 * s / D, 16 * (s + 1) / D, pend, epi_dst, epi_sc, ROWS && linear);
+                    if (have && s < D) epilogue_elements<H, PREC>(tp, 16 * s / D, 16 * (s + 1) / D, pend, epi_dst, epi_sc, ROWS && linear, amax_p);
                 } else {
-                    if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, epi_sc, ROWS && linear);
+                    if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, epi_sc, ROWS && linear, amax_p);
                 }
                 // one weight-stream request per STEPS / LPW k-steps, behind the step's first MFMA; g = steps since the acquire
                 constexpr int PERIOD = STEPS / C::LPW;
@@ -1038,8 +1111,12 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 // layer -- the head (no bias; MODE 0) / layer 0 of the next rows (MODE 1)
                 const lds_f* next_bias = t + 1 < NT ? bias + 32 * (t + 1) : (l + 1 < layers ? bias + H : (!ROWS || (MODE == 3 && p.proj_out) ? nullptr : par));
                 // the epilogue beside tile 0 belongs to the previous layer (never the linear one); the others to this layer
-                if (t == 0) pend = run_tile(in, !FIRST, NT - 1, in, next_bias, sc_prev);
-                else pend = run_tile(in, true, t - 1, out, next_bias, sc, l == layers - 1);
+                if (t == 0) {
+                    pend = run_tile(in, !FIRST, NT - 1, in, next_bias, sc_prev);
+                    if (!FIRST) flush_max(l);               // the operand of layer l is complete
+                } else {
+                    pend = run_tile(in, true, t - 1, out, next_bias, sc, l == layers - 1);
+                }
             }
             sc_prev = sc;
         };
@@ -1047,6 +1124,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         auto store_messages = [&](const Act<H, PREC>& m) {
             // every wavefront issues exactly H / 8 store instructions (lanes beyond the edge count masked off, the address
             // clamped; an edge slot without a live lane issues none): the next chunk wait counts on them (Chain::stores_count)
+            const float kOut = end_factor(2);
 #pragma unroll
             for (int q8 = 0; q8 < H / 8; ++q8) {
                 const int t = q8 >> 2, q = q8 & 3, es = L::es(q);
@@ -1071,6 +1149,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         // themselves never reach memory.  Returns a lower bound of the store instructions issued (for the next chunk wait).
         auto aggregate_pieces = [&](const Act<H, PREC>& m) -> int {
             const int64_t wave_base = tile * kTileEdges + wave * 32;
+            const float kOut = end_factor(2);
             const int n_live = n_edges - wave_base >= 32 ? 32 : (n_edges > wave_base ? (int)(n_edges - wave_base) : 0);
             const int c16 = col & 15;
             float gate[NS][4];                              // 1.0: the edge 1 / 2 / 4 / 8 below is in this lane's piece
@@ -1137,6 +1216,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         // register 0 of the lanes with h == 0 (16x16 shape: registers 0 and 4, the two column groups)
         auto head_tile = [&](Act<H, PREC>& in) {
             const f32x16 acc = run_tile(in, true, NT - 1, in, par, sc_prev);      // after the head: layer 0, tile 0 of the next edges
+            flush_max(layers);
             const float to_out = load_scale(layers).out;                          // (the head row is packed as it is: ln 2 comes here)
 #pragma unroll
             for (int es = 0; es < NS; ++es) {
@@ -1147,8 +1227,10 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         };
         // MODE 1: the last tile of the last (linear) layer has no tile after it to run beside; then out = residual + y
         auto finish_rows = [&](Act<H, PREC>& y, Act<H, PREC>& u) {
-            epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, y, sc_prev, true);
+            epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, y, sc_prev, true, amax_p);
+            flush_max(layers);
             const bool project = MODE == 3 && p.proj_out != nullptr;       // out is also the operand of two more linear layers
+            const float kOut = end_factor(2);
 #pragma unroll
             for (int q8 = 0; q8 < H / 8; ++q8) {
                 const int t = q8 >> 2, q = q8 & 3, es = L::es(q), off = 32 * t + L::fb(q, h);
@@ -1176,14 +1258,17 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     // a pipelined epilogue).  Their operand: the rows just written, read back into the free register set
                     // (filling it while y and the residual are live spills 480 B per lane); this lane reads what it wrote.
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const float kIn = end_factor(3);
 #pragma unroll
                     for (int q8 = 0; q8 < H / 8; ++q8) {
                         const int es = L::es(q8 & 3), off = 32 * (q8 >> 2) + L::fb(q8 & 3, h);
                         const f32x4 a = *(const f32x4*)(p.rows_out + e[es] * H + off);
+                        note4(a[0] * kIn, a[1] * kIn, a[2] * kIn, a[3] * kIn);
                         put_pair<H>(u, q8 >> 2, 4 * (q8 & 3), a[0] * kIn, a[1] * kIn);
                         put_pair<H>(u, q8 >> 2, 4 * (q8 & 3) + 2, a[2] * kIn, a[3] * kIn);
                         if ((q8 & 15) == 15) __builtin_amdgcn_sched_barrier(0);
                     }
+                    flush_max(layers + 1);
 #pragma unroll 1
                     for (int t2 = 0; t2 < 2 * NT; ++t2) {
                         if constexpr (C::SPREAD) ch.scalar_addresses();    // (loop-carried: see scalar_addresses)
@@ -1213,6 +1298,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 park(xb, t, acc);
             }
             // the operand registers again, with agg (columns H .. 2H-1 of the row)
+            const float kIn = end_factor(1);
 #pragma unroll
             for (int q8 = 0; q8 < H / 8; ++q8) {
                 const int es = L::es(q8 & 3), off = 32 * (q8 >> 2) + L::fb(q8 & 3, h);
@@ -1221,11 +1307,13 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3), a[0] * kIn, a[1] * kIn);
                     put_pair<H>(xa, q8 >> 2, 4 * (q8 & 3) + 2, a[2] * kIn, a[3] * kIn);
                 } else {
+                    note4(a[0] * kIn, a[1] * kIn, a[2] * kIn, a[3] * kIn);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) put<H>(xa, q8 >> 2, 4 * (q8 & 3) + i, a[i] * kIn);
                 }
                 if ((q8 & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
+            flush_max(0);
             // pass B: layer 1 = the second half on agg, every tile started from its parked accumulator
             acc_next = unpark(xb, 0);
 #pragma unroll
@@ -1288,6 +1376,9 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     MDX_STAMP_REALTIME(23);
     if constexpr (SPLIT) {
         if (p.status && out_of_range) atomicOr(p.status, MDX_STATUS_EGNN_F16_RANGE);
+    } else {
+        __syncthreads();
+        if (p.act_max && (int)threadIdx.x < layers + 2 && max_table[threadIdx.x]) atomicMax(p.act_max + threadIdx.x, max_table[threadIdx.x]);
     }
 }
 
@@ -1343,6 +1434,26 @@ __global__ void egnn_chain_exponents_kernel(PackArgs p)
             for (int k = lo + 1; k <= l; ++k) a = p.exps[k] < a ? p.exps[k] : a;
             for (int k = lo; k <= l; ++k) p.exps[k] = a;
         }
+}
+
+// Activation exponents from the maxima the exact-f32 kernels collected (one thread): position q with a recorded maximum m
+// (float bits) gets min(its current exponent, c) with 2^c m in [2^12, 2^13) -- eight times below the f16 range -- c clamped to
+// [kMinActExp, kActExp]: an exponent only ever goes DOWN (a layer seen hot once keeps its headroom), never above the default
+// (whose precision floor the accuracy tests hold), and a position nothing was recorded for keeps what it has.  An infinite or
+// NaN maximum counts as the largest float.  The maxima are cleared for the next collection.
+constexpr int kMinActExp = -14;
+__global__ void egnn_chain_act_exponents_kernel(uint32_t* maxima, int count, int32_t* exps)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    for (int q = 0; q < count; ++q) {
+        const uint32_t b = maxima[q] & 0x7fffffffu;
+        maxima[q] = 0;
+        if (!b) continue;
+        const int e = b >= 0x7f800000u ? 127 : (int)(b >> 23) - 127;          // floor(log2 m); subnormals: -127
+        int c = 12 - e;
+        c = c > kActExp<1> ? kActExp<1> : (c < kMinActExp ? kMinActExp : c);
+        if (c < exps[q]) exps[q] = c;
+    }
 }
 
 __global__ __launch_bounds__(256) void egnn_chain_pack_kernel(PackArgs p)
@@ -1514,8 +1625,9 @@ int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
 {
     using C = Chain<H, PREC>;
     // ring | biases + first-layer vectors | per-wavefront source ids of the in-kernel aggregation
+    // ring | biases + first-layer vectors + scale table | per-wavefront source ids of the in-kernel aggregation | maxima table
     const size_t lds = (size_t)kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H + 4 * kScaleSlots) +
-                       (MODE == 2 ? sizeof(int) * kWaves * 32 : 0);
+                       sizeof(int) * kWaves * 32 + sizeof(uint32_t) * kMaxPositions;
     static bool granted[64] = {};       // (one flag per instantiation: function-local static of a template)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MDX_ERR_HIP;
@@ -1591,6 +1703,7 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
     ChainArgs a{};
     a.image = (const char*)c->weight_image; a.biases = c->biases; a.bias_in = c->bias_in; a.w_radial = c->w_radial;
     a.exps = c->weight_exponents;
+    a.act_exps = c->activation_exponents; a.act_max = c->activation_maxima;
     a.node_proj = node_proj; a.coord = coord; a.edges = edges; a.n_edges_dev = n_edges_dev;
     a.n_edges = n_edges; a.n_message = c->n_message_layers; a.n_coord = c->n_coord_layers; a.D = coord_dimension;
     a.messages = messages_out; a.edge_scalar = edge_scalar_out; a.status = status;
@@ -1615,6 +1728,14 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
     }
 #undef MDX_CHAIN_CASE
     return MDX_ERR_UNSUPPORTED;
+}
+
+int mdx_egnn_chain_adapt_activation_exponents(uint32_t* maxima_inout, int count, int32_t* exponents_inout, mdx_stream_t stream)
+{
+    if (!maxima_inout || !exponents_inout || count < 1 || count > MDX_EGNN_CHAIN_MAX_LAYERS + 2) return MDX_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(egnn_chain_act_exponents_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), maxima_inout,
+                       count, exponents_inout);
+    return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 
 int64_t mdx_egnn_piece_rows(int64_t n_edges, int64_t n_nodes)
@@ -1664,6 +1785,7 @@ int mdx_mlp_chain_rows(const mdx_egnn_chain_t* c, const float* x, const float* r
     if (!c->weight_image || !c->biases || !x || !out || (c->precision >= 1 && !c->weight_exponents)) return MDX_ERR_INVALID_ARG;
     ChainArgs a{};
     a.image = (const char*)c->weight_image; a.biases = c->biases; a.exps = c->weight_exponents;
+    a.act_exps = c->activation_exponents; a.act_max = c->activation_maxima;
     a.n_edges_dev = n_rows_dev; a.n_edges = n_rows; a.n_message = c->n_message_layers; a.n_coord = 0; a.D = 0;
     a.rows_in = x; a.residual = residual; a.rows_out = out; a.status = status; a.ld_in = c->hidden;
     const int layers = a.n_message;
@@ -1712,6 +1834,7 @@ static int node_mlp_rows(const mdx_egnn_chain_t* c, const float* node_in, int64_
     if (!c->weight_image || !c->biases || !node_in || !agg || !out || (c->precision >= 1 && !c->weight_exponents)) return MDX_ERR_INVALID_ARG;
     ChainArgs a{};
     a.image = (const char*)c->weight_image; a.biases = c->biases; a.exps = c->weight_exponents;
+    a.act_exps = c->activation_exponents; a.act_max = c->activation_maxima;
     a.n_edges_dev = n_rows_dev; a.n_edges = n_rows; a.n_message = c->n_message_layers; a.n_coord = 0; a.D = 0;
     a.rows_in = node_in; a.residual = add_residual ? node_in : nullptr; a.rows_out = out; a.status = status;
     a.ld_in = ld; a.rows_in2 = agg; a.ld_in2 = ld_agg;

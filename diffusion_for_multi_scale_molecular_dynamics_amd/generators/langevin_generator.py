@@ -447,6 +447,14 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
             return True
         return False
 
+    def _adapt_f16_range(self):
+        """After the exact-f32 pass: the network derives per-layer activation exponents for its split-f16 kernels from the
+        maxima that pass has collected (EGNNScoreNetwork.adapt_f16_range), so a layer that runs hot does not send every
+        following iteration through the f32 kernels."""
+        adapt = getattr(self.axl_network, "adapt_f16_range", None)
+        if adapt is not None:
+            adapt()
+
     def _count_fallback(self, index_i: int):
         import warnings
         self.f16_range_fallbacks += 1
@@ -495,6 +503,7 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
                 return self._iteration(composition, i, forces)
             finally:
                 net.edge_chain_precision = precision
+                self._adapt_f16_range()
         finally:
             if keeps:
                 self.noise_source = source
@@ -782,5 +791,6 @@ class IterationLoop:
                 self._one(visits=1 + gen.resampling_steps)      # eager launches of the same iteration, exact-f32 kernels
             finally:
                 net.edge_chain_precision = precision
+                gen._adapt_f16_range()
             checked += 1
             k = checked

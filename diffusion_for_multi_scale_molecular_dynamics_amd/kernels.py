@@ -638,12 +638,42 @@ def _pack_chain_image(weights, w_out, H: int, precision: str, tied_layers: int =
     return image, exponents      # (the temporaries are freed in stream order: the image holds its own copy)
 
 
+F16_ACTIVATION_EXPONENT = 6        # MDX_EGNN_F16_ACTIVATION_EXPONENT
+
+
+class ActivationScales:
+    """The per-position powers of two the split-f16 kernels carry a chain's activations with, and the maxima the exact-f32
+    kernels collect for them (mdx_egnn_chain_t.activation_exponents / activation_maxima): two small device arrays owned by
+    whoever owns the chain's parameters and SHARED by the chain's packs of every precision -- the f32 pass that follows a
+    range report fills the maxima, adapt() turns them into exponents (on the device, no host read), and the split-f16
+    launches that follow -- captured ones included: the kernels read the array at every launch -- carry the hot positions
+    with more headroom."""
+
+    def __init__(self, n_layers: int, device):
+        self.count = n_layers + 2
+        self.exponents = torch.full((self.count,), F16_ACTIVATION_EXPONENT, dtype=I32, device=device)
+        self.maxima = torch.zeros(self.count, dtype=I32, device=device)
+
+    def adapt(self):
+        with torch.cuda.device(self.exponents.device):
+            check(lib().mdx_egnn_chain_adapt_activation_exponents(C.c_void_p(self.maxima.data_ptr()), self.count,
+                                                                  C.c_void_p(self.exponents.data_ptr()), stream_handle()),
+                  "mdx_egnn_chain_adapt_activation_exponents")
+
+    def pointers(self, precision: str):
+        """(activation_exponents, activation_maxima) of a pack of `precision`: the split kernels read the exponents, the
+        exact-f32 kernels write the maxima."""
+        return (None, self.maxima.data_ptr()) if precision == "f32" else (self.exponents.data_ptr(), None)
+
+
 class EdgeChainPack:
     """Device image of one E_GCL layer's per-edge MLP chain for mdx_egnn_edge_chain: the H -> H weight matrices of the
     message MLP (after its first layer) and of the coordinate MLP, re-laid out by mdx_egnn_chain_pack for `precision`,
-    plus the small vectors.  Built from the modules' parameters at construction; `stamp` tells when to rebuild."""
+    plus the small vectors.  Built from the modules' parameters at construction; `stamp` tells when to rebuild.
+    scales (ActivationScales, optional): shared with the layer's packs of the other precisions."""
 
-    def __init__(self, first_message_layer, message_layers, coord_layers, coord_out_layer, input_size: int, precision: str):
+    def __init__(self, first_message_layer, message_layers, coord_layers, coord_out_layer, input_size: int, precision: str,
+                 scales=None):
         H = first_message_layer.out_features
         dev = first_message_layer.weight.device
         layers = list(message_layers) + list(coord_layers)
@@ -659,12 +689,15 @@ class EdgeChainPack:
         # [2H, n_in]: the per-node projections of the first message layer (source half | destination half) as ONE matrix
         w0 = first_message_layer.weight.detach().to(F32)
         self.proj_weight = torch.cat([w0[:, :input_size], w0[:, input_size:2 * input_size]], dim=0).contiguous()
+        self.scales = scales
+        act = scales.pointers(precision) if scales is not None else (None, None)
+        assert scales is None or scales.count == len(layers) + 2
         self.c_struct = _hip.EgnnChain(H, len(list(message_layers)), len(list(coord_layers)),
                                        EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
                                        self.biases.data_ptr(), self.bias_in.data_ptr(), self.w_radial.data_ptr(),
-                                       self.exponents.data_ptr())
+                                       self.exponents.data_ptr(), *act)
         # the kernel's LDS: weight ring + small vectors + per-layer scale table + the source ids of the in-kernel aggregation
-        lds = 4 * 32 * H * 4 + 4 * (len(layers) * H + 2 * H) + 16 * (_hip.EGNN_CHAIN_MAX_LAYERS + 3) + 4 * 4 * 32
+        lds = 4 * 32 * H * 4 + 4 * (len(layers) * H + 2 * H) + 16 * (_hip.EGNN_CHAIN_MAX_LAYERS + 4) + 4 * 4 * 32 + 4 * (_hip.EGNN_CHAIN_MAX_LAYERS + 2)
         self.piece_sums_ok = lds <= 160 * 1024
         self.device = dev
 
@@ -683,7 +716,7 @@ class RowChainPack:
     """Device image of a chain of H -> H nn.Linear layers applied to the rows of a matrix (mdx_mlp_chain_rows): every layer
     but the last is followed by SiLU.  Used for the per-node MLP of an EGNN layer after its first (2H -> H) layer."""
 
-    def __init__(self, layers, precision: str):
+    def __init__(self, layers, precision: str, scales=None):
         layers = list(layers)
         H = layers[0].in_features
         if precision not in EDGE_CHAIN_PRECISIONS:
@@ -694,8 +727,11 @@ class RowChainPack:
         self.precision, self.hidden = precision, H
         self.image, self.exponents = _pack_chain_image([layer.weight for layer in layers], None, H, precision)
         self.biases = torch.stack([layer.bias.detach().to(F32) for layer in layers]).contiguous()
+        self.scales = scales
+        act = scales.pointers(precision) if scales is not None else (None, None)
+        assert scales is None or scales.count == len(layers) + 2
         self.c_struct = _hip.EgnnChain(H, len(layers), 0, EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
-                                       self.biases.data_ptr(), None, None, self.exponents.data_ptr())
+                                       self.biases.data_ptr(), None, None, self.exponents.data_ptr(), *act)
 
     @staticmethod
     def supported(layers) -> bool:
@@ -711,9 +747,10 @@ class NodeMlpPack:
     """Device image of a whole EGNN node MLP -- Linear(2H, H), SiLU, [Linear(H, H), SiLU]*, Linear(H, H) -- for
     mdx_node_mlp_rows: the first layer's [H, 2H] weight as two H x H chain layers."""
 
-    def __init__(self, layers, precision: str, next_projection=None):
+    def __init__(self, layers, precision: str, next_projection=None, scales=None):
         """next_projection: [2H, H] = the next graph layer's per-node projection weight (EdgeChainPack.proj_weight): its
-        two H x H halves follow the MLP in the image, and node_mlp_rows also returns out @ next_projection.T."""
+        two H x H halves follow the MLP in the image, and node_mlp_rows also returns out @ next_projection.T.
+        scales: ActivationScales(n_chain_layers(layers), device), shared between the precisions."""
         layers = list(layers)
         if precision not in EDGE_CHAIN_PRECISIONS:
             raise _hip.MdxError(f"chain precision must be one of {sorted(EDGE_CHAIN_PRECISIONS)}; got {precision!r}")
@@ -736,8 +773,16 @@ class NodeMlpPack:
         zeros = torch.zeros(H, dtype=F32, device=dev)
         self.biases = torch.stack([layers[0].bias.detach().to(F32), zeros] +
                                   [l.bias.detach().to(F32) for l in layers[1:]]).contiguous()
+        self.scales = scales
+        act = scales.pointers(precision) if scales is not None else (None, None)
+        assert scales is None or scales.count == n + 2
         self.c_struct = _hip.EgnnChain(H, n, 0, EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
-                                       self.biases.data_ptr(), None, None, self.exponents.data_ptr())
+                                       self.biases.data_ptr(), None, None, self.exponents.data_ptr(), *act)
+
+    @staticmethod
+    def n_chain_layers(layers) -> int:
+        """chain layers of the MLP part of the image: the wide first layer counts twice"""
+        return len(list(layers)) + 1
 
     @staticmethod
     def supported(layers) -> bool:

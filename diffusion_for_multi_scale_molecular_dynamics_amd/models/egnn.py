@@ -118,7 +118,25 @@ class E_GCL(nn.Module):
         state["_node_mlp"] = (None, None)
         state.pop("_chain_kept", None)
         state.pop("_node_mlp_kept", None)
+        state.pop("_activation_scales", None)
         return state
+
+    def _scales(self, kind: str, n_layers: int, device):
+        """kernels.ActivationScales of one of the layer's chains ("edge", "node", "rows"): the per-position powers of two of
+        the split-f16 kernels and the maxima the exact-f32 kernels collect, shared by the chain's packs of every precision
+        and kept across repacks (an exponent only ever goes down)."""
+        from .. import kernels
+        kept = self.__dict__.setdefault("_activation_scales", {})
+        key = (kind, n_layers, str(device))
+        if key not in kept:
+            kept[key] = kernels.ActivationScales(n_layers, device)
+        return kept[key]
+
+    def adapt_f16_range(self):
+        """After an exact-f32 pass (the generator's answer to an f16-range report): turn the maxima that pass collected into
+        activation exponents for the split-f16 kernels (device-side, no host read)."""
+        for scales in self.__dict__.get("_activation_scales", {}).values():
+            scales.adapt()
 
     def _messages(self, h: torch.Tensor, edge_index: torch.Tensor, radial: torch.Tensor, fused: bool) -> torch.Tensor:
         first = self.message_mlp[0]
@@ -175,8 +193,10 @@ class E_GCL(nn.Module):
             # (one image per precision is kept: the generator's one-call switch to "f32" and back repacks nothing)
             kept = self.__dict__.setdefault("_chain_kept", {})
             if kept.get(self.edge_chain_precision, (None, None))[0] != stamp:
-                kept[self.edge_chain_precision] = (stamp, kernels.EdgeChainPack(*modules, input_size=self.input_size,
-                                                                                precision=self.edge_chain_precision))
+                n_layers = len(list(modules[1])) + len(list(modules[2]))
+                kept[self.edge_chain_precision] = (stamp, kernels.EdgeChainPack(
+                    *modules, input_size=self.input_size, precision=self.edge_chain_precision,
+                    scales=self._scales("edge", n_layers, modules[0].weight.device)))
             self._chain = kept[self.edge_chain_precision]
         return self._chain[1]
 
@@ -197,7 +217,8 @@ class E_GCL(nn.Module):
             return None
         stamp = (self.edge_chain_precision,) + tuple((t.data_ptr(), t._version) for lin in rest for t in (lin.weight, lin.bias))
         if self._node_chain[0] != stamp:
-            self._node_chain = (stamp, kernels.RowChainPack(rest, self.edge_chain_precision))
+            self._node_chain = (stamp, kernels.RowChainPack(rest, self.edge_chain_precision,
+                                                            scales=self._scales("rows", len(rest), rest[0].weight.device)))
         return self._node_chain[1]
 
     def _node_mlp_pack(self, next_layer=None):
@@ -225,8 +246,9 @@ class E_GCL(nn.Module):
         if self._node_mlp[0] != stamp:
             kept = self.__dict__.setdefault("_node_mlp_kept", {})
             if kept.get(self.edge_chain_precision, (None, None))[0] != stamp:
-                kept[self.edge_chain_precision] = (stamp, kernels.NodeMlpPack(linears, self.edge_chain_precision,
-                                                                              next_projection=projection))
+                kept[self.edge_chain_precision] = (stamp, kernels.NodeMlpPack(
+                    linears, self.edge_chain_precision, next_projection=projection,
+                    scales=self._scales("node", kernels.NodeMlpPack.n_chain_layers(linears), linears[0].weight.device)))
             self._node_mlp = kept[self.edge_chain_precision]
         return self._node_mlp[1]
 

@@ -125,6 +125,13 @@ class EGNNScoreNetwork(ScoreNetwork):
         for layer in self.egnn.graph_layers:
             layer.edge_chain_precision = value
 
+    def adapt_f16_range(self):
+        """What a generator calls after it has recomputed an iteration with the exact-f32 kernels because the split-f16 ones
+        reported a value beyond the f16 range: every graph layer turns the activation maxima that pass collected into
+        per-position exponents for its split-f16 kernels (kernels.ActivationScales; device-side, no host read)."""
+        for layer in self.egnn.graph_layers:
+            layer.adapt_f16_range()
+
     def check_status(self):
         """Raise for any MDX_STATUS_* bit the forward passes have collected (one host read); clears the word."""
         if self.graph_status is not None:

@@ -47,6 +47,11 @@ class ForceFieldAugmentedScoreNetwork(torch.nn.Module):
         if hasattr(self._score_network, "edge_chain_precision"):
             self._score_network.edge_chain_precision = value
 
+    def adapt_f16_range(self):
+        adapt = getattr(self._score_network, "adapt_f16_range", None)
+        if adapt is not None:
+            adapt()
+
     def forward(self, batch: Dict[AnyStr, torch.Tensor], conditional: Optional[bool] = None) -> AXL:
         raw = self._score_network(batch, conditional)
         return AXL(A=raw.A, X=raw.X + self.get_relative_coordinates_pseudo_force(batch), L=raw.L)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 11
+#define MDX_ABI_VERSION 12
 
 /* status codes */
 #define MDX_OK 0
@@ -413,7 +413,24 @@ typedef struct mdx_egnn_chain {
     const float* w_radial;     /* [H]  its weight column for the squared distance            */
     const int32_t* weight_exponents;   /* device, [packed layers + 1]: as written by mdx_egnn_chain_pack; required for
                                           precision 1, ignored (may be NULL) for precision 0 */
+    /* Split-f16 precisions, nullable (NULL: MDX_EGNN_F16_ACTIVATION_EXPONENT everywhere): one power of two per POSITION of the
+     * chain, device, [n_layers + 2], n_layers = n_message_layers + n_coord_layers.  Position q <= n_layers = the operand
+     * entering layer q (0: the first layer's output / the rows handed in; n_layers: what leaves the last layer), position
+     * n_layers + 1 = the rows read back in front of the projection layers of mdx_node_mlp_rows.  The activations carried at
+     * position q are 2^e_q times their value; the f16 range is left at |value| > 65504 / 2^e_q (MDX_STATUS_EGNN_F16_RANGE).
+     * mdx_node_mlp_rows treats positions 0 and 1 as one (position 0's exponent).  Read by the kernel at every launch: a
+     * launch captured into a hipGraph follows later changes of the array. */
+    const int32_t* activation_exponents;
+    /* Precision 0, nullable: device, uint32 [n_layers + 2], the float bits of the largest |carried value| seen at each
+     * position so far (atomic maxima; the caller zero-fills it) -- the input of mdx_egnn_chain_adapt_activation_exponents. */
+    uint32_t* activation_maxima;
 } mdx_egnn_chain_t;
+/* exponents_inout[q] = min(exponents_inout[q], e) with 2^e maxima[q] in [2^12, 2^13) (e clamped to [-14,
+ * MDX_EGNN_F16_ACTIVATION_EXPONENT]) for every position with a recorded maximum; the maxima are zeroed.  Device-side, no host
+ * synchronisation: what a caller runs after an exact-f32 pass that followed an MDX_STATUS_EGNN_F16_RANGE report, so that the
+ * split-f16 kernels carry the hot positions with more headroom from then on. */
+MDX_API int mdx_egnn_chain_adapt_activation_exponents(uint32_t* maxima_inout, int count, int32_t* exponents_inout,
+                                                      mdx_stream_t stream);
 MDX_API int64_t mdx_egnn_chain_image_bytes(int hidden, int n_layers);
 /* tied_layers: bit l set = layer l uses the same power of two as layer l - 1 (the two H x H halves of a Linear(2H, H), whose
  * accumulators continue one another: mdx_node_mlp_rows).  exponents_out: device, [n_layers + 1] (last: the head row's);

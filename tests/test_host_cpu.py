@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert re.search(rf"\sT\s{sym}\b", exported), f"{sym} is declared in include/mdx_hip.h but not exported"
     lib = _hip.lib()                      # loads without a GPU; no compute call is made here
-    assert lib.mdx_abi_version() == _hip.ABI_VERSION == 11
+    assert lib.mdx_abi_version() == _hip.ABI_VERSION == 12
     assert lib.mdx_status_string(-2).decode() == "unsupported size or option"
     # the shared object carries gfx950 code
     assert b"gfx950" in open(_hip.LIB_PATH, "rb").read()

@@ -31,6 +31,7 @@ ap.add_argument("--n-msg", type=int, default=4)
 ap.add_argument("--n-crd", type=int, default=5)
 ap.add_argument("--rows-mode", action="store_true", help="messages as rows (default: piece sums, the product's mode)")
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--any-abi", action="store_true", help="accept libraries of another MDX_ABI_VERSION (A/B against an older build)")
 ap.add_argument("--warm-seconds", type=float, default=1.0, help="back-to-back launches before timing (clock settles)")
 args = ap.parse_args()
 
@@ -42,6 +43,11 @@ for entry in args.libs.split(","):
     modes.append(mode or args.mode)
     path = tree if entry == "tree" else os.path.abspath(entry)
     _hip._lib, _hip.LIB_PATH = None, path
+    if args.any_abi:          # (an older build of the library: its structs are prefixes of today's)
+        import ctypes
+        probe = ctypes.CDLL(path)
+        probe.mdx_abi_version.restype = ctypes.c_int
+        _hip.ABI_VERSION = probe.mdx_abi_version()
     handles.append(_hip.lib())
     names.append(("tree" if entry == "tree" else os.path.basename(path).replace("libmdx_", "").replace(".so", "")) +
                  (":" + mode if mode else ""))
