@@ -43,11 +43,22 @@ for entry in args.libs.split(","):
     modes.append(mode or args.mode)
     path = tree if entry == "tree" else os.path.abspath(entry)
     _hip._lib, _hip.LIB_PATH = None, path
-    if args.any_abi:          # (an older build of the library: its structs are prefixes of today's)
+    if args.any_abi:          # (an older build of the library: its structs are prefixes of today's, some entry points absent)
         import ctypes
-        probe = ctypes.CDLL(path)
-        probe.mdx_abi_version.restype = ctypes.c_int
-        _hip.ABI_VERSION = probe.mdx_abi_version()
+
+        class Tolerant:
+            def __init__(self, lib):
+                self.lib = lib
+
+            def __getattr__(self, name):
+                try:
+                    return getattr(self.lib, name)
+                except AttributeError:
+                    return type("Absent", (), {})()
+
+        old = ctypes.CDLL(path)
+        _hip._declare(Tolerant(old))
+        _hip._lib = old
     handles.append(_hip.lib())
     names.append(("tree" if entry == "tree" else os.path.basename(path).replace("libmdx_", "").replace(".so", "")) +
                  (":" + mode if mode else ""))
