@@ -721,7 +721,7 @@ __device__ __forceinline__ void linear_wave(WP wt, WP bias, lds_cf* in, int in_d
         if constexpr (QUAD) {
             lds_cf4* w = (lds_cf4*)wt + j;
             const int kq = (in_dim + 3) >> 2;
-#pragma unroll 4
+#pragma unroll 8
             for (int q = 0; q < kq; ++q) {
                 const lds_f4 wv = w[q * out_dim];
                 const lds_f4 v = in4[q];                                           // input padded with zeros
@@ -882,6 +882,34 @@ __global__ __launch_bounds__(kBlock) void mlp_pack_image_kernel(mdx_mlp_t m, flo
     write_mlp_image(m, o, image);
 }
 
+// ---- generic instantiation with the input embeddings and the output heads FOLDED (any dimensions) ---------------------
+// The same algebra as the register-resident family below (mdx_mlp_t.folded_input / folded_output, formed by the host in
+// binary64 for any network): [cos | sin | sigma | t | atom-type embeddings | lattice embedding] -> hidden 0 is ONE linear map
+// and (last hidden layer, three heads) is ONE linear map, so a forward is n_hidden layers instead of n_hidden + 2 and the
+// software sincospi of the layer-by-layer form becomes the hardware v_cos / v_sin (argument in revolutions).  The two folded
+// matrices ride behind the workgroup's LDS image.  Pays when the folded first layer is smaller than the two it replaces (small
+// structures: the coordinate embedding 2 N d -> e_c is a low-rank factor for large N); the host decides (mlp_fold_pays).
+__host__ __device__ inline int mlp_folded_inputs(const mdx_mlp_t& m)
+{
+    return 2 * m.number_of_atoms * m.spatial_dimension + 2 + m.number_of_atoms * m.e_atom_type + m.e_lattice;
+}
+__host__ __device__ inline int mlp_outputs(const mdx_mlp_t& m)
+{
+    const int N = m.number_of_atoms, d = m.spatial_dimension;
+    return N * m.num_classes + N * d + d * (d + 1) / 2;
+}
+// floats of the two folded blobs: [ceil(in / 4)][H][4] + bias [H]; [ceil(H / 4)][outputs][4] + bias [outputs]
+__host__ __device__ inline int mlp_folded_in_floats(const mdx_mlp_t& m) { return ((mlp_folded_inputs(m) + 3) & ~3) * m.hidden_size + m.hidden_size; }
+__host__ __device__ inline int mlp_folded_out_floats(const mdx_mlp_t& m) { return ((m.hidden_size + 3) & ~3) * mlp_outputs(m) + mlp_outputs(m); }
+inline bool mlp_fold_pays(const mdx_mlp_t& m)
+{
+    if (!m.folded_input || !m.folded_output || m.n_hidden < 2) return false;
+    const int64_t N = m.number_of_atoms, d = m.spatial_dimension, H = m.hidden_size;
+    const int64_t in0 = m.e_coordinates + m.e_noise + m.e_time + N * m.e_atom_type + m.e_lattice;
+    const int64_t plain = 2 * N * d * m.e_coordinates + in0 * H + H * H, folded = (int64_t)mlp_folded_inputs(m) * H;
+    return folded < plain;      // (the heads' H x outputs product is common to both)
+}
+
 // MLPScoreNetwork forward for ONE structure by one wavefront (mlp_score_network.py:281-370).
 // buf_a / buf_b: this wavefront's LDS scratch of mlp_scratch_floats() floats each.
 template <bool QUAD, typename W>
@@ -942,6 +970,49 @@ __device__ __forceinline__ void mlp_forward_wave(const mdx_mlp_t& m, const W& w,
     }
     wave_sync();
     for (int n = lane; n < N; n += kWave) logits[n * C + C - 1] = -__builtin_huge_valf();
+    wave_sync();
+}
+
+// The folded form of mlp_forward_wave (LDS image + the two folded blobs `fin`, `fout` in LDS); n_hidden >= 2.
+__device__ __forceinline__ void mlp_forward_wave_folded(const mdx_mlp_t& m, const MlpWeightsLds& w, lds_cf* fin, lds_cf* fout,
+                                                        int lane, lds_cf* x, lds_ci64* a, lds_cf* l, float time, float sigma,
+                                                        lds_f* buf_a, lds_f* buf_b, lds_f* logits)
+{
+    const int N = m.number_of_atoms, d = m.spatial_dimension, C = m.num_classes, nl = d * (d + 1) / 2, H = m.hidden_size;
+    const int nd = N * d, ea = m.e_atom_type, el = m.e_lattice;
+    const int in_f = mlp_folded_inputs(m), nt = mlp_outputs(m);
+    for (int e = lane; e < nd; e += kWave) {
+        const float xv = x[e];                                   // hardware cos / sin of 2 pi x: the argument is in revolutions
+        buf_a[e] = __builtin_amdgcn_cosf(xv);
+        buf_a[nd + e] = __builtin_amdgcn_sinf(xv);
+    }
+    if (lane == 0) buf_a[2 * nd] = sigma;
+    if (lane == 1) buf_a[2 * nd + 1] = time;
+    for (int t = lane; t < N * ea; t += kWave) {                 // Linear(one_hot(a)) = W[:, a] + b
+        const int n = t / ea, e = t - n * ea;
+        buf_a[2 * nd + 2 + t] = w.wa[(int)a[n] * ea + e] + w.ba[e];
+    }
+    for (int j = lane; j < el; j += kWave) {
+        float acc = w.bl[j];
+        for (int k = 0; k < nl; ++k) acc = __builtin_fmaf(w.wl[k * el + j], l[k], acc);
+        buf_a[2 * nd + 2 + N * ea + j] = acc;
+    }
+    if (lane < 4) buf_a[in_f + lane] = 0.0f;                     // zero padding read by the four-wide layer loop
+    wave_sync();
+    linear_wave<true>(fin, fin + ((in_f + 3) & ~3) * H, buf_a, in_f, H, buf_b, lane, true);
+    if (lane < 4) buf_b[H + lane] = 0.0f;
+    wave_sync();
+    lds_f* in = buf_b;
+    lds_f* out = buf_a;
+    for (int k = 1; k + 1 < m.n_hidden; ++k) {
+        linear_wave<true>(w.wh(k), w.bh(k), in, H, H, out, lane, true);
+        if (lane < 4) out[H + lane] = 0.0f;
+        wave_sync();
+        lds_f* t = in; in = out; out = t;
+    }
+    linear_wave<true>(fout, fout + ((H + 3) & ~3) * nt, in, H, nt, logits, lane, false);    // logits | score_x | score_l
+    wave_sync();
+    for (int n = lane; n < N; n += kWave) logits[n * C + C - 1] = -__builtin_huge_valf();   // MASK logit (score_network.py:183-185)
     wave_sync();
 }
 
@@ -1030,9 +1101,9 @@ __device__ __forceinline__ void mlp_forward_regs(const MlpWeightsLds& w, const M
 
 __host__ __device__ inline int mlp_scratch_floats(const mdx_mlp_t& m)
 {
-    const int N = m.number_of_atoms, d = m.spatial_dimension;
+    const int N = m.number_of_atoms;
     const int in0 = m.e_coordinates + m.e_noise + m.e_time + N * m.e_atom_type + m.e_lattice;
-    int mx = 2 * N * d;
+    int mx = mlp_folded_inputs(m);                           // >= 2 N d: the input vector of the folded first layer
     if (in0 > mx) mx = in0;
     if (m.hidden_size > mx) mx = m.hidden_size;
     return ((mx + 3) & ~3) + 4;                              // + zero padding for the four-wide layer loop
@@ -1200,6 +1271,7 @@ struct MlpSampleArgs {
     PcArgs pc;               // flags, schedule, rng, dims (pointers unused)
     mdx_mlp_t mlp;
     int M, types_in_corrector, start_index, n_iterations;
+    int fold;                // generic instantiation: the folded forward (mlp_forward_wave_folded); the blobs sit behind the image
     int diag_skip;           // diagnostics / tests (MDX_DIAG_SKIP bits): 1 = no forward, 2 = no update, 8 = no hoisted softmax
     int64_t* a;
     float *x, *l;
@@ -1352,6 +1424,9 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
     const int N = m.number_of_atoms, d = m.spatial_dimension, nl = d * (d + 1) / 2;
     const MlpOffsets off = mlp_offsets(m);
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    // generic instantiation, folded forward: the two folded blobs behind the LDS image, in front of the wavefronts' regions
+    [[maybe_unused]] lds_cf* fold_in = nullptr;
+    [[maybe_unused]] lds_cf* fold_out = nullptr;
     auto run = [&](const auto& w, lds_f* scratch) {
         const MlpWaveLds r = carve_wave_lds(m, scratch + wave * mlp_wave_floats(m));
         [[maybe_unused]] MlpRegs regs;
@@ -1408,7 +1483,14 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
                         else if constexpr (spec_folded(SPEC) && LDS_WEIGHTS)
                             mlp_forward_folded(w, folded, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b,
                                                r.logits);
-                        else
+                        else if constexpr (SPEC == 0 && LDS_WEIGHTS) {
+                            if (p.fold)
+                                mlp_forward_wave_folded(m, w, fold_in, fold_out, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma,
+                                                        r.buf_a, r.buf_b, r.logits);
+                            else
+                                mlp_forward_wave<LDS_WEIGHTS>(m, w, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a,
+                                                              r.buf_b, r.logits, r.sx, r.sl);
+                        } else
                             mlp_forward_wave<LDS_WEIGHTS>(m, w, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a,
                                                           r.buf_b, r.logits, r.sx, r.sl);
                     }
@@ -1445,8 +1527,20 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
     };
     if constexpr (LDS_WEIGHTS) {
         const MlpWeightsLds w = weights_to_lds(m, off, lds);
+        int extra = 0;
+        if constexpr (SPEC == 0) {
+            if (p.fold) {
+                const int n_in = mlp_folded_in_floats(m), n_out = mlp_folded_out_floats(m);
+                lds_f* blob = lds + off.total;
+                for (int e = threadIdx.x; e < n_in; e += blockDim.x) blob[e] = m.folded_input[e];
+                for (int e = threadIdx.x; e < n_out; e += blockDim.x) blob[n_in + e] = m.folded_output[e];
+                fold_in = blob;
+                fold_out = blob + n_in;
+                extra = (n_in + n_out + 3) & ~3;
+            }
+        }
         __syncthreads();
-        run(w, lds + off.total);
+        run(w, lds + off.total + extra);
     } else {
         run(weights_global(m), lds);
     }
@@ -2455,10 +2549,16 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
         if (hipGetLastError() != hipSuccess) return MDX_ERR_HIP;
     }
     if (in_lds) {
-        const size_t lds = per_wave * kMlpWaves + image;
+        size_t lds = per_wave * kMlpWaves + image;
         // 0: generic instantiation; 1: template dimensions as literals, layer by layer; >= 100: the register-resident family
         // with the folded input / output layers (100 + 10 C + NH)
         const int spec = mlp_sampler_variant(*mlp_host, options);
+        // the generic instantiation runs the folded forward when the caller supplied the folded matrices, it pays and fits
+        const size_t blobs = sizeof(float) * (((size_t)mlp_folded_in_floats(*mlp_host) + mlp_folded_out_floats(*mlp_host) + 3) & ~(size_t)3);
+        if (spec == 0 && !(options & MDX_MLP_SAMPLE_UNFOLDED) && mlp_fold_pays(*mlp_host) && lds + blobs <= 2 * kMlpLdsBudget) {
+            a.fold = 1;
+            lds += blobs;
+        }
         if (lds > kMlpLdsBudget) {       // up to 128 KiB of the CU's 160 KiB: opt in above the 64 KiB default
             // the attribute is a property of the code object: set it when the requirement grows, not on every launch
             // (per device: a process that samples on a second GPU must opt in there as well)

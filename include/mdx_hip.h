@@ -320,7 +320,9 @@ MDX_API int mdx_mlp_forward(const mdx_mlp_t* mlp_host, const int64_t* atom_types
  *   rec0 = [ z N*d | gumbel N*C | u N | table 8 ]  (table[7] = 0: "no per-step posterior table", always valid)
  *   rec1 = rec0 if atom_type_transition_in_corrector else [ z N*d ]. */
 #define MDX_MLP_SAMPLE_GENERIC_KERNEL 1u    /* never select a dimension-specialised instantiation                       */
-#define MDX_MLP_SAMPLE_UNFOLDED 2u          /* layer-by-layer forward even when folded_input / folded_output are given  */
+#define MDX_MLP_SAMPLE_UNFOLDED 2u          /* layer-by-layer forward even when folded_input / folded_output are given
+                                             * (the generic kernel too uses them, for any dimensions, when the folded first
+                                             * layer is smaller than the two it replaces and the matrices fit in LDS)   */
 #define MDX_MLP_SAMPLE_CALLER_NOISE 4u      /* noise_workspace already holds the records (parity tests replay the
                                                reference's recorded draws): the pre-pass is skipped; the whole segment
                                                must fit the workspace                                                    */

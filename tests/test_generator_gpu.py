@@ -842,6 +842,47 @@ def test_fused_sampler_folded_input_layer(cuda, monkeypatch):
     assert (results["1", 40].A != 1).all()
 
 
+@pytest.mark.parametrize("n_atoms,nat,hidden,n_hidden,fits", [(8, 1, 64, 3, True), (5, 4, 48, 2, True), (12, 1, 64, 2, True),
+                                                              (8, 2, 64, 4, True), (8, 2, 128, 2, False)])
+def test_fused_sampler_generic_folded_forward(cuda, n_atoms, nat, hidden, n_hidden, fits):
+    """The GENERIC instantiation of the persistent sampler (any MLP shape) with the folded forward -- input embeddings folded into
+    the first hidden layer, last hidden layer folded into the heads, hardware sin / cos (round 4; what shapes outside the
+    register-resident family run) -- against its layer-by-layer form (MLP_SAMPLE_UNFOLDED): the same function, last-bit
+    different rounding.  One iteration from the same state: atom types exact, coordinates within 1e-6; a whole trajectory of a
+    neutral configuration (linear schedule): atom types exact, coordinates within 1e-5."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+    import warnings
+    P = _pkg()
+    torch.manual_seed(77)
+    net = nets.mlp_net(n_atoms, nat, hidden=hidden, n_hidden=n_hidden).to(cuda)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = P["Noise"](**cases.noise_ns(40, **cases.LIN))
+        spar = P["Sampling"](**cases.sampling_ns(n_atoms, nat), rng_mode="device", seed=3, fused_score_network=True)
+    gen = LangevinGenerator(npar, spar, net)
+    with torch.no_grad():
+        sched = gen._prepare(cuda)
+        gen._begin_call(cuda)
+        start = gen.initialize(150, cuda)
+        pack = gen.fused_pack(cuda)
+        assert pack.c_struct.folded_input and pack.c_struct.folded_output
+        results = {}
+        for name, options in (("folded", _hip.MLP_SAMPLE_GENERIC_KERNEL), ("plain", _hip.MLP_SAMPLE_GENERIC_KERNEL | _hip.MLP_SAMPLE_UNFOLDED)):
+            for n_iterations in (1, 40):
+                comp = RS.AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
+                kernels.mlp_pc_sample(sched, pack, gen._flags(True), 1, False, 40, n_iterations, gen._rng(0), comp.A, comp.X,
+                                      comp.L, gen._status, workspace=gen._noise_workspace, options=options)
+                results[name, n_iterations] = _np(comp)
+    for n_iterations, tol in ((1, 1e-6), (40, 1e-5)):
+        a, b = results["folded", n_iterations], results["plain", n_iterations]
+        assert np.array_equal(a.A, b.A), n_iterations
+        assert torus_rel_l2(a.X, b.X) < tol, (n_iterations, torus_rel_l2(a.X, b.X))
+    if fits:      # (hidden 128: the weight image alone exceeds the LDS budget, the kernel reads global weights, unfolded)
+        assert not np.array_equal(results["folded", 40].X.view(np.int32), results["plain", 40].X.view(np.int32)), \
+            "the folded forward did not run (same bits as the layer-by-layer form)"
+
+
 # -------------------------------------------------------------------------------------------------------------
 # EGNN helpers: library GEMM with fused bias+SiLU epilogue, fused first message layer
 # -------------------------------------------------------------------------------------------------------------
