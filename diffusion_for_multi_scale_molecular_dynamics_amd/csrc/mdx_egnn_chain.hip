@@ -507,10 +507,10 @@ struct Chain {
 // and a NaN one layer later, in every feature of its edge: it reaches the kernel's outputs, where it is looked for.  Branch-free, so that it is one scheduling region with the MFMAs around
 // it.  tp, r0, r1 are constants after unrolling.
 // `linear` (wave-uniform): the tile belongs to a layer without activation (the last layer of a row chain): u = z, a select.
-// `amax` (exact-f32 kernels; nullable): running maximum of |u| over the values written (ChainArgs::act_max).
+// `amax` (exact-f32 kernels only): running maximum of |u| over the values written (ChainArgs::act_max).
 template <int H, int PREC>
 __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const f32x16& pend, Act<H, PREC>& dst,
-                                                  const Scale& sc, bool linear = false, float* amax = nullptr)
+                                                  const Scale& sc, bool linear, float& amax)
 {
     // split-f16: the accumulator is 2^(a+b) z (struct Scale): -z, then 2^b z / (1 + 2^-z) with the divisor pre-scaled
     auto act = [&](float A) -> float {
@@ -524,7 +524,7 @@ __device__ __forceinline__ void epilogue_elements(int tp, int r0, int r1, const 
         if constexpr (PREC == 0) {
             // (one value at a time: in pairs this instantiation nearly doubles its run time -- 7.25 -> 12.9 ms at H = 256)
             const float y = linear ? lin(pend[r]) : act(pend[r]);
-            if (amax) *amax = __builtin_fmaxf(*amax, __builtin_fabsf(y));
+            amax = __builtin_fmaxf(amax, __builtin_fabsf(y));
             put<H>(dst, tp, r, y);
         } else if (!(r & 1)) {
             const float y0 = linear ? lin(pend[r]) : act(pend[r]), y1 = linear ? lin(pend[r + 1]) : act(pend[r + 1]);
@@ -877,7 +877,6 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         // exact-f32 kernels with ChainArgs::act_max: the largest |u| this lane has written since the last flush_max(); a flush
         // reduces it over the wavefront and raises the position's word (float bits of non-negative values order like integers)
         float amax = 0.0f;
-        float* const amax_p = PREC == 0 ? &amax : nullptr;
         auto note4 = [&](float y0, float y1, float y2, float y3) {
             if constexpr (PREC == 0)
                 amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(y0), __builtin_fabsf(y1))),
@@ -1048,9 +1047,9 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     // (16x16 shape: ALL sixteen values of the pending tile are elements of ONE k-step of the next layer, the one
                     // this tile reads in its last two steps when it is that layer's first tile: complete before those steps)
                     constexpr int D = STEPS > 2 ? STEPS - 2 : 1;
-                    if (have && s < D) epilogue_elements<H, PREC>(tp, 16 * s / D, 16 * (s + 1) / D, pend, epi_dst, epi_sc, ROWS && linear, amax_p);
+                    if (have && s < D) epilogue_elements<H, PREC>(tp, 16 * s / D, 16 * (s + 1) / D, pend, epi_dst, epi_sc, ROWS && linear, amax);
                 } else {
-                    if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, epi_sc, ROWS && linear, amax_p);
+                    if (have) epilogue_elements<H, PREC>(tp, 16 * s / STEPS, 16 * (s + 1) / STEPS, pend, epi_dst, epi_sc, ROWS && linear, amax);
                 }
                 // one weight-stream request per STEPS / LPW k-steps, behind the step's first MFMA; g = steps since the acquire
                 constexpr int PERIOD = STEPS / C::LPW;
@@ -1227,7 +1226,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         };
         // MODE 1: the last tile of the last (linear) layer has no tile after it to run beside; then out = residual + y
         auto finish_rows = [&](Act<H, PREC>& y, Act<H, PREC>& u) {
-            epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, y, sc_prev, true, amax_p);
+            epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, y, sc_prev, true, amax);
             flush_max(layers);
             const bool project = MODE == 3 && p.proj_out != nullptr;       // out is also the operand of two more linear layers
             const float kOut = end_factor(2);
