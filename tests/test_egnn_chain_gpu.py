@@ -672,16 +672,18 @@ class _RangeReportAt(torch.nn.Module):
         return out
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16x3_32x32"])
+@pytest.mark.parametrize("precision,repaint", [("f16x3", False), ("f16x3_32x32", False), ("f16x3", True)])
 @pytest.mark.parametrize("use_graph", [True, False])
 @pytest.mark.parametrize("M,flagged", [(0, 1), (2, 2)])
-def test_f16_range_fallback_costs_one_iteration(cuda, M, flagged, use_graph, precision):
+def test_f16_range_fallback_costs_one_iteration(cuda, M, flagged, use_graph, precision, repaint):
     """The f16-range report is handled per ITERATION: a run whose network reports the range bit
     at one time value only -- seen by ONE iteration with no correctors, by two neighbouring ones with correctors (an
     iteration's correctors and the next iteration's predictor share a time value) -- completes with exactly that many
     iterations recomputed in f32, and its result equals, bit for bit, a run in which exactly those iterations were computed
     with the f32 kernels and all the others with the split-f16 kernels.  Both loops (hipGraph replays watched two iterations
-    behind the queue; eager steps), both split modes; the iterations queued behind the flagged one are dropped and repeated."""
+    behind the queue; eager steps), both split modes; the iterations queued behind the flagged one are dropped and repeated.
+    `repaint`: the constrained generator with one resampling pass per time index (each iteration = two predictor / corrector
+    visits and a forward step; the redone iteration runs all of them eagerly in f32)."""
     from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
     from diffusion_for_multi_scale_molecular_dynamics_amd.generators.predictor_corrector_axl_generator import \
         PredictorCorrectorSamplingParameters
@@ -699,7 +701,17 @@ def test_f16_range_fallback_costs_one_iteration(cuda, M, flagged, use_graph, pre
             npar = NoiseParameters(**cases.noise_ns(T, **cases.LIN))
             spar = PredictorCorrectorSamplingParameters(**cases.sampling_ns(64, 1, M=M, greedy=False, one=False, cell=[10.86] * 3),
                                                         rng_mode="device", seed=5, use_hip_graph=use_graph and wrap)
-        gen = LangevinGenerator(npar, spar, net)
+        if repaint:
+            from diffusion_for_multi_scale_molecular_dynamics_amd.generators.constrained_langevin_generator import \
+                ConstrainedLangevinGenerator
+            from diffusion_for_multi_scale_molecular_dynamics_amd.generators.sampling_constraint import SamplingConstraint
+            spar.repaint_resampling_steps = 1
+            g = torch.Generator().manual_seed(8)
+            constraint = SamplingConstraint(elements=["Si"], constrained_relative_coordinates=torch.rand(20, 3, generator=g),
+                                            constrained_atom_types=torch.zeros(20, dtype=torch.long))
+            gen = ConstrainedLangevinGenerator(npar, spar, net, constraint)
+        else:
+            gen = LangevinGenerator(npar, spar, net)
         gen._prepare(cuda)
         if wrap:
             gen.axl_network = _RangeReportAt(net, float(gen.noise.time[k]))
@@ -719,6 +731,8 @@ def test_f16_range_fallback_costs_one_iteration(cuda, M, flagged, use_graph, pre
             in_f32 = i == k or (M > 0 and i == k + 1)       # predictor of k; correctors of k + 1 (time index k + 1: time[k])
             ref_net.edge_chain_precision = "f32" if in_f32 else precision
             comp = ref._iteration(comp, i, forces)
+        if repaint:
+            comp = ref._apply_constraint(comp, cuda)          # (what ConstrainedLangevinGenerator.sample does at the end)
         ref.check_status()
     assert torch.equal(got.A, comp.A) and torch.equal(got.X, comp.X)
     assert torch.isfinite(got.X).all() and (got.A == 0).all()
