@@ -24,8 +24,9 @@ def _minimum_image_distances(X):
     return np.sqrt((d * d).sum(-1))                    # [B, N, N]
 
 
-def statistics(X, per_atom=False):
-    """dict name -> 1-D float64 array of the scalars listed in the module docstring."""
+def statistics(X, per_atom=False, sites=None):
+    """dict name -> 1-D float64 array of the scalars listed in the module docstring; with `sites` [N, 3] also `disp`: the
+    displacement of every coordinate from its site, wrapped to [-1/2, 1/2)."""
     X = np.asarray(X)
     B, N, _ = X.shape
     r = _minimum_image_distances(X)
@@ -35,6 +36,9 @@ def statistics(X, per_atom=False):
     out["nn"] = r.min(-1).ravel()
     for k, axis in enumerate("xyz"):
         out[axis] = X[..., k].astype(np.float64).ravel()
+    if sites is not None:
+        u = X.astype(np.float64) - np.asarray(sites, np.float64)[None]
+        out["disp"] = (u - np.round(u)).ravel()
     if per_atom:
         for n in range(N):
             for k, axis in enumerate("xyz"):

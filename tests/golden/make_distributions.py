@@ -10,6 +10,8 @@ and the KS distance of deliberately WRONG samplers to the pool (the power of the
   dist_mlp_c2.npz   BASELINE configs[1]: the MLP template (weights = tests/golden/net_mlp_c1.npz: `_mlp(8, 1)`), N = 8, T = 1000,
                     sigma 1e-4 .. 0.25 exponential, M = 1, greedy + one-transition defaults, 1024 structures per seed
                     (src/.../generators/langevin_generator.py:27-831 through src/.../sampling/diffusion_sampling.py:16-73)
+  dist_analytic.npz the reference's AnalyticalScoreNetwork (exact score of Gaussians of width 0.05 around the diamond sites of
+                    Si 1x1x1), T = 200, sigma 1e-4 .. 0.25 exponential, M = 1, 1024 structures x 48 seeds: the case with POWER
   dist_egnn_rc.npz  a small radial-cutoff EGNN (hidden 32, 2 graph layers; weights = tests/golden/traj_egnn_rc.npz), N = 64,
                     cell 10.86, T = 100 of configs[2]'s linear schedule, M = 2, 64 structures per seed; its coordinate score x 100
                     (see egnn_rc below: with the bare random-init network the check would have no power)
@@ -26,6 +28,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))      # (tests/cases.py imports the product's torch modules)
 import make_golden as G  # noqa: E402  (installs the stubs, imports the reference)
 import distribution_stats as DS  # noqa: E402
 
@@ -45,7 +48,7 @@ class ScaledScore(torch.nn.Module):
         return G.AXL(A=out.A, X=out.X * self.factor, L=out.L)
 
 
-def run(make, seeds, batch, per_atom, name, probes, extra=None):
+def run(make, seeds, batch, per_atom, name, probes, extra=None, sites=None, probe_calls=1):
     per_seed = []
     for seed in seeds:
         gen = make()
@@ -54,7 +57,7 @@ def run(make, seeds, batch, per_atom, name, probes, extra=None):
         with torch.no_grad():
             axl = gen.sample(batch, torch.device("cpu"))
         assert (axl.A != gen.num_classes - 1).all()
-        per_seed.append(DS.statistics(axl.X.numpy(), per_atom=per_atom))
+        per_seed.append(DS.statistics(axl.X.numpy(), per_atom=per_atom, sites=sites))
         print(f"{name}: seed {seed} done in {time.perf_counter() - t0:.1f} s", flush=True)
     keys = list(per_seed[0])
     out = {"seeds": np.array(seeds), "batch": np.array(batch), "scalars": np.array(keys)}
@@ -79,15 +82,23 @@ def run(make, seeds, batch, per_atom, name, probes, extra=None):
             b = np.concatenate([per_seed[i][key] for i in order[len(seeds) // 2:]])
             halves.append(DS.ks_two_sample(a, b))
         out[f"half_split/{key}"] = np.array(halves)
+    out["probe_calls"] = np.array(probe_calls)
     for probe, make_wrong in probes.items():
-        gen = make_wrong()
-        torch.manual_seed(seeds[0])
-        with torch.no_grad():
-            axl = gen.sample(batch, torch.device("cpu"))
-        stats = DS.statistics(axl.X.numpy(), per_atom=per_atom)
+        calls = []
+        for c in range(probe_calls):          # the wrong sampler's calls: the first alone, and all of them pooled
+            gen = make_wrong()
+            torch.manual_seed(seeds[0] + 1000 * c)
+            with torch.no_grad():
+                axl = gen.sample(batch, torch.device("cpu"))
+            calls.append(DS.statistics(axl.X.numpy(), per_atom=per_atom, sites=sites))
         for key in keys:
-            out[f"probe/{probe}/{key}"] = np.array(DS.ks_to_table(stats[key], out[f"table/{key}"].astype(np.float64)))
-        print(f"{name}: probe {probe}: " + ", ".join(f"{k} {float(out[f'probe/{probe}/{k}']):.3f}" for k in keys[:5]), flush=True)
+            table = out[f"table/{key}"].astype(np.float64)
+            out[f"probe/{probe}/{key}"] = np.array(DS.ks_to_table(calls[0][key], table))
+            if probe_calls > 1:
+                out[f"probe_pooled/{probe}/{key}"] = np.array(DS.ks_to_table(np.concatenate([c[key] for c in calls]), table))
+        print(f"{name}: probe {probe}: " + ", ".join(f"{k} {float(out[f'probe/{probe}/{k}']):.3f}" for k in keys[:5]) +
+              (" | pooled: " + ", ".join(f"{k} {float(out[f'probe_pooled/{probe}/{k}']):.4f}" for k in keys[:5]) if probe_calls > 1 else ""),
+              flush=True)
     for key in keys[:5]:
         print(f"{name}: {key}: leave-one-out {out[f'leave_one_out/{key}'].round(4)}  pairwise max {out[f'pairwise/{key}'].max():.4f}")
     out.update(extra or {})
@@ -128,8 +139,62 @@ def egnn_rc():
         extra={"score_factor": np.array(EGNN_SCORE_FACTOR)})
 
 
+ANALYTIC = dict(number_of_atoms=8, kmax=4, sigma_d=0.05, T=200, sigma_min=1e-4, sigma_max=0.25)
+
+
+def analytic():
+    """A case where the score MATTERS by construction: the reference's AnalyticalScoreNetwork
+    (src/.../models/score_networks/analytical_score_network.py:63-298) -- the exact score of independent wrapped Gaussians of
+    width sigma_d around the eight diamond sites of Si 1x1x1 -- under the reference's LangevinGenerator (T = 200, sigma
+    1e-4 .. 0.25 exponential, M = 1): the sampler must CONTRACT the uniform initial cloud onto the sites, and the final width
+    depends on every factor of the update (g^2, epsilon, the score's weight).  1024 structures x 48 seeds.  Besides the
+    statistics of the other cases, `disp` = the displacement of every coordinate from its site (wrapped to [-1/2, 1/2)).
+    Also stored: a forward of the reference's network on random inputs, to pin the tests' own restatement of it."""
+    from diffusion_for_multi_scale_molecular_dynamics.models.score_networks.analytical_score_network import (
+        AnalyticalScoreNetwork, AnalyticalScoreNetworkParameters)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from cases import diamond_sites
+    sites = diamond_sites(1)
+    c = ANALYTIC
+
+    def network():
+        return AnalyticalScoreNetwork(AnalyticalScoreNetworkParameters(
+            number_of_atoms=c["number_of_atoms"], kmax=c["kmax"], sigma_d=c["sigma_d"], spatial_dimension=3, num_atom_types=1,
+            equilibrium_relative_coordinates=sites.tolist()))
+
+    kw = dict(T=c["T"], N=c["number_of_atoms"], num_atom_types=1, M=1,
+              noise_kw=dict(sigma_min=c["sigma_min"], sigma_max=c["sigma_max"]))
+
+    def make(net=None, **over):
+        return G.make_generator(net=net or network(), **dict(kw, **over))[0]
+    probes = {
+        "zero_score": lambda: make(net=ScaledScore(network(), 0.0)),
+        "score_x0.9": lambda: make(net=ScaledScore(network(), 0.9)),
+        "score_x0.97": lambda: make(net=ScaledScore(network(), 0.97)),
+        "no_corrector": lambda: make(M=0),
+        "sigma_max_0.2": lambda: make(noise_kw=dict(sigma_min=c["sigma_min"], sigma_max=0.2)),
+        "sigma_min_1e-2": lambda: make(noise_kw=dict(sigma_min=1e-2, sigma_max=c["sigma_max"])),
+    }
+    g = torch.Generator().manual_seed(4040)
+    B = 6
+    x = torch.rand(B, c["number_of_atoms"], 3, generator=g)
+    sig = torch.tensor([1e-4, 1e-3, 1e-2, 0.05, 0.15, 0.25]).reshape(B, 1)
+    batch = {G.NOISY_AXL_COMPOSITION: G.AXL(A=torch.zeros(B, c["number_of_atoms"], dtype=torch.long), X=x,
+                                            L=torch.tensor([5.43, 5.43, 5.43, 0, 0, 0.0]).repeat(B, 1)),
+             G.TIME: torch.rand(B, 1, generator=g), G.NOISE: sig, G.CARTESIAN_FORCES: torch.zeros(B, c["number_of_atoms"], 3)}
+    with torch.no_grad():
+        out = network()(batch, conditional=False)
+    extra = {"forward/X": G._np(x), "forward/sigma": G._np(sig), "forward/out_X": G._np(out.X), "forward/out_A": G._np(out.A),
+             "sites": G._np(sites), "settings": np.array([c[k] for k in ("number_of_atoms", "kmax", "sigma_d", "T", "sigma_min", "sigma_max")],
+                                                          dtype=np.float64)}
+    run(make, seeds=list(range(101, 149)), batch=1024, per_atom=False, name="dist_analytic", probes=probes, extra=extra,
+        sites=G._np(sites), probe_calls=24)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "analytic"):
+        analytic()
     if which in ("all", "mlp"):
         mlp_c2()
     if which in ("all", "egnn"):

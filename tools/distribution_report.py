@@ -59,6 +59,19 @@ with torch.no_grad(), warnings.catch_warnings():
         print(f"   reference-side wrong sampler {probe:14s}: " + ", ".join(f"{k} {float(g[f'probe/{probe}/{k}']):.4f}" for k in T.POOLED) +
               f", largest / mean per-atom marginal {d.max():.4f} / {d.mean():.4f}  -> {'rejected' if T.probe_fails(g, probe) else 'not seen'}")
 
+    g = load_golden("dist_analytic.npz")
+    noise_kw, sampling_kw, net = T.analytic_case(g)
+    for use_graph in (True, False):
+        gen = P["Langevin"](P["Noise"](**noise_kw), P["Sampling"](**sampling_kw, rng_mode="device", seed=1717, use_hip_graph=use_graph),
+                            net.to(cuda))
+        summary(f"analytic Gaussian-well score (plugin), N = 8, T = 200, per-step HIP kernels, {'hipGraph' if use_graph else 'eager'}", g,
+                [gen.sample(int(g["batch"]), cuda).X.cpu().numpy() for _ in range(24)])
+    for probe in ("zero_score", "score_x0.9", "score_x0.97", "no_corrector", "sigma_max_0.2", "sigma_min_1e-2"):
+        keys = T.scalars_of(g)
+        print(f"   reference-side wrong sampler {probe:14s}: first call " + ", ".join(f"{k} {float(g[f'probe/{probe}/{k}']):.4f}" for k in keys) +
+              f" | {int(g['probe_calls'])} calls pooled " + ", ".join(f"{k} {float(g[f'probe_pooled/{probe}/{k}']):.4f}" for k in keys) +
+              f"  -> {'rejected' if T.probe_fails(g, probe) else 'not seen'}")
+
     g = load_golden("dist_egnn_rc.npz")
     for precision in ("f16x3", "f32"):
         inner = nets.load_fixture_weights(nets.egnn_net(1, "radial_cutoff", 7.5), load_golden("traj_egnn_rc.npz"))
