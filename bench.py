@@ -342,10 +342,10 @@ def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
     if split:
         note = ("peak = datasheet dense f16 MFMA rate at 2.4 GHz, counting the 3 executed products per algorithmic one.  Measured "
                 "inside the kernel (s_memtime / s_memrealtime) the chip holds " +
-                ("2.03-2.11 GHz on the 16x16x32 shape (2.32 GHz, same cycle count, on all-zero activations: power sets the clock); "
-                 "its one wavefront per SIMD is instruction-issue-bound: ~1 800-2 000 cycles of in-order issue per 1 536 cycles of MFMAs"
-                 if shape16 else "1.80-1.82 GHz on the 32x32x16 shape: power-bound") +
-                " (profiles/r03_chain_ablation.md)")
+                ("1.96-2.11 GHz on the 16x16x32 shape (2.32 GHz, same cycle count, on all-zero activations: power sets the clock); "
+                 "the launch is bounded by its energy, not its cycles: 2.9 % fewer cycles per wavefront in round 4 (bit-identical "
+                 "outputs) left the wall clock where it was (profiles/r04_chain_ablation.md)"
+                 if shape16 else "1.80-1.82 GHz on the 32x32x16 shape: power-bound (profiles/r03_chain_ablation.md)"))
     return dict(bound="mfma", achieved=round(executed, 2), peak=peak, unit="TFLOP/s", frac=round(executed / peak, 4),
                 traffic=traffic, traffic_from=traffic_from,
                 kernel=f"egnn_edge_chain_kernel<{H},{prec_index},{2 if pieces else 0}> ({mfma}"
