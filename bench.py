@@ -631,7 +631,8 @@ def main():
             from diffusion_for_multi_scale_molecular_dynamics_amd import _hip
             generic = {}
             for key, options in (("folded", _hip.MLP_SAMPLE_GENERIC_KERNEL),
-                                 ("layer_by_layer", _hip.MLP_SAMPLE_GENERIC_KERNEL | _hip.MLP_SAMPLE_UNFOLDED)):
+                                 ("layer_by_layer", _hip.MLP_SAMPLE_GENERIC_KERNEL | _hip.MLP_SAMPLE_UNFOLDED),
+                                 ("padded_family", _hip.MLP_SAMPLE_PADDED_FAMILY)):
                 gen.fused_sampler_options = options
                 loop_g = new_loop()
                 advance(loop_g, T, T)
@@ -643,7 +644,12 @@ def main():
                                 trajectory_ms=round(generic["folded"], 4),
                                 value=round((batch * world) / ((generic["folded"] + gather_ms) * 1e-3), 2), unit="structures/s",
                                 layer_by_layer=dict(trajectory_ms=round(generic["layer_by_layer"], 4),
-                                                    value=round((batch * world) / ((generic["layer_by_layer"] + gather_ms) * 1e-3), 2)))
+                                                    value=round((batch * world) / ((generic["layer_by_layer"] + gather_ms) * 1e-3), 2)),
+                                # the same network through the PADDED register-resident family (mlp_pc_sample_kernel<8,true,213>:
+                                # run-time structure dimensions, fixed padded layer sizes): what every MLP configuration of the
+                                # reference outside the exact template runs (hidden <= 64, N <= 8, <= 192 folded inputs)
+                                padded_family=dict(trajectory_ms=round(generic["padded_family"], 4),
+                                                   value=round((batch * world) / ((generic["padded_family"] + gather_ms) * 1e-3), 2)))
 
         roofline = forward_gemm = roofline_hbm = None
         if rank == 0:

@@ -38,6 +38,7 @@ MLP_MAX_HIDDEN = 8
 # options of mdx_mlp_pc_sample (include/mdx_hip.h)
 MLP_SAMPLE_GENERIC_KERNEL, MLP_SAMPLE_UNFOLDED, MLP_SAMPLE_CALLER_NOISE, MLP_SAMPLE_NO_FIXED_SOFTMAX, \
     MLP_SAMPLE_NO_P2_TABLE, MLP_SAMPLE_DIAG_NO_FORWARD, MLP_SAMPLE_DIAG_NO_UPDATE = 1, 2, 4, 8, 16, 256, 512
+MLP_SAMPLE_PADDED_FAMILY = 128
 
 
 class MdxError(RuntimeError):
@@ -78,7 +79,7 @@ class Mlp(C.Structure):
                                    "w_atom_type_t", "b_atom_type", "w_lattice_t", "b_lattice")] + \
         [("w_hidden_t", C.c_void_p * 8), ("b_hidden", C.c_void_p * 8)] + \
         [(n, C.c_void_p) for n in ("w_out_a_t", "b_out_a", "w_out_x_t", "b_out_x", "w_out_l_t", "b_out_l",
-                                   "packed_image", "folded_input", "folded_output")]
+                                   "packed_image", "folded_input", "folded_output", "folded_padded")]
 
 
 class EgnnChain(C.Structure):

@@ -1103,8 +1103,8 @@ __host__ __device__ inline int mlp_scratch_floats(const mdx_mlp_t& m)
 {
     const int N = m.number_of_atoms;
     const int in0 = m.e_coordinates + m.e_noise + m.e_time + N * m.e_atom_type + m.e_lattice;
-    int mx = mlp_folded_inputs(m);                           // >= 2 N d: the input vector of the folded first layer
-    if (in0 > mx) mx = in0;
+    int mx = (mlp_folded_inputs(m) + 63) & ~63;              // >= 2 N d: the input vector of the folded first layer, padded to
+    if (in0 > mx) mx = in0;                                  // the 64-value blocks the padded family reads (and >= 64 neurons)
     if (m.hidden_size > mx) mx = m.hidden_size;
     return ((mx + 3) & ~3) + 4;                              // + zero padding for the four-wide layer loop
 }
@@ -1121,9 +1121,19 @@ __host__ __device__ inline int mlp_scratch_floats(const mdx_mlp_t& m)
 // weight quads = 188 registers, no AGPR traffic -- instead of five.
 // The family of register-resident instantiations: N = 8, d = 3, hidden 64, atom-type / lattice embeddings of size 1 (the
 // reference's template), C in {2, 3} classes and NH in {2, 3, 4} hidden layers.  SPEC = 100 + 10 C + NH.
-constexpr bool spec_folded(int SPEC) { return SPEC >= 100; }
-constexpr int spec_classes(int SPEC) { return SPEC >= 100 ? (SPEC - 100) / 10 : 2; }
-constexpr int spec_hidden_layers(int SPEC) { return SPEC >= 100 ? (SPEC - 100) % 10 : 3; }
+constexpr bool spec_folded(int SPEC) { return SPEC >= 100 && SPEC < 200; }
+constexpr int spec_classes(int SPEC) { return SPEC >= 100 && SPEC < 200 ? (SPEC - 100) / 10 : 2; }
+constexpr int spec_hidden_layers(int SPEC) { return SPEC >= 100 ? (SPEC % 100) % 10 : 3; }
+// The PADDED register-resident family (SPEC = 200 + 10 (FQ / 16) + NH): any MLP with hidden <= 64, N <= 8 atoms,
+// N C + N d + d (d + 1) / 2 <= 64 outputs, a folded input vector of <= 192 values and NH in {2, 3, 4} hidden layers -- every
+// MLP configuration of the reference (its templates and experiments use hidden 16 .. 64 on 2 or 8 atoms with embeddings of 1
+// .. 64).  The host pads the folded matrices with zeros to FIXED sizes (hidden -> 64 neurons, first-layer input -> FQ = 16, 32
+// or 48 quads: mdx_mlp_t.folded_padded), so the layer loops have literal trip counts and the weights of all layers live in
+// the lane's registers (up to 96 quads = 384 of the 512 a lone wavefront per SIMD may use); the dimensions of the structure
+// (N, d, C, embedding sizes) stay run-time values in the input assembly and the update.  A zero quad adds fma(0, 0, s) = s:
+// the same bits as the generic folded forward on the unpadded matrices (tests compare the two bit for bit).
+constexpr bool spec_padded(int SPEC) { return SPEC >= 200; }
+constexpr int spec_first_quads(int SPEC) { return SPEC >= 200 ? 16 * ((SPEC - 200) / 10) : 16; }
 
 template <int C, int NH>
 struct MlpRegsFolded {
@@ -1198,6 +1208,78 @@ __device__ __forceinline__ void mlp_forward_folded(const MlpWeightsLds& w, const
         logits[lane] = (lane < 8 * C && (lane % C) == C - 1) ? -__builtin_huge_valf() : o;
     }
     // no hand-off here: the caller stores the step's noise record next to these outputs and synchronises once
+}
+
+template <int FQ, int NH>
+struct MlpRegsPadded {
+    static constexpr int MID = NH - 2;
+    lds_f4 wf[FQ], wmid[MID > 0 ? MID : 1][16], wfo[16];
+    float bf, bmid[MID > 0 ? MID : 1], bfo;
+};
+
+// mdx_mlp_t.folded_padded: [FQ][64][4] + bias [64] | (NH - 2) x ([16][64][4] + bias [64]) | [16][64][4] + bias [64]
+template <int FQ, int NH>
+__device__ __forceinline__ void load_mlp_regs_padded(MlpRegsPadded<FQ, NH>& R, const mdx_mlp_t& m, int lane)
+{
+    const lds_f4* blob = reinterpret_cast<const lds_f4*>(m.folded_padded);
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) R.wf[q] = blob[q * 64 + lane];
+    R.bf = m.folded_padded[FQ * 256 + lane];
+    const float* at = m.folded_padded + FQ * 256 + 64;
+#pragma unroll
+    for (int k = 0; k < NH - 2; ++k) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) R.wmid[k][q] = reinterpret_cast<const lds_f4*>(at)[q * 64 + lane];
+        R.bmid[k] = at[16 * 256 + lane];
+        at += 16 * 256 + 64;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) R.wfo[q] = reinterpret_cast<const lds_f4*>(at)[q * 64 + lane];
+    R.bfo = at[16 * 256 + lane];
+}
+
+template <int FQ, int NH>
+__device__ __forceinline__ void mlp_forward_padded(const mdx_mlp_t& m, const MlpWeightsLds& w, const MlpRegsPadded<FQ, NH>& R,
+                                                   int lane, lds_cf* x, lds_ci64* a, lds_cf* l, float time, float sigma,
+                                                   lds_f* buf_a, lds_f* buf_b, lds_f* logits)
+{
+    const int N = m.number_of_atoms, d = m.spatial_dimension, C = m.num_classes, nl = d * (d + 1) / 2;
+    const int nd = N * d, ea = m.e_atom_type, el = m.e_lattice;
+    const int in_f = mlp_folded_inputs(m), nt = mlp_outputs(m);
+    // the input vector of the folded first layer, as mlp_forward_wave_folded builds it; zeros up to the padded length
+    for (int e = lane; e < nd; e += kWave) {
+        const float xv = x[e];
+        buf_b[e] = __builtin_amdgcn_cosf(xv);
+        buf_b[nd + e] = __builtin_amdgcn_sinf(xv);
+    }
+    if (lane == 0) buf_b[2 * nd] = sigma;
+    if (lane == 1) buf_b[2 * nd + 1] = time;
+    for (int t = lane; t < N * ea; t += kWave) {
+        const int n = t / ea, e = t - n * ea;
+        buf_b[2 * nd + 2 + t] = w.wa[(int)a[n] * ea + e] + w.ba[e];
+    }
+    for (int j = lane; j < el; j += kWave) {
+        float acc = w.bl[j];
+        for (int k = 0; k < nl; ++k) acc = __builtin_fmaf(w.wl[k * el + j], l[k], acc);
+        buf_b[2 * nd + 2 + N * ea + j] = acc;
+    }
+    for (int e = in_f + lane; e < 4 * FQ; e += kWave) buf_b[e] = 0.0f;
+    wave_sync();
+    buf_a[lane] = silu_(dot_regs<FQ>(R.wf, buf_b, R.bf));       // (neurons beyond hidden_size: zero weights and bias -> 0)
+    wave_sync();
+    lds_f* cur = buf_a;
+    lds_f* other = buf_b;
+#pragma unroll
+    for (int k = 0; k < NH - 2; ++k) {
+        other[lane] = silu_(dot_regs<16>(R.wmid[k], cur, R.bmid[k]));
+        wave_sync();
+        lds_f* t = cur; cur = other; other = t;
+    }
+    if (lane < nt) {                                            // logits (N C) | score_x (N d) | score_l (nl), contiguous
+        const float o = dot_regs<16>(R.wfo, cur, R.bfo);
+        logits[lane] = (lane < N * C && (lane % C) == C - 1) ? -__builtin_huge_valf() : o;
+    }
+    // (no hand-off here: the caller synchronises once, behind the step's noise record)
 }
 
 // floats of LDS one wavefront needs besides the shared weight image
@@ -1388,7 +1470,7 @@ __global__ __launch_bounds__(kBlock) void pc_noise_fill_kernel(NoiseFillArgs p)
 template <int SPEC>
 __device__ __forceinline__ void specialise(mdx_mlp_t& m, PcArgs& pc)
 {
-    if constexpr (SPEC >= 1) {
+    if constexpr (SPEC >= 1 && SPEC < 200) {
         m.number_of_atoms = 8; m.spatial_dimension = 3; m.num_classes = spec_classes(SPEC); m.hidden_size = 64;
         m.n_hidden = spec_hidden_layers(SPEC);
         m.e_coordinates = 32; m.e_noise = 16; m.e_time = 16; m.e_atom_type = 1; m.e_lattice = 1;
@@ -1431,6 +1513,11 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
         const MlpWaveLds r = carve_wave_lds(m, scratch + wave * mlp_wave_floats(m));
         [[maybe_unused]] MlpRegs regs;
         [[maybe_unused]] MlpRegsFolded<spec_classes(SPEC), spec_hidden_layers(SPEC)> folded;
+        [[maybe_unused]] MlpRegsPadded<spec_first_quads(SPEC), spec_padded(SPEC) ? spec_hidden_layers(SPEC) : 2> padded;
+        if constexpr (spec_padded(SPEC) && LDS_WEIGHTS) {
+            load_mlp_regs_padded(padded, m, lane);
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): as for the folded family below
+        }
         if constexpr (SPEC == 1 && LDS_WEIGHTS) load_mlp_regs(regs, w, lane);
         if constexpr (spec_folded(SPEC) && LDS_WEIGHTS) {
             load_mlp_regs_folded(folded, m, w, lane);
@@ -1457,7 +1544,7 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
                                                                                 : FixedSoftmaxC2{0.0f, 0.0f, 0};
             PcArgs pc_types_only = p.pc;                                   // P2 + P3 only (P1 done one lane per component)
             pc_types_only.do_coords = 0;
-            constexpr int kPre = SPEC >= 1 ? 1 : (MDX_MAX_CLASSES + 5);   // 64-lane fetches covering N (d + C + 1) floats
+            constexpr int kPre = SPEC >= 1 && SPEC < 200 ? 1 : (spec_padded(SPEC) ? 2 : MDX_MAX_CLASSES + 5);   // 64-lane fetches covering N (d + C + 1) + 8 floats (padded family: N <= 8, C <= 8 -> <= 104)
             const int rec_total = p.rec0 + p.M * p.rec1;
             for (int it = 0; it < p.n_iterations; ++it) {
                 const int i = p.start_index - 1 - it;               // loop variable of the reference (:147)
@@ -1482,6 +1569,9 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
                             mlp_forward_regs(w, regs, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b, r.logits);
                         else if constexpr (spec_folded(SPEC) && LDS_WEIGHTS)
                             mlp_forward_folded(w, folded, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b,
+                                               r.logits);
+                        else if constexpr (spec_padded(SPEC) && LDS_WEIGHTS)
+                            mlp_forward_padded(m, w, padded, lane, r.x, r.a, r.l, st.sc.time, st.sc.sigma, r.buf_a, r.buf_b,
                                                r.logits);
                         else if constexpr (SPEC == 0 && LDS_WEIGHTS) {
                             if (p.fold)
@@ -1997,11 +2087,13 @@ static void launch_mlp_sampler(int G, unsigned grid, size_t lds, hipStream_t st,
 }
 
 #define MDX_FOLDED_FAMILY(X) X(122) X(123) X(124) X(132) X(133) X(134)
+#define MDX_PADDED_FAMILY(X) X(212) X(213) X(214) X(222) X(223) X(224) X(232) X(233) X(234)
 
 static const void* mlp_sampler_lds_function(int G, int spec)
 {
 #define MDX_CASE(S) if (spec == S) return (const void*)mlp_pc_sample_kernel<8, true, S>;
     MDX_FOLDED_FAMILY(MDX_CASE)
+    MDX_PADDED_FAMILY(MDX_CASE)
 #undef MDX_CASE
     if (spec == 1) return (const void*)mlp_pc_sample_kernel<8, true, 1>;
     switch (G) {
@@ -2442,10 +2534,20 @@ int64_t mdx_mlp_pc_sample_workspace_floats(const mdx_mlp_t* mlp_host, int number
     return (rec0 + number_of_corrector_steps * rec1) * batch * n_iterations;
 }
 
+// the padded register-resident family (SPEC >= 200): 200 + 10 (first-layer quads / 16) + hidden layers, or 0
+inline int padded_family_spec(const mdx_mlp_t& m)
+{
+    if (!m.folded_padded || m.hidden_size > 64 || m.number_of_atoms > 8 || m.n_hidden < 2 || m.n_hidden > 4) return 0;
+    if (mlp_outputs(m) > 64 || mlp_folded_inputs(m) > 192) return 0;
+    return 200 + 10 * ((mlp_folded_inputs(m) + 63) / 64) + m.n_hidden;
+}
+
 static int mlp_sampler_variant(const mdx_mlp_t& m, uint32_t options)
 {
     int spec = matches_template_mlp(m) && !(options & MDX_MLP_SAMPLE_GENERIC_KERNEL) ? 1 : 0;
-    if (!(options & (MDX_MLP_SAMPLE_GENERIC_KERNEL | MDX_MLP_SAMPLE_UNFOLDED)) && folded_family_spec(m)) spec = folded_family_spec(m);
+    const bool plain = options & (MDX_MLP_SAMPLE_GENERIC_KERNEL | MDX_MLP_SAMPLE_UNFOLDED);
+    if (!plain && folded_family_spec(m) && !(options & MDX_MLP_SAMPLE_PADDED_FAMILY)) spec = folded_family_spec(m);
+    else if (!plain && padded_family_spec(m)) spec = padded_family_spec(m);
     return spec;
 }
 
@@ -2469,6 +2571,7 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
     if (mlp_host->number_of_atoms > kWave) return MDX_ERR_UNSUPPORTED;      // one lane per atom in the update
     if ((int64_t)batch * mlp_host->number_of_atoms > 0xffffffffLL) return MDX_ERR_UNSUPPORTED;
     constexpr uint32_t kKnownOptions = MDX_MLP_SAMPLE_GENERIC_KERNEL | MDX_MLP_SAMPLE_UNFOLDED | MDX_MLP_SAMPLE_CALLER_NOISE |
+                                       MDX_MLP_SAMPLE_PADDED_FAMILY |
                                        MDX_MLP_SAMPLE_NO_FIXED_SOFTMAX | MDX_MLP_SAMPLE_NO_P2_TABLE |
                                        MDX_MLP_SAMPLE_DIAG_NO_FORWARD | MDX_MLP_SAMPLE_DIAG_NO_UPDATE;
     if (options & ~kKnownOptions) return MDX_ERR_INVALID_ARG;
@@ -2562,10 +2665,11 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
         if (lds > kMlpLdsBudget) {       // up to 128 KiB of the CU's 160 KiB: opt in above the 64 KiB default
             // the attribute is a property of the code object: set it when the requirement grows, not on every launch
             // (per device: a process that samples on a second GPU must opt in there as well)
-            static std::atomic<size_t> granted[kMaxDevices][16];
+            static std::atomic<size_t> granted[kMaxDevices][24];
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return MDX_ERR_HIP;
-            const int slot = spec >= 100 ? 8 + (spec - 120) / 10 * 3 + (spec % 10 - 2)      // 8 .. 13
+            const int slot = spec >= 200 ? 14 + (spec - 210) / 10 * 3 + (spec % 10 - 2)     // 14 .. 22
+                             : spec >= 100 ? 8 + (spec - 120) / 10 * 3 + (spec % 10 - 2)    // 8 .. 13
                              : spec ? 7 : (G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : G == 32 ? 5 : 6);
             if (granted[dev][slot].load() < lds) {
                 if (hipFuncSetAttribute(mlp_sampler_lds_function(G, spec), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2577,6 +2681,7 @@ int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_hos
 #define MDX_CASE(S) \
         if (spec == S) hipLaunchKernelGGL((mlp_pc_sample_kernel<8, true, S>), dim3(grid), dim3(kMlpWaves * kWave), lds, st, a); else
         MDX_FOLDED_FAMILY(MDX_CASE)
+        MDX_PADDED_FAMILY(MDX_CASE)
 #undef MDX_CASE
         if (spec == 1)
             hipLaunchKernelGGL((mlp_pc_sample_kernel<8, true, 1>), dim3(grid), dim3(kMlpWaves * kWave), lds, st, a);

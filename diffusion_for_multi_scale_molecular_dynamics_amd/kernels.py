@@ -362,9 +362,13 @@ class MlpPack:
         self.folded = _fold_input_layers(network, m, device)
         m.folded_output = None
         self.folded_out = _fold_output_layers(network, device) if self.folded is not None else None
+        m.folded_padded = None
         if self.folded is not None and self.folded_out is not None:
             m.folded_input = self.folded.data_ptr()
             m.folded_output = self.folded_out.data_ptr()
+            self.folded_padded = _pad_folded_layers(network, m, device)
+            if self.folded_padded is not None:
+                m.folded_padded = self.folded_padded.data_ptr()
         n_floats = lib().mdx_mlp_image_floats(C.byref(m))
         if n_floats > 0:      # the kernels' own layout, built once: kernel start-up becomes one coalesced copy
             self.image = torch.empty(n_floats, dtype=F32, device=device)
@@ -403,6 +407,59 @@ def _fold_input_layers(network, m, device):
                              w0[:, o4:]], dim=1)                  # [H, el]
         bias = b0 + w0[:, :o1] @ bc + w0[:, o1:o2] @ bn + w0[:, o2:o3] @ bt
         return torch.cat([_quad_image(columns), bias]).to(device=device, dtype=F32).contiguous()
+
+
+def _folded_matrices(network, m):
+    """(W_first [H, F], b_first [H]), [(W_k, b_k) of the middle hidden layers], (W_out [outputs, H], b_out) in binary64: the
+    network as n_hidden linear maps (see _fold_input_layers / _fold_output_layers)."""
+    f64 = torch.float64
+    with torch.no_grad():
+        w0 = network.mlp_layers[0].weight.detach().to(f64).cpu()
+        b0 = network.mlp_layers[0].bias.detach().to(f64).cpu()
+        ec, en, et = m.e_coordinates, m.e_noise, m.e_time
+        na = m.number_of_atoms * m.e_atom_type
+        o1, o2, o3, o4 = ec, ec + en, ec + en + et, ec + en + et + na
+        cpu = lambda t: t.detach().to(f64).cpu()       # noqa: E731
+        wc, bc = cpu(network.relative_coordinates_embedding_layer.weight), cpu(network.relative_coordinates_embedding_layer.bias)
+        wn, bn = cpu(network.noise_embedding_layer.weight), cpu(network.noise_embedding_layer.bias)
+        wt_, bt = cpu(network.time_embedding_layer.weight), cpu(network.time_embedding_layer.bias)
+        first = torch.cat([w0[:, :o1] @ wc, w0[:, o1:o2] @ wn, w0[:, o2:o3] @ wt_, w0[:, o3:o4], w0[:, o4:]], dim=1)
+        first_bias = b0 + w0[:, :o1] @ bc + w0[:, o1:o2] @ bn + w0[:, o2:o3] @ bt
+        mids = [(cpu(layer.weight), cpu(layer.bias)) for layer in list(network.mlp_layers)[1:-1]]
+        last = network.mlp_layers[-1]
+        heads = (network.output_A_layer, network.output_X_layer, network.output_L_layer)
+        w_heads = torch.cat([cpu(h.weight) for h in heads], dim=0)
+        b_heads = torch.cat([cpu(h.bias) for h in heads], dim=0)
+        return (first, first_bias), mids, (w_heads @ cpu(last.weight), w_heads @ cpu(last.bias) + b_heads)
+
+
+def _pad_folded_layers(network, m, device):
+    """mdx_mlp_t.folded_padded: the folded layers zero-padded to the fixed sizes of the padded register-resident family
+    (64 neurons, 16 / 32 / 48 first-layer quads, 64 outputs), or None when the network is outside that family's limits.
+    The same binary64 products as folded_input / folded_output, rounded once: the padded family and the generic folded forward
+    compute the same bits."""
+    n_hidden = len(network.mlp_layers)
+    n_in = 2 * m.number_of_atoms * m.spatial_dimension + 2 + m.number_of_atoms * m.e_atom_type + m.e_lattice
+    d = m.spatial_dimension
+    n_out = m.number_of_atoms * m.num_classes + m.number_of_atoms * d + d * (d + 1) // 2
+    if m.hidden_size > 64 or m.number_of_atoms > 8 or not 2 <= n_hidden <= 4 or n_out > 64 or n_in > 192:
+        return None
+    (w_first, b_first), mids, (w_out, b_out) = _folded_matrices(network, m)
+    if w_first.shape[1] != n_in:
+        return None
+
+    def padded(w, b, inputs):
+        wp = torch.zeros(64, inputs, dtype=torch.float64)
+        wp[: w.shape[0], : w.shape[1]] = w
+        bp = torch.zeros(64, dtype=torch.float64)
+        bp[: b.shape[0]] = b
+        return [_quad_image(wp), bp]
+
+    parts = padded(w_first, b_first, 64 * ((n_in + 63) // 64))
+    for w, b in mids:
+        parts += padded(w, b, 64)
+    parts += padded(w_out, b_out, 64)
+    return torch.cat(parts).to(device=device, dtype=F32).contiguous()
 
 
 def _quad_image(matrix64: torch.Tensor) -> torch.Tensor:

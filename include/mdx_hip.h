@@ -290,6 +290,14 @@ typedef struct mdx_mlp {
                                                             ceil(hidden_size/4) x (N C + N d + d(d+1)/2) weight quads
                                                             [q][output][4] (outputs: logits | score_x | score_l), then the
                                                             folded bias */
+    const float* folded_padded;                          /* optional (ABI v12): the folded layers zero-padded to fixed sizes,
+                                                            for the register-resident family of mdx_mlp_pc_sample (hidden_size
+                                                            <= 64, N <= 8, <= 64 outputs, F <= 192 folded inputs, 2 .. 4 hidden
+                                                            layers): [FQ][64][4] + bias [64] with FQ = 16 ceil(F / 64) quads of
+                                                            the folded first layer (neurons >= hidden_size and inputs >= F
+                                                            zero) | per middle hidden layer [16][64][4] + bias [64] |
+                                                            [16][64][4] + bias [64] of the folded output layer (outputs >= N C
+                                                            + N d + d(d+1)/2 zero) */
 } mdx_mlp_t;
 
 /* Size (in floats) and construction of the packed weight image referenced by mdx_mlp_t.packed_image. */
@@ -328,6 +336,8 @@ MDX_API int mdx_mlp_forward(const mdx_mlp_t* mlp_host, const int64_t* atom_types
                                                must fit the workspace                                                    */
 #define MDX_MLP_SAMPLE_NO_FIXED_SOFTMAX 8u  /* evaluate the clipped softmax per atom (bit-identical; tests)              */
 #define MDX_MLP_SAMPLE_NO_P2_TABLE 16u      /* ignore the per-step posterior table of the records (bit-identical; tests) */
+#define MDX_MLP_SAMPLE_PADDED_FAMILY 128u   /* prefer the padded register-resident family (any dimensions within its limits)
+                                               to the exact-dimension one where both apply (A/B runs, tests)             */
 #define MDX_MLP_SAMPLE_DIAG_NO_FORWARD 256u /* timing diagnostics, honoured only by a -DMDX_DIAGNOSTICS build of the     */
 #define MDX_MLP_SAMPLE_DIAG_NO_UPDATE 512u  /* library; the release build returns MDX_ERR_UNSUPPORTED for them           */
 MDX_API int64_t mdx_mlp_pc_sample_workspace_floats(const mdx_mlp_t* mlp_host, int number_of_corrector_steps,
@@ -336,7 +346,9 @@ MDX_API int64_t mdx_mlp_pc_sample_workspace_floats(const mdx_mlp_t* mlp_host, in
 /* Which instantiation mdx_mlp_pc_sample runs for this network and these options: 0 = generic (any shape), 1 = the
  * reference template's dimensions as literals (layer by layer), 100 + 10 C + NH = the register-resident family with folded
  * input / output layers: N = 8, d = 3, hidden 64, embeddings 32/16/16/1/1, C in {2,3} classes, NH in {2,3,4} hidden layers
- * (needs folded_input and folded_output).  -1: invalid descriptor. */
+ * (needs folded_input and folded_output); 200 + 10 ceil(F / 64) + NH = the PADDED register-resident family (needs
+ * folded_padded: hidden_size <= 64, N <= 8, <= 64 outputs, F <= 192 folded inputs, NH in {2,3,4}): every MLP configuration
+ * of the reference's templates and experiments.  -1: invalid descriptor. */
 MDX_API int mdx_mlp_pc_sample_variant(const mdx_mlp_t* mlp_host, uint32_t options);
 MDX_API int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t* mlp_host,
                               const mdx_pc_flags_t* flags_host, int number_of_corrector_steps,

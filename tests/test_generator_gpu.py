@@ -883,6 +883,80 @@ def test_fused_sampler_generic_folded_forward(cuda, n_atoms, nat, hidden, n_hidd
             "the folded forward did not run (same bits as the layer-by-layer form)"
 
 
+def _mlp_any(n_atoms, nat, hidden, n_hidden, e_coord, e_noise, e_time, e_atom, e_lattice):
+    from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.mlp_score_network import (
+        MLPScoreNetwork, MLPScoreNetworkParameters)
+    return MLPScoreNetwork(MLPScoreNetworkParameters(
+        number_of_atoms=n_atoms, num_atom_types=nat, n_hidden_dimensions=n_hidden, hidden_dimensions_size=hidden,
+        relative_coordinates_embedding_dimensions_size=e_coord, noise_embedding_dimensions_size=e_noise,
+        time_embedding_dimensions_size=e_time, atom_type_embedding_dimensions_size=e_atom,
+        lattice_parameters_embedding_dimensions_size=e_lattice)).eval()
+
+
+# the reference's own MLP configurations (configuration_templates/.../config_diffusion_mlp.yaml, ..._orion.yaml,
+# analysis_and_sanity_checks/{toy_problems,atom_types_only_experiments}/training/*.yaml) and a few around them:
+# (N, atom types, hidden, hidden layers, e_coordinates, e_noise, e_time, e_atom_type, e_lattice) -> expected instantiation
+PADDED_FAMILY_SHAPES = [
+    ((8, 1, 64, 3, 32, 16, 16, 1, 1), 213),        # the template at N = 8 (60 folded inputs)
+    ((2, 1, 64, 3, 32, 16, 16, 1, 1), 213),        # the template as written (N = 2)
+    ((8, 2, 64, 3, 2, 64, 64, 64, 2), 233),        # atom_types_only_experiments: 48 + 2 + 8 x 64 + 2 > 192 inputs -> see below
+    ((8, 1, 16, 1, 32, 16, 16, 16, 8), 0),         # orion, one hidden layer: nothing to fold an output layer into
+    ((8, 1, 32, 4, 32, 16, 16, 16, 8), 234),       # orion: 48 + 2 + 128 + 8 = 186 inputs, hidden 32, four layers
+    ((8, 1, 64, 2, 32, 16, 16, 16, 8), 232),
+    ((5, 3, 48, 3, 8, 4, 4, 3, 2), 213),
+    ((8, 2, 64, 4, 32, 16, 16, 1, 1), 214),
+]
+
+
+GENERIC_UNFOLDED_SHAPES = {(8, 1, 64, 2, 32, 16, 16, 16, 8)}
+
+
+@pytest.mark.parametrize("shape,variant", PADDED_FAMILY_SHAPES)
+def test_fused_sampler_padded_family_equals_generic_folded(cuda, shape, variant):
+    """The padded register-resident family (round 4: weights of every layer in registers, fixed padded sizes, run-time structure
+    dimensions -- what every MLP configuration of the reference runs) against the generic instantiation's folded forward on the
+    unpadded matrices: a zero quad adds fma(0, 0, s) = s, so the two agree BIT FOR BIT over a whole trajectory; and
+    mdx_mlp_pc_sample_variant names the instantiation."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+    import warnings
+    n_atoms, nat = shape[0], shape[1]
+    P = _pkg()
+    torch.manual_seed(91)
+    net = _mlp_any(*shape).to(cuda)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = P["Noise"](**cases.noise_ns(25, **cases.LIN))
+        spar = P["Sampling"](**cases.sampling_ns(n_atoms, nat, M=2), rng_mode="device", seed=3, fused_score_network=True)
+    gen = LangevinGenerator(npar, spar, net)
+    with torch.no_grad():
+        sched = gen._prepare(cuda)
+        gen._begin_call(cuda)
+        start = gen.initialize(130, cuda)
+        pack = gen.fused_pack(cuda)
+        n_inputs = 6 * n_atoms + 2 + n_atoms * shape[7] + shape[8]
+        if n_inputs > 192:                       # outside the family's limits: no padded matrices, generic kernel
+            variant = 0
+        got = _hip.lib().mdx_mlp_pc_sample_variant(__import__("ctypes").byref(pack.c_struct), _hip.MLP_SAMPLE_PADDED_FAMILY)
+        assert got == variant, (got, variant)
+        assert bool(pack.c_struct.folded_padded) == (variant >= 200)
+        results = {}
+        for name, options in (("padded", _hip.MLP_SAMPLE_PADDED_FAMILY), ("generic", _hip.MLP_SAMPLE_GENERIC_KERNEL)):
+            comp = RS.AXL(A=start.A.clone(), X=start.X.clone(), L=start.L.clone())
+            kernels.mlp_pc_sample(sched, pack, gen._flags(True), 2, False, 25, 25, gen._rng(0), comp.A, comp.X, comp.L,
+                                  gen._status, workspace=gen._noise_workspace, options=options)
+            results[name] = _np(comp)
+    assert np.array_equal(results["padded"].A, results["generic"].A)
+    same_bits = np.array_equal(results["padded"].X.view(np.int32), results["generic"].X.view(np.int32))
+    if shape in GENERIC_UNFOLDED_SHAPES:
+        # (the generic kernel keeps its layer-by-layer forward here -- image + folded matrices exceed its LDS budget --: the same
+        # function with last-bit different rounding, as in test_fused_sampler_generic_folded_forward)
+        assert not same_bits and torus_rel_l2(results["padded"].X, results["generic"].X) < 1e-5
+    else:
+        assert same_bits
+    assert (results["padded"].A != nat).all() and np.isfinite(results["padded"].X).all()
+
+
 # -------------------------------------------------------------------------------------------------------------
 # EGNN helpers: library GEMM with fused bias+SiLU epilogue, fused first message layer
 # -------------------------------------------------------------------------------------------------------------
