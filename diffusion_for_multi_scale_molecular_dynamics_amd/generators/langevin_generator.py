@@ -8,7 +8,9 @@ Same class name, constructor, step methods and behaviour as the reference's Lang
     coordinate update + periodic wrap (P1), lattice update (P3) -- is ONE fused kernel launch per step
     (mdx_pc_step_update), with per-structure reductions done by wavefront shuffles;
   * no per-step host synchronisation: the reference's asserts are collected in a device status word that is read
-    once at the end of sample();
+    once at the end of sample().  (A score network that runs split-f16 MFMA kernels also has its f16-range report
+    watched per iteration -- through asynchronous copies to page-locked memory read two iterations behind the queue,
+    so the device never waits for the host: IterationLoop._advance_watched);
   * rng_mode="device" removes the per-step CPU draws + PCIe uploads, and use_hip_graph=True replays one captured
     predictor+correctors iteration T times with the step index living on the device.
 
