@@ -655,7 +655,8 @@ class _RangeReportAt(torch.nn.Module):
 
     def __init__(self, net, time_value):
         super().__init__()
-        self.net, self.time_value = net, float(time_value)
+        self.net = net
+        self.register_buffer("time_values", torch.as_tensor(time_value, dtype=torch.float32).reshape(-1))
 
     graph_status = property(lambda self: self.net.graph_status)
     edge_chain_precision = property(lambda self: self.net.edge_chain_precision,
@@ -666,7 +667,7 @@ class _RangeReportAt(torch.nn.Module):
         from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import AXL, TIME
         out = self.net(batch, conditional)
         if self.net.edge_chain_precision in ("f16x3", "f16x3_32x32"):
-            hit = (batch[TIME][:1, 0] == self.time_value)
+            hit = (batch[TIME][:1, 0:1] == self.time_values).any().reshape(1)       # (the buffer lives on the device: .to(cuda))
             self.net.graph_status.bitwise_or_(hit.to(torch.int32) * _hip.STATUS_EGNN_F16_RANGE)
             out = AXL(A=out.A, X=out.X + hit.to(out.X.dtype) * 1.0e3, L=out.L)
         return out
@@ -714,7 +715,7 @@ def test_f16_range_fallback_costs_one_iteration(cuda, M, flagged, use_graph, pre
             gen = LangevinGenerator(npar, spar, net)
         gen._prepare(cuda)
         if wrap:
-            gen.axl_network = _RangeReportAt(net, float(gen.noise.time[k]))
+            gen.axl_network = _RangeReportAt(net, float(gen.noise.time[k])).to(cuda)
         return gen, net
 
     gen, net = build(wrap=True)
@@ -743,6 +744,52 @@ def test_f16_range_fallback_costs_one_iteration(cuda, M, flagged, use_graph, pre
     assert plain.f16_range_fallbacks == 0
     diff = (other.X - got.X + 0.5) % 1.0 - 0.5
     assert float(diff.norm() / got.X.norm()) < 1e-5
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_f16_range_fallback_many_events(cuda, use_graph):
+    """The watched loop under several reports in one call: the FIRST iteration (nothing queued before it), two consecutive ones
+    (the second is flagged again when it is repeated behind the first's f32 pass), one in the middle and the LAST iteration
+    (time index 0: nothing queued behind it) -- five iterations recomputed, and the result equals, bit for bit, the run with
+    exactly those five computed by the f32 kernels."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.predictor_corrector_axl_generator import \
+        PredictorCorrectorSamplingParameters
+    from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters
+    import cases
+    import warnings
+    T, B = 24, 4
+    flagged = [T - 1, 15, 14, 7, 0]
+
+    def build(wrap):
+        torch.manual_seed(21)
+        net = nets.egnn_net(1, "radial_cutoff", 7.5, hidden=32, n_layers=2, n_hidden=2).to(cuda)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            npar = NoiseParameters(**cases.noise_ns(T, **cases.LIN))
+            spar = PredictorCorrectorSamplingParameters(**cases.sampling_ns(64, 1, M=0, greedy=False, one=False, cell=[10.86] * 3),
+                                                        rng_mode="device", seed=5, use_hip_graph=use_graph and wrap)
+        gen = LangevinGenerator(npar, spar, net)
+        gen._prepare(cuda)
+        if wrap:
+            gen.axl_network = _RangeReportAt(net, gen.noise.time[flagged]).to(cuda)
+        return gen, net
+
+    gen, net = build(wrap=True)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = gen.sample(B, cuda)
+    assert gen.f16_range_fallbacks == len(flagged)
+    ref, ref_net = build(wrap=False)
+    with torch.no_grad():
+        ref._begin_call(cuda)
+        comp = ref.initialize(B, cuda)
+        forces = torch.zeros_like(comp.X)
+        for i in range(T - 1, -1, -1):
+            ref_net.edge_chain_precision = "f32" if i in flagged else "f16x3"
+            comp = ref._iteration(comp, i, forces)
+        ref.check_status()
+    assert torch.equal(got.A, comp.A) and torch.equal(got.X, comp.X)
 
 
 @pytest.mark.parametrize("precision", CHAIN_MODES)
