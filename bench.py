@@ -391,13 +391,14 @@ def cpu_baseline(w, name, budget_s=15.0, resampling=0):
     value = batch / (T * per_iter)
     # the port against the REFERENCE ITSELF, both timed on one host (the reference cannot run on the GPU box): the committed
     # calibration of tools/time_reference.py --port; a reported context figure, like the baseline itself
-    ratio = {"C2": 1.37}.get(name, 1.45)
+    ratio = {"C2": 1.0}.get(name, 1.30)
     return dict(value=value, unit="structures/s", cores=cores, kind="port",
                 sample=f"{count} of {T} iterations of workload {name} at batch {batch} "
                        f"({elapsed:.1f} s, {per_iter * 1e3:.2f} ms/iteration), extrapolated to the {T}-step job",
                 reference_equivalent=dict(value=value / ratio, port_over_reference=ratio,
-                                          source="profiles/r03_reference_cpu_timing.json: the reference and this port timed on "
-                                                 "the build container's 8 cores (C3: 0.0116 vs 0.0169 structures/s; C2: 163.8 vs 223.7)"))
+                                          source="profiles/r04_reference_cpu_timing.json: the reference and this port timed on "
+                                                 "the build container's 8 cores (C3: 0.01415 vs 0.0184 structures/s; C2: 238.4 vs "
+                                                 "240.1; round 3 measured 1.45 and 1.37)"))
 
 
 import contextlib
