@@ -28,6 +28,8 @@ ap.add_argument("--rows", action="store_true", help="also time the row chain (md
 ap.add_argument("--zero-activations", action="store_true", help="zero projections, coordinates and biases: every activation of "
                 "every layer is an exact zero while the weights stay random (what the same instruction stream costs without "
                 "operand switching activity)")
+ap.add_argument("--power", type=float, default=0.0, help="seconds of back-to-back launches per mode while a thread samples the "
+                "card's power sensor, power cap and shader clock (hwmon / pp_dpm_sclk in sysfs; rocm-smi as the fallback)")
 ap.add_argument("--lib", default=None, help="alternative libmdx_hip.so (ablation builds)")
 args = ap.parse_args()
 if args.lib:
@@ -35,6 +37,87 @@ if args.lib:
     _hip.LIB_PATH = os.path.abspath(args.lib)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
+
+
+class PowerSampler:
+    """Average socket power (W), the cap and the current shader clock of card 0, polled from sysfs while launches run."""
+
+    def __init__(self):
+        import ctypes
+        import glob
+        sensors = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") +
+                         glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+        # the card this process computes on, by its PCI address (a host shows every card and partition of the node in sysfs)
+        self.bdf = None
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, 0) == 0:
+                self.bdf = buf.value.decode().lower()
+        except OSError:
+            pass
+        mine = [f for f in sensors if self.bdf and os.path.realpath(f.split("/hwmon/")[0]).lower().endswith(self.bdf)]
+        self.others = [f for f in sensors if f not in mine]
+        self.power = mine or sensors
+        self.cap = [f.rsplit("/", 1)[0] + "/power1_cap" for f in self.power]
+        self.sclk = [f.split("/hwmon/")[0] + "/pp_dpm_sclk" for f in self.power]
+        self.samples, self.clocks, self.stop = [], [], False
+        self.other_samples = {f: [] for f in self.others}
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read()
+        except OSError:
+            return None
+
+    def _smi(self):
+        import subprocess
+        try:
+            out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, text=True, timeout=20).stdout
+            card = json.loads(out).get("card0", {})
+            for k, v in card.items():
+                if "power" in k.lower() and "(w)" in k.lower():
+                    self.samples.append(float(v))
+                if k.lower().startswith("sclk"):
+                    self.clocks.append(float(str(v).strip("()Mhz ")))
+        except Exception as e:                                             # noqa: BLE001  (a diagnostic tool: report, go on)
+            self.error = repr(e)
+
+    def run(self):
+        import time
+        while not self.stop:
+            got = False
+            for f, c in zip(self.power[:1], self.sclk[:1]):
+                v = self._read(f)
+                if v and v.strip().isdigit() and int(v) > 0:
+                    self.samples.append(int(v) / 1e6)
+                    got = True
+                clk = self._read(c) or ""
+                for line in clk.splitlines():
+                    if line.rstrip().endswith("*"):
+                        self.clocks.append(float(line.split(":")[1].replace("Mhz", "").replace("*", "").strip()))
+            if not got:
+                self._smi()
+            for f in self.others:                   # (every other sensor of the host too: which card the load shows on)
+                v = self._read(f)
+                if v and v.strip().isdigit():
+                    self.other_samples[f].append(int(v) / 1e6)
+            time.sleep(0.05)
+
+    def summary(self):
+        cap = self._read(self.cap[0]) if self.cap else None
+        s, c = sorted(self.samples), self.clocks
+        others = {f.split("/")[4]: round(sum(v) / len(v), 1) for f, v in self.other_samples.items() if v}
+        return {"pci": self.bdf, "sensor": (self.power[0] if self.power else "rocm-smi"), "samples": len(s),
+                "other_cards_W_mean": others,
+                "power_W_mean": round(sum(s) / len(s), 1) if s else None, "power_W_median": s[len(s) // 2] if s else None,
+                "power_W_max": s[-1] if s else None, "power_cap_W": int(cap) / 1e6 if cap and cap.strip().isdigit() else None,
+                "sclk_MHz_mean": round(sum(c) / len(c), 1) if c else None, "error": getattr(self, "error", None)}
+
+
 H, n_in, n_msg, n_crd = args.hidden, args.hidden, args.n_msg, args.n_crd
 n_nodes, E = args.nodes, args.nodes * args.degree
 lin0 = torch.nn.Linear(2 * n_in + 1, H).to(dev)
@@ -111,6 +194,26 @@ with torch.no_grad():
                     v = sorted(v)
                     print(key, "n", len(v), "median", v[len(v) // 2], "mean", sum(v) / len(v), "max", v[-1])
                 continue
+        if args.power > 0:
+            import threading
+            import time
+            launch()
+            torch.cuda.synchronize()
+            sampler = PowerSampler()
+            thread = threading.Thread(target=sampler.run)
+            thread.start()
+            t0, n = time.perf_counter(), 0
+            while time.perf_counter() - t0 < args.power:
+                for _ in range(20):
+                    launch()
+                torch.cuda.synchronize()
+                n += 20
+            elapsed = time.perf_counter() - t0
+            sampler.stop = True
+            thread.join()
+            res[mode] = dict(ms=round(elapsed / n * 1e3, 4), launches=n, **sampler.summary())
+            time.sleep(2.0)                             # let the sensor's averaging window drain before the next mode
+            continue
         if args.eager:
             launch()
             torch.cuda.synchronize()
