@@ -344,7 +344,8 @@ def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
                 "inside the kernel (s_memtime / s_memrealtime) the chip holds " +
                 ("1.96-2.11 GHz on the 16x16x32 shape (2.32 GHz, same cycle count, on all-zero activations: power sets the clock); "
                  "the launch is bounded by its energy, not its cycles: 2.9 % fewer cycles per wavefront in round 4 (bit-identical "
-                 "outputs) left the wall clock where it was (profiles/r04_chain_ablation.md)"
+                 "outputs) left the wall clock where it was (profiles/r04_chain_ablation.md); the card's sensor reads 1346 W "
+                 "mean of its 1400 W cap during these launches, clock level 2141 MHz (profiles/r04_chain_power.json)"
                  if shape16 else "1.80-1.82 GHz on the 32x32x16 shape: power-bound (profiles/r03_chain_ablation.md)"))
     return dict(bound="mfma", achieved=round(executed, 2), peak=peak, unit="TFLOP/s", frac=round(executed / peak, 4),
                 traffic=traffic, traffic_from=traffic_from,

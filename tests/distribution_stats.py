@@ -10,6 +10,7 @@ used here, all functions of the final relative coordinates X [B, N, 3] of an ort
   pair    every minimum-image pair distance i < j                                                 B N (N-1) / 2 values
   x, y, z every atom's coordinate along one axis                                                  B N values each
   atom<k><axis>  (optional, networks that are not permutation equivariant) the coordinate of atom k along an axis: B values
+  to_pinned  (repaint runs) every free atom's minimum-image distance to the nearest pinned site      B (N - K) values
 
 The reference side is stored as QUANTILE TABLES (tests/golden/dist_*.npz, made by tests/golden/make_distributions.py from the
 reference's own runs): `table[k]` = the k / (len - 1) quantile of the pooled reference sample.  ks_to_table evaluates
@@ -24,10 +25,20 @@ def _minimum_image_distances(X):
     return np.sqrt((d * d).sum(-1))                    # [B, N, N]
 
 
-def statistics(X, per_atom=False, sites=None):
+def statistics(X, per_atom=False, sites=None, pinned=None):
     """dict name -> 1-D float64 array of the scalars listed in the module docstring; with `sites` [N, 3] also `disp`: the
-    displacement of every coordinate from its site, wrapped to [-1/2, 1/2)."""
+    displacement of every coordinate from its site, wrapped to [-1/2, 1/2).  With `pinned` [K, 3] (a repaint run: the first K
+    atoms are held at these sites) the scalars are those of the FREE atoms X[:, K:] alone, plus `to_pinned`: every free atom's
+    minimum-image distance to the nearest pinned site."""
     X = np.asarray(X)
+    if pinned is not None:
+        pinned = np.asarray(pinned, np.float64)
+        free = X[:, pinned.shape[0]:]
+        out = statistics(free, per_atom=per_atom)
+        d = free[:, :, None, :].astype(np.float64) - pinned[None, None]
+        d -= np.round(d)
+        out["to_pinned"] = np.sqrt((d * d).sum(-1)).min(-1).ravel()
+        return out
     B, N, _ = X.shape
     r = _minimum_image_distances(X)
     iu = np.triu_indices(N, k=1)

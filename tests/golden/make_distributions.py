@@ -1,6 +1,6 @@
 """Reference-made DISTRIBUTIONS of whole sampling jobs (container-only: imports /root/reference through make_golden's stubs).
 
-    PYTHONPATH=/root/reference/src python tests/golden/make_distributions.py [mlp|egnn]
+    PYTHONPATH=/root/reference/src python tests/golden/make_distributions.py [analytic|mlp|egnn|egnn_c3_wide|egnn_repaint]
 
 Runs the REFERENCE's LangevinGenerator for complete trajectories where that is cheap, several seeds each, and stores summary
 statistics only -- quantile tables of the pooled final structures' scalars (tests/distribution_stats.py), the reference-vs-
@@ -15,6 +15,10 @@ and the KS distance of deliberately WRONG samplers to the pool (the power of the
   dist_egnn_rc.npz  a small radial-cutoff EGNN (hidden 32, 2 graph layers; weights = tests/golden/traj_egnn_rc.npz), N = 64,
                     cell 10.86, T = 100 of configs[2]'s linear schedule, M = 2, 64 structures per seed; its coordinate score x 100
                     (see egnn_rc below: with the bare random-init network the check would have no power)
+  dist_egnn_repaint.npz  ConstrainedLangevinGenerator (repaint, configs[4]'s algorithm) around the same small EGNN: 32 of the 64 atoms
+                    pinned at diamond sites, the statistics of the 32 free ones
+  dist_egnn_c3_wide.npz  the PRODUCTION network of configs[2] (EGNN 4 x 256 x 4, rc 7.5, formula weights), same schedule and
+                    T = 100, 16 structures x 6 seeds; coordinate score x 150
 
 No structure, draw or source text is stored: the tables hold 2049 quantiles per scalar.
 """
@@ -48,7 +52,7 @@ class ScaledScore(torch.nn.Module):
         return G.AXL(A=out.A, X=out.X * self.factor, L=out.L)
 
 
-def run(make, seeds, batch, per_atom, name, probes, extra=None, sites=None, probe_calls=1):
+def run(make, seeds, batch, per_atom, name, probes, extra=None, sites=None, probe_calls=1, pinned=None):
     per_seed = []
     for seed in seeds:
         gen = make()
@@ -57,7 +61,7 @@ def run(make, seeds, batch, per_atom, name, probes, extra=None, sites=None, prob
         with torch.no_grad():
             axl = gen.sample(batch, torch.device("cpu"))
         assert (axl.A != gen.num_classes - 1).all()
-        per_seed.append(DS.statistics(axl.X.numpy(), per_atom=per_atom, sites=sites))
+        per_seed.append(DS.statistics(axl.X.numpy(), per_atom=per_atom, sites=sites, pinned=pinned))
         print(f"{name}: seed {seed} done in {time.perf_counter() - t0:.1f} s", flush=True)
     keys = list(per_seed[0])
     out = {"seeds": np.array(seeds), "batch": np.array(batch), "scalars": np.array(keys)}
@@ -90,16 +94,16 @@ def run(make, seeds, batch, per_atom, name, probes, extra=None, sites=None, prob
             torch.manual_seed(seeds[0] + 1000 * c)
             with torch.no_grad():
                 axl = gen.sample(batch, torch.device("cpu"))
-            calls.append(DS.statistics(axl.X.numpy(), per_atom=per_atom, sites=sites))
+            calls.append(DS.statistics(axl.X.numpy(), per_atom=per_atom, sites=sites, pinned=pinned))
         for key in keys:
             table = out[f"table/{key}"].astype(np.float64)
             out[f"probe/{probe}/{key}"] = np.array(DS.ks_to_table(calls[0][key], table))
             if probe_calls > 1:
                 out[f"probe_pooled/{probe}/{key}"] = np.array(DS.ks_to_table(np.concatenate([c[key] for c in calls]), table))
-        print(f"{name}: probe {probe}: " + ", ".join(f"{k} {float(out[f'probe/{probe}/{k}']):.3f}" for k in keys[:5]) +
+        print(f"{name}: probe {probe}: " + ", ".join(f"{k} {float(out[f'probe/{probe}/{k}']):.3f}" for k in keys[:6]) +
               (" | pooled: " + ", ".join(f"{k} {float(out[f'probe_pooled/{probe}/{k}']):.4f}" for k in keys[:5]) if probe_calls > 1 else ""),
               flush=True)
-    for key in keys[:5]:
+    for key in keys[:6]:
         print(f"{name}: {key}: leave-one-out {out[f'leave_one_out/{key}'].round(4)}  pairwise max {out[f'pairwise/{key}'].max():.4f}")
     out.update(extra or {})
     G.save(name + ".npz", **out)
@@ -137,6 +141,62 @@ def egnn_rc():
     }
     run(make, seeds=[21, 22, 23, 24, 25, 26], batch=64, per_atom=False, name="dist_egnn_rc", probes=probes,
         extra={"score_factor": np.array(EGNN_SCORE_FACTOR)})
+
+
+def egnn_repaint():
+    """The reference's ConstrainedLangevinGenerator (src/.../generators/constrained_langevin_generator.py:94-163: the repaint
+    algorithm BASELINE configs[4] samples with) over whole trajectories: the small radial-cutoff EGNN of egnn_rc (score x 100),
+    N = 64, cell 10.86, T = 100, M = 2, the first K = 32 atoms pinned at the first 32 diamond sites of Si 2x2x2
+    (constrained_indices = arange), 64 structures per seed.  The statistics are those of the 32 FREE atoms (the pinned rows end
+    at their sites by construction), `to_pinned` included.  The probe `no_repaint` is the unconstrained generator: what the
+    free atoms' distribution would be without the conditioning."""
+    from cases import diamond_sites
+    K = 32
+    sites = diamond_sites(2)[:K].clone()
+    kw = dict(T=100, N=64, num_atom_types=1, M=2, one=False, greedy=False, cell=[10.86] * 3, noise_kw=LIN)
+
+    def make(factor=EGNN_SCORE_FACTOR, constrained=True, **over):
+        constraint = G.SamplingConstraint(elements=["Si"], constrained_relative_coordinates=sites.clone(),
+                                          constrained_atom_types=torch.zeros(K, dtype=torch.long)) if constrained else None
+        gen = G.make_generator(net=ScaledScore(G._egnn(1, "radial_cutoff", 7.5), factor), constraint=constraint,
+                               **dict(kw, **over))[0]
+        if constrained:
+            assert torch.equal(gen.constraint_indices, torch.arange(K))
+        return gen
+    probes = {
+        "zero_score": lambda: make(factor=0.0),
+        "score_x0.5": lambda: make(factor=0.5 * EGNN_SCORE_FACTOR),
+        "no_corrector": lambda: make(M=0),
+        "no_repaint": lambda: make(constrained=False),
+    }
+    run(make, seeds=[41, 42, 43, 44, 45, 46], batch=64, per_atom=False, name="dist_egnn_repaint", probes=probes,
+        extra={"score_factor": np.array(EGNN_SCORE_FACTOR), "pinned_sites": G._np(sites)}, pinned=G._np(sites))
+
+
+C3_WIDE_SCORE_FACTOR = 150.0
+
+
+def egnn_c3_wide():
+    """The network BASELINE configs[2] is quoted on -- the reference's EGNN 4 x 256 x 4, radial cutoff 7.5, weights by
+    tests/formula_weights.py as in net_egnn_c3.npz -- over whole (shortened) trajectories: N = 64, cell 10.86, T = 100 of
+    configs[2]'s linear schedule, M = 2, 16 structures per seed (1.4 s per iteration on this container's 8 cores).  The formula
+    network's sigma-normalised scores are 2e-3 rms, so, as in egnn_rc, the coordinate score is multiplied by a constant
+    (C3_WIDE_SCORE_FACTOR: rms 0.3) by a plugin on both sides.  Under that score the 64 atoms of a structure end in a few tight
+    clusters: the translation-invariant scalars (pair, nn) then separate samplers sharply (zeroed score: KS 0.99; halved: 0.49;
+    seed to seed: 0.035), while the per-axis coordinates only say where a structure's clusters landed (16 structures per call:
+    seed-to-seed KS 0.08 .. 0.33, the zero-score probe inside it) -- `judged` names the scalars the criterion uses."""
+    kw = dict(T=100, N=64, num_atom_types=1, M=2, one=False, greedy=False, cell=[10.86] * 3, noise_kw=LIN)
+    inner = G._egnn_c3(1)
+
+    def make(factor=C3_WIDE_SCORE_FACTOR, **over):
+        return G.make_generator(net=ScaledScore(inner, factor), **dict(kw, **over))[0]
+    probes = {
+        "zero_score": lambda: make(factor=0.0),
+        "score_x0.5": lambda: make(factor=0.5 * C3_WIDE_SCORE_FACTOR),
+        "no_corrector": lambda: make(M=0),
+    }
+    run(make, seeds=[31, 32, 33, 34, 35, 36], batch=16, per_atom=False, name="dist_egnn_c3_wide", probes=probes,
+        extra={"score_factor": np.array(C3_WIDE_SCORE_FACTOR), "judged": np.array(["pair", "nn"])})
 
 
 ANALYTIC = dict(number_of_atoms=8, kmax=4, sigma_d=0.05, T=200, sigma_min=1e-4, sigma_max=0.25)
@@ -199,3 +259,7 @@ if __name__ == "__main__":
         mlp_c2()
     if which in ("all", "egnn"):
         egnn_rc()
+    if which in ("all", "egnn_c3_wide"):
+        egnn_c3_wide()
+    if which in ("all", "egnn_repaint"):
+        egnn_repaint()

@@ -53,8 +53,11 @@ def thresholds(g, n_calls=None):
 
 
 def scalars_of(g):
-    """the pooled scalars a fixture holds: the five common ones, and `disp` when it names sites"""
-    return POOLED + (("disp",) if "sites" in g.files else ())
+    """the pooled scalars a fixture is judged on: the ones it names (`judged`), else the five common ones, `disp` when it names
+    sites, `to_pinned` for a repaint run"""
+    if "judged" in g.files:
+        return tuple(str(k) for k in g["judged"])
+    return POOLED + (("disp",) if "sites" in g.files else ()) + (("to_pinned",) if "pinned_sites" in g.files else ())
 
 
 def measure(g, calls):
@@ -63,7 +66,8 @@ def measure(g, calls):
     pooled = scalars_of(g)
     table = {k: g[f"table/{k}"] for k in list(pooled) + atoms}
     rows = []
-    per_call = [DS.statistics(x, per_atom=bool(atoms), sites=g["sites"] if "sites" in g.files else None) for x in calls]
+    per_call = [DS.statistics(x, per_atom=bool(atoms), sites=g["sites"] if "sites" in g.files else None,
+                              pinned=g["pinned_sites"] if "pinned_sites" in g.files else None) for x in calls]
     for c, st in enumerate(per_call):
         for k in pooled:
             rows.append((f"call {c}: {k}", DS.ks_to_table(st[k], table[k]), lim[k][0]))
@@ -99,6 +103,7 @@ def probe_fails(g, probe):
 @pytest.mark.parametrize("fixture,caught,missed", [
     ("dist_mlp_c2.npz", ["zero_score", "no_corrector"], ["score_x0.9", "sigma_max_0.2"]),
     ("dist_egnn_rc.npz", ["zero_score", "score_x0.5", "no_corrector"], []),
+    ("dist_egnn_c3_wide.npz", ["zero_score", "score_x0.5", "no_corrector"], []),
     ("dist_analytic.npz", ["zero_score", "score_x0.9", "score_x0.97", "no_corrector", "sigma_min_1e-2"], ["sigma_max_0.2"])])
 def test_the_criterion_has_teeth(fixture, caught, missed):
     """The reference's own wrong samplers against the criterion: a zeroed score, a halved score and a run without correctors
@@ -220,6 +225,74 @@ def test_egnn_graph_loop_samples_the_reference_distribution(cuda, precision):
         npar = P["Noise"](**noise_kw)
         spar = P["Sampling"](**sampling_kw, rng_mode="device", seed=777, use_hip_graph=True)
     inner = nets.load_fixture_weights(nets.egnn_net(1, "radial_cutoff", 7.5), load_golden("traj_egnn_rc.npz"))
+    net = nets.ScaledScore(inner, float(g["score_factor"])).to(cuda)
+    net.edge_chain_precision = precision
+    gen = P["Langevin"](npar, spar, net)
+    calls = []
+    with torch.no_grad():
+        for _ in range(len(g["seeds"])):
+            out = gen.sample(int(g["batch"]), cuda)
+            assert (out.A == 0).all()
+            calls.append(out.X.cpu().numpy())
+    assert gen.f16_range_fallbacks == 0
+    assert all(layer._chain[1] is not None and layer._chain[1].precision == precision for layer in inner.egnn.graph_layers)
+    assert judge(g, calls) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_repaint_graph_loop_samples_the_reference_distribution(cuda, use_graph):
+    """ConstrainedLangevinGenerator (repaint: BASELINE configs[4]'s algorithm) in the fast mode -- device Philox, the known
+    rows noised and written by the HIP repaint kernel inside the captured iteration -- around the small radial-cutoff EGNN
+    (score x 100), 32 of 64 atoms pinned at diamond sites: the distribution of the 32 FREE atoms (and of their distance to the
+    nearest pinned site) against the reference's ConstrainedLangevinGenerator, 6 calls of 64 structures."""
+    from test_generator_gpu import _pkg
+    import warnings
+    P = _pkg()
+    g = load_golden("dist_egnn_repaint.npz")
+    sites = torch.from_numpy(g["pinned_sites"])
+    K = sites.shape[0]
+    noise_kw = cases.noise_ns(100, **cases.LIN)
+    sampling_kw = cases.sampling_ns(64, 1, M=2, one=False, greedy=False, cell=[10.86] * 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = P["Noise"](**noise_kw)
+        spar = P["Sampling"](**sampling_kw, rng_mode="device", seed=888, use_hip_graph=use_graph)
+    inner = nets.load_fixture_weights(nets.egnn_net(1, "radial_cutoff", 7.5), load_golden("traj_egnn_rc.npz"))
+    net = nets.ScaledScore(inner, float(g["score_factor"])).to(cuda)
+    constraint = P["Constraint"](elements=["Si"], constrained_relative_coordinates=sites.clone(),
+                                 constrained_atom_types=torch.zeros(K, dtype=torch.long))
+    gen = P["Constrained"](npar, spar, net, constraint)
+    calls = []
+    with torch.no_grad():
+        for _ in range(len(g["seeds"])):
+            out = gen.sample(int(g["batch"]), cuda)
+            assert (out.A == 0).all()
+            x = out.X.cpu()
+            u = x[:, :K] - sites[None]                  # (the last correctors move the known rows off their sites a little,
+            assert float((u - u.round()).abs().max()) < 0.02          # as in the reference: the repaint is in the predictor)
+            calls.append(x.numpy())
+    assert gen.f16_range_fallbacks == 0
+    assert judge(g, calls) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_production_egnn_graph_loop_samples_the_reference_distribution(cuda, precision):
+    """The network BASELINE configs[2] is quoted on (EGNN 4 x 256 x 4, rc 7.5, formula weights: the benchmarked kernel
+    instantiation, egnn_edge_chain_kernel<256, ...>) over whole trajectories of T = 100 of configs[2]'s schedule, M = 2, N = 64,
+    coordinate score x 150 on both sides; device Philox, hipGraph loop; 6 calls of 16 structures against the reference's 6 x 16."""
+    from test_generator_gpu import _pkg
+    import warnings
+    P = _pkg()
+    g = load_golden("dist_egnn_c3_wide.npz")
+    noise_kw = cases.noise_ns(100, **cases.LIN)
+    sampling_kw = cases.sampling_ns(64, 1, M=2, one=False, greedy=False, cell=[10.86] * 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = P["Noise"](**noise_kw)
+        spar = P["Sampling"](**sampling_kw, rng_mode="device", seed=4242, use_hip_graph=True)
+    inner = nets.egnn_c3_net(1)
     net = nets.ScaledScore(inner, float(g["score_factor"])).to(cuda)
     net.edge_chain_precision = precision
     gen = P["Langevin"](npar, spar, net)

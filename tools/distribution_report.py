@@ -85,3 +85,35 @@ with torch.no_grad(), warnings.catch_warnings():
     for probe in ("zero_score", "score_x0.5", "score_x0.9", "no_corrector"):
         print(f"   reference-side wrong sampler {probe:14s}: " + ", ".join(f"{k} {float(g[f'probe/{probe}/{k}']):.4f}" for k in T.POOLED) +
               f"  -> {'rejected' if T.probe_fails(g, probe) else 'not seen'}")
+
+    g = load_golden("dist_egnn_c3_wide.npz")
+    for precision in ("f16x3", "f32"):
+        net = nets.ScaledScore(nets.egnn_c3_net(1), float(g["score_factor"])).to(cuda)
+        net.edge_chain_precision = precision
+        gen = P["Langevin"](P["Noise"](**cases.noise_ns(100, **cases.LIN)),
+                            P["Sampling"](**cases.sampling_ns(64, 1, M=2, one=False, greedy=False, cell=[10.86] * 3),
+                                          rng_mode="device", seed=4242, use_hip_graph=True), net)
+        summary(f"production EGNN 4 x 256 x 4 (configs[2]'s network), N = 64, T = 100, score x {float(g['score_factor']):.0f}, "
+                f"hipGraph loop, edge chain {precision}", g,
+                [gen.sample(int(g["batch"]), cuda).X.cpu().numpy() for _ in range(len(g["seeds"]))])
+    for probe in ("zero_score", "score_x0.5", "no_corrector"):
+        print(f"   reference-side wrong sampler {probe:14s}: " + ", ".join(f"{k} {float(g[f'probe/{probe}/{k}']):.4f}" for k in T.POOLED) +
+              f"  (judged on {', '.join(T.scalars_of(g))})  -> {'rejected' if T.probe_fails(g, probe) else 'not seen'}")
+
+    if os.path.exists(os.path.join(ROOT, "tests", "golden", "dist_egnn_repaint.npz")):
+        g = load_golden("dist_egnn_repaint.npz")
+        sites = torch.from_numpy(g["pinned_sites"])
+        for use_graph in (True, False):
+            inner = nets.load_fixture_weights(nets.egnn_net(1, "radial_cutoff", 7.5), load_golden("traj_egnn_rc.npz"))
+            net = nets.ScaledScore(inner, float(g["score_factor"])).to(cuda)
+            constraint = P["Constraint"](elements=["Si"], constrained_relative_coordinates=sites.clone(),
+                                         constrained_atom_types=torch.zeros(sites.shape[0], dtype=torch.long))
+            gen = P["Constrained"](P["Noise"](**cases.noise_ns(100, **cases.LIN)),
+                                   P["Sampling"](**cases.sampling_ns(64, 1, M=2, one=False, greedy=False, cell=[10.86] * 3),
+                                                 rng_mode="device", seed=888, use_hip_graph=use_graph), net, constraint)
+            summary(f"repaint (ConstrainedLangevinGenerator), EGNN hidden 32, 32 of 64 atoms pinned, T = 100, "
+                    f"{'hipGraph' if use_graph else 'eager'}: the 32 free atoms", g,
+                    [gen.sample(int(g["batch"]), cuda).X.cpu().numpy() for _ in range(len(g["seeds"]))])
+        for probe in ("zero_score", "score_x0.5", "no_corrector", "no_repaint"):
+            print(f"   reference-side wrong sampler {probe:14s}: " + ", ".join(f"{k} {float(g[f'probe/{probe}/{k}']):.4f}" for k in T.scalars_of(g)) +
+                  f"  -> {'rejected' if T.probe_fails(g, probe) else 'not seen'}")
