@@ -104,6 +104,7 @@ def probe_fails(g, probe):
     ("dist_mlp_c2.npz", ["zero_score", "no_corrector"], ["score_x0.9", "sigma_max_0.2"]),
     ("dist_egnn_rc.npz", ["zero_score", "score_x0.5", "no_corrector"], []),
     ("dist_egnn_c3_wide.npz", ["zero_score", "score_x0.5", "no_corrector"], []),
+    ("dist_egnn_repaint.npz", ["zero_score", "score_x0.5", "no_corrector", "no_repaint"], []),
     ("dist_analytic.npz", ["zero_score", "score_x0.9", "score_x0.97", "no_corrector", "sigma_min_1e-2"], ["sigma_max_0.2"])])
 def test_the_criterion_has_teeth(fixture, caught, missed):
     """The reference's own wrong samplers against the criterion: a zeroed score, a halved score and a run without correctors
