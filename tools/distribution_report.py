@@ -25,7 +25,8 @@ P = _pkg()
 
 def summary(title, g, calls):
     rows = T.measure(g, calls)
-    print(f"== {title}: {len(calls)} calls of {calls[0].shape[0]} structures")
+    first = calls[0][0] if isinstance(calls[0], tuple) else calls[0]
+    print(f"== {title}: {len(calls)} calls of {first.shape[0]} structures")
     groups = {}
     for what, d, limit in rows:
         key = what.split(": ", 1)[1] if what.startswith("call") else what
@@ -117,3 +118,25 @@ with torch.no_grad(), warnings.catch_warnings():
         for probe in ("zero_score", "score_x0.5", "no_corrector", "no_repaint"):
             print(f"   reference-side wrong sampler {probe:14s}: " + ", ".join(f"{k} {float(g[f'probe/{probe}/{k}']):.4f}" for k in T.scalars_of(g)) +
                   f"  -> {'rejected' if T.probe_fails(g, probe) else 'not seen'}")
+
+    for fixture, greedy_one in (("dist_egnn_types.npz", False), ("dist_egnn_types_greedy.npz", True)):
+        if not os.path.exists(os.path.join(ROOT, "tests", "golden", fixture)):
+            continue
+        g = load_golden(fixture)
+        inner = nets.load_fixture_weights(nets.egnn_net(2, "radial_cutoff", 7.5), load_golden("net_egnn_rc.npz"))
+        net = nets.ScaledScore(inner, float(g["score_factor"]), float(g["logit_factor"])).to(cuda)
+        gen = P["Langevin"](P["Noise"](**cases.noise_ns(100, **cases.LIN)),
+                            P["Sampling"](**cases.sampling_ns(64, 2, M=2, one=greedy_one, greedy=greedy_one, cell=[11.084] * 3),
+                                          rng_mode="device", seed=999, use_hip_graph=True), net)
+        calls = []
+        for _ in range(len(g["seeds"])):
+            out = gen.sample(int(g["batch"]), cuda)
+            calls.append((out.X.cpu().numpy(), out.A.cpu().numpy()))
+        summary(f"two atom types, EGNN hidden 32, N = 64, T = 100, logits x {float(g['logit_factor']):.0f}, "
+                f"{'greedy + one transition per step' if greedy_one else 'Gumbel draws'}, hipGraph loop", g, calls)
+        mean, limit = T.type_fraction_limits(g)
+        print(f"   fraction of type 0: reference seeds {np.round(g['type_fraction/per_seed'], 4)} (mean {mean:.4f}, limit +- {limit:.4f}); "
+              f"product calls {np.round([float((a == 0).mean()) for _, a in calls], 4)}")
+        for probe in ("zero_score", "uniform_types", "logits_x0.5", "other_type_update"):
+            print(f"   reference-side wrong sampler {probe:18s}: " + ", ".join(f"{k} {float(g[f'probe/{probe}/{k}']):.4f}" for k in T.scalars_of(g)) +
+                  f", type fraction {float(g[f'probe_type_fraction/{probe}']):.4f}  -> {'rejected' if T.probe_fails(g, probe) else 'not seen'}")
