@@ -11,6 +11,7 @@ used here, all functions of the final relative coordinates X [B, N, 3] of an ort
   x, y, z every atom's coordinate along one axis                                                  B N values each
   atom<k><axis>  (optional, networks that are not permutation equivariant) the coordinate of atom k along an axis: B values
   to_pinned  (repaint runs) every free atom's minimum-image distance to the nearest pinned site      B (N - K) values
+  pair_same, pair_diff, nn_same  (several atom types) pair distances by equal / different type, nearest atom of the own type
 
 The reference side is stored as QUANTILE TABLES (tests/golden/dist_*.npz, made by tests/golden/make_distributions.py from the
 reference's own runs): `table[k]` = the k / (len - 1) quantile of the pooled reference sample.  ks_to_table evaluates
@@ -25,11 +26,13 @@ def _minimum_image_distances(X):
     return np.sqrt((d * d).sum(-1))                    # [B, N, N]
 
 
-def statistics(X, per_atom=False, sites=None, pinned=None):
+def statistics(X, per_atom=False, sites=None, pinned=None, types=None):
     """dict name -> 1-D float64 array of the scalars listed in the module docstring; with `sites` [N, 3] also `disp`: the
     displacement of every coordinate from its site, wrapped to [-1/2, 1/2).  With `pinned` [K, 3] (a repaint run: the first K
     atoms are held at these sites) the scalars are those of the FREE atoms X[:, K:] alone, plus `to_pinned`: every free atom's
-    minimum-image distance to the nearest pinned site."""
+    minimum-image distance to the nearest pinned site.  With `types` [B, N] (several atom types) also `pair_same` /
+    `pair_diff` (the pair distances between atoms of equal / of different type) and `nn_same` (every atom's distance to the
+    nearest atom of its own type): continuous scalars that carry the joint distribution of types and positions."""
     X = np.asarray(X)
     if pinned is not None:
         pinned = np.asarray(pinned, np.float64)
@@ -43,8 +46,15 @@ def statistics(X, per_atom=False, sites=None, pinned=None):
     r = _minimum_image_distances(X)
     iu = np.triu_indices(N, k=1)
     out = {"pair": r[:, iu[0], iu[1]].ravel()}
+    if types is not None:
+        same = np.asarray(types)[:, :, None] == np.asarray(types)[:, None, :]
+        pairs, same_pairs = r[:, iu[0], iu[1]], same[:, iu[0], iu[1]]
+        out["pair_same"], out["pair_diff"] = pairs[same_pairs], pairs[~same_pairs]
     r[:, np.arange(N), np.arange(N)] = np.inf
     out["nn"] = r.min(-1).ravel()
+    if types is not None:
+        nn_same = np.where(same, r, np.inf).min(-1).ravel()
+        out["nn_same"] = nn_same[np.isfinite(nn_same)]           # (an atom alone of its type in a structure has none)
     for k, axis in enumerate("xyz"):
         out[axis] = X[..., k].astype(np.float64).ravel()
     if sites is not None:

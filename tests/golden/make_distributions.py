@@ -1,6 +1,6 @@
 """Reference-made DISTRIBUTIONS of whole sampling jobs (container-only: imports /root/reference through make_golden's stubs).
 
-    PYTHONPATH=/root/reference/src python tests/golden/make_distributions.py [analytic|mlp|egnn|egnn_c3_wide|egnn_repaint]
+    PYTHONPATH=/root/reference/src python tests/golden/make_distributions.py [analytic|mlp|egnn|egnn_c3_wide|egnn_repaint|egnn_types|egnn_types_greedy]
 
 Runs the REFERENCE's LangevinGenerator for complete trajectories where that is cheap, several seeds each, and stores summary
 statistics only -- quantile tables of the pooled final structures' scalars (tests/distribution_stats.py), the reference-vs-
@@ -17,6 +17,8 @@ and the KS distance of deliberately WRONG samplers to the pool (the power of the
                     (see egnn_rc below: with the bare random-init network the check would have no power)
   dist_egnn_repaint.npz  ConstrainedLangevinGenerator (repaint, configs[4]'s algorithm) around the same small EGNN: 32 of the 64 atoms
                     pinned at diamond sites, the statistics of the 32 free ones
+  dist_egnn_types.npz, dist_egnn_types_greedy.npz  two atom types (configs[3]'s cell): the small EGNN with num_atom_types = 2, types
+                    drawn with Gumbel noise / configs[3]'s greedy + one-transition settings; logits x 10
   dist_egnn_c3_wide.npz  the PRODUCTION network of configs[2] (EGNN 4 x 256 x 4, rc 7.5, formula weights), same schedule and
                     T = 100, 16 structures x 6 seeds; coordinate score x 150
 
@@ -41,19 +43,26 @@ LIN = dict(sigma_min=1e-4, sigma_max=0.2, schedule_type="linear", corrector_step
 
 
 class ScaledScore(torch.nn.Module):
-    """A deliberately wrong network for the power probes: the wrapped network's coordinate score times a factor."""
+    """A deliberately wrong network for the power probes: the wrapped network's coordinate score times a factor (and its
+    atom-type logits times `logit_factor`; the MASK class's -inf stays -inf)."""
 
-    def __init__(self, net, factor):
+    def __init__(self, net, factor, logit_factor=1.0):
         super().__init__()
-        self.net, self.factor = net, factor
+        self.net, self.factor, self.logit_factor = net, factor, logit_factor
 
     def forward(self, batch, conditional=False):
         out = self.net(batch, conditional=conditional)
-        return G.AXL(A=out.A, X=out.X * self.factor, L=out.L)
+        A = out.A if self.logit_factor == 1.0 else torch.where(torch.isinf(out.A), out.A, out.A * self.logit_factor)
+        return G.AXL(A=A, X=out.X * self.factor, L=out.L)
 
 
-def run(make, seeds, batch, per_atom, name, probes, extra=None, sites=None, probe_calls=1, pinned=None):
-    per_seed = []
+def run(make, seeds, batch, per_atom, name, probes, extra=None, sites=None, probe_calls=1, pinned=None, with_types=False):
+    per_seed, fractions = [], []
+
+    def stats(axl):
+        return DS.statistics(axl.X.numpy(), per_atom=per_atom, sites=sites, pinned=pinned,
+                             types=axl.A.numpy() if with_types else None)
+
     for seed in seeds:
         gen = make()
         torch.manual_seed(seed)
@@ -61,7 +70,8 @@ def run(make, seeds, batch, per_atom, name, probes, extra=None, sites=None, prob
         with torch.no_grad():
             axl = gen.sample(batch, torch.device("cpu"))
         assert (axl.A != gen.num_classes - 1).all()
-        per_seed.append(DS.statistics(axl.X.numpy(), per_atom=per_atom, sites=sites, pinned=pinned))
+        per_seed.append(stats(axl))
+        fractions.append(float((axl.A == 0).double().mean()))
         print(f"{name}: seed {seed} done in {time.perf_counter() - t0:.1f} s", flush=True)
     keys = list(per_seed[0])
     out = {"seeds": np.array(seeds), "batch": np.array(batch), "scalars": np.array(keys)}
@@ -87,6 +97,9 @@ def run(make, seeds, batch, per_atom, name, probes, extra=None, sites=None, prob
             halves.append(DS.ks_two_sample(a, b))
         out[f"half_split/{key}"] = np.array(halves)
     out["probe_calls"] = np.array(probe_calls)
+    if with_types:          # the fraction of atoms that end as type 0, per seed (one number per call: held by its spread, not by KS)
+        out["type_fraction/per_seed"] = np.array(fractions)
+        print(f"{name}: fraction of type 0 per seed {np.round(fractions, 4)}", flush=True)
     for probe, make_wrong in probes.items():
         calls = []
         for c in range(probe_calls):          # the wrong sampler's calls: the first alone, and all of them pooled
@@ -94,16 +107,19 @@ def run(make, seeds, batch, per_atom, name, probes, extra=None, sites=None, prob
             torch.manual_seed(seeds[0] + 1000 * c)
             with torch.no_grad():
                 axl = gen.sample(batch, torch.device("cpu"))
-            calls.append(DS.statistics(axl.X.numpy(), per_atom=per_atom, sites=sites, pinned=pinned))
+            calls.append(stats(axl))
+            if with_types and c == 0:
+                out[f"probe_type_fraction/{probe}"] = np.array(float((axl.A == 0).double().mean()))
         for key in keys:
             table = out[f"table/{key}"].astype(np.float64)
             out[f"probe/{probe}/{key}"] = np.array(DS.ks_to_table(calls[0][key], table))
             if probe_calls > 1:
                 out[f"probe_pooled/{probe}/{key}"] = np.array(DS.ks_to_table(np.concatenate([c[key] for c in calls]), table))
-        print(f"{name}: probe {probe}: " + ", ".join(f"{k} {float(out[f'probe/{probe}/{k}']):.3f}" for k in keys[:6]) +
+        print(f"{name}: probe {probe}: " + ", ".join(f"{k} {float(out[f'probe/{probe}/{k}']):.3f}" for k in keys[:8]) +
+              (f", type fraction {float(out[f'probe_type_fraction/{probe}']):.4f}" if with_types else "") +
               (" | pooled: " + ", ".join(f"{k} {float(out[f'probe_pooled/{probe}/{k}']):.4f}" for k in keys[:5]) if probe_calls > 1 else ""),
               flush=True)
-    for key in keys[:6]:
+    for key in keys[:8]:
         print(f"{name}: {key}: leave-one-out {out[f'leave_one_out/{key}'].round(4)}  pairwise max {out[f'pairwise/{key}'].max():.4f}")
     out.update(extra or {})
     G.save(name + ".npz", **out)
@@ -171,6 +187,34 @@ def egnn_repaint():
     }
     run(make, seeds=[41, 42, 43, 44, 45, 46], batch=64, per_atom=False, name="dist_egnn_repaint", probes=probes,
         extra={"score_factor": np.array(EGNN_SCORE_FACTOR), "pinned_sites": G._np(sites)}, pinned=G._np(sites))
+
+
+LOGIT_FACTOR = 10.0
+
+
+def egnn_two_types(greedy_one):
+    """Two atom types (BASELINE configs[3]'s SiGe cell, 11.084): the small radial-cutoff EGNN with num_atom_types = 2 (weights =
+    tests/golden/net_egnn_rc.npz), N = 64, T = 100 of configs[2]'s schedule, M = 2, 64 structures per seed; coordinate score
+    x 100 and atom-type LOGITS x 10 on both sides (the random-init network's logits differ by 0.2: every class probability
+    would be 0.5 +- 0.05 whatever the sampler does with them).  Two settings of the atom-type update
+    (src/.../generators/langevin_generator.py:247-439): greedy_one = False -- types drawn with Gumbel noise, any number of
+    transitions per step (the device-Philox uniforms of the fast mode at work); greedy_one = True -- configs[3]'s own settings
+    (atom_type_greedy_sampling and one_atom_type_transition_per_step on).  Stored besides the position scalars: pair distances
+    by equal / different type, the nearest atom of the own type, and the fraction of atoms that end as type 0 per seed."""
+    kw = dict(T=100, N=64, num_atom_types=2, M=2, one=greedy_one, greedy=greedy_one, cell=[11.084] * 3, noise_kw=LIN)
+
+    def make(factor=EGNN_SCORE_FACTOR, logit_factor=LOGIT_FACTOR, **over):
+        net = ScaledScore(G._egnn(2, "radial_cutoff", 7.5), factor, logit_factor)
+        return G.make_generator(net=net, **dict(kw, **over))[0]
+    probes = {
+        "zero_score": lambda: make(factor=0.0),
+        "uniform_types": lambda: make(logit_factor=0.0),
+        "logits_x0.5": lambda: make(logit_factor=0.5 * LOGIT_FACTOR),
+        "other_type_update": lambda: make(one=not greedy_one, greedy=not greedy_one),
+    }
+    name = "dist_egnn_types_greedy" if greedy_one else "dist_egnn_types"
+    run(make, seeds=[51, 52, 53, 54, 55, 56], batch=64, per_atom=False, name=name, probes=probes, with_types=True,
+        extra={"score_factor": np.array(EGNN_SCORE_FACTOR), "logit_factor": np.array(LOGIT_FACTOR)})
 
 
 C3_WIDE_SCORE_FACTOR = 150.0
@@ -263,3 +307,7 @@ if __name__ == "__main__":
         egnn_c3_wide()
     if which in ("all", "egnn_repaint"):
         egnn_repaint()
+    if which in ("all", "egnn_types"):
+        egnn_two_types(False)
+    if which in ("all", "egnn_types_greedy"):
+        egnn_two_types(True)

@@ -72,14 +72,15 @@ def oracle_edge_builder(relative_coordinates, unit_cell, radial_cutoff):
 
 
 class ScaledScore(torch.nn.Module):
-    """A plugin around a score network: the coordinate score times a factor (tests/golden/make_distributions.py wraps the
-    reference's EGNN the same way, so that the distribution the sampler ends in depends on the score).  What the generators look
+    """A plugin around a score network: the coordinate score times a factor, the atom-type logits times `logit_factor` (the MASK
+    class's -inf stays) (tests/golden/make_distributions.py wraps the reference's EGNN the same way, so that the distribution
+    the sampler ends in depends on the score).  What the generators look
     for on a network -- the status word of its HIP kernels, the arithmetic of its MFMA kernels -- is passed through, as
     ForceFieldAugmentedScoreNetwork does."""
 
-    def __init__(self, net, factor):
+    def __init__(self, net, factor, logit_factor=1.0):
         super().__init__()
-        self.net, self.factor = net, float(factor)
+        self.net, self.factor, self.logit_factor = net, float(factor), float(logit_factor)
 
     @property
     def graph_status(self):
@@ -95,7 +96,8 @@ class ScaledScore(torch.nn.Module):
 
     def forward(self, batch, conditional=None):
         out = self.net(batch, conditional)
-        return AXL(A=out.A, X=out.X * self.factor, L=out.L)
+        A = out.A if self.logit_factor == 1.0 else torch.where(torch.isinf(out.A), out.A, out.A * self.logit_factor)
+        return AXL(A=A, X=out.X * self.factor, L=out.L)
 
 
 class GaussianWellScoreNetwork(ScoreNetwork):

@@ -52,22 +52,41 @@ def thresholds(g, n_calls=None):
     return lim, atoms
 
 
+TYPED = ("pair_same", "pair_diff", "nn_same")
+
+
 def scalars_of(g):
     """the pooled scalars a fixture is judged on: the ones it names (`judged`), else the five common ones, `disp` when it names
-    sites, `to_pinned` for a repaint run"""
+    sites, `to_pinned` for a repaint run, the type-aware ones for several atom types"""
     if "judged" in g.files:
         return tuple(str(k) for k in g["judged"])
-    return POOLED + (("disp",) if "sites" in g.files else ()) + (("to_pinned",) if "pinned_sites" in g.files else ())
+    return (POOLED + (("disp",) if "sites" in g.files else ()) + (("to_pinned",) if "pinned_sites" in g.files else ()) +
+            (TYPED if "type_fraction/per_seed" in g.files else ()))
+
+
+def type_fraction_limits(g):
+    """(mean of the reference's seeds, allowed distance of one call from it): the fraction of atoms ending as type 0 is one
+    number per call, held to MARGIN x the largest distance of a reference seed from the mean of the others."""
+    f = g["type_fraction/per_seed"]
+    loo = np.array([abs(f[i] - np.delete(f, i).mean()) for i in range(f.size)])
+    return float(f.mean()), MARGIN * float(loo.max())
 
 
 def measure(g, calls):
-    """calls: list of X [B, N, 3] (one per sample() call) -> rows (what, measured KS distance, limit)."""
+    """calls: list of X [B, N, 3] (one per sample() call), or of (X, A [B, N]) for a fixture with several atom types
+    -> rows (what, measured KS distance, limit)."""
     lim, atoms = thresholds(g, len(calls))
     pooled = scalars_of(g)
     table = {k: g[f"table/{k}"] for k in list(pooled) + atoms}
     rows = []
-    per_call = [DS.statistics(x, per_atom=bool(atoms), sites=g["sites"] if "sites" in g.files else None,
-                              pinned=g["pinned_sites"] if "pinned_sites" in g.files else None) for x in calls]
+    typed = "type_fraction/per_seed" in g.files
+    per_call = [DS.statistics(c[0] if typed else c, per_atom=bool(atoms), sites=g["sites"] if "sites" in g.files else None,
+                              pinned=g["pinned_sites"] if "pinned_sites" in g.files else None, types=c[1] if typed else None)
+                for c in calls]
+    if typed:
+        mean, limit = type_fraction_limits(g)
+        for c, (_, A) in enumerate(calls):
+            rows.append((f"call {c}: fraction of type 0", abs(float((np.asarray(A) == 0).mean()) - mean), limit))
     for c, st in enumerate(per_call):
         for k in pooled:
             rows.append((f"call {c}: {k}", DS.ks_to_table(st[k], table[k]), lim[k][0]))
@@ -92,6 +111,9 @@ def probe_fails(g, probe):
     calls = int(g["probe_calls"]) if "probe_calls" in g.files else 1
     lim, atoms = thresholds(g, calls)
     bad = any(float(g[f"probe/{probe}/{k}"]) > lim[k][0] for k in scalars_of(g))
+    if "type_fraction/per_seed" in g.files:
+        mean, limit = type_fraction_limits(g)
+        bad = bad or abs(float(g[f"probe_type_fraction/{probe}"]) - mean) > limit
     if calls > 1:
         bad = bad or any(float(g[f"probe_pooled/{probe}/{k}"]) > lim[k][1] for k in scalars_of(g))
     if atoms:
@@ -105,6 +127,7 @@ def probe_fails(g, probe):
     ("dist_egnn_rc.npz", ["zero_score", "score_x0.5", "no_corrector"], []),
     ("dist_egnn_c3_wide.npz", ["zero_score", "score_x0.5", "no_corrector"], []),
     ("dist_egnn_repaint.npz", ["zero_score", "score_x0.5", "no_corrector", "no_repaint"], []),
+    ("dist_egnn_types.npz", ["zero_score", "uniform_types", "logits_x0.5", "other_type_update"], []),
     ("dist_analytic.npz", ["zero_score", "score_x0.9", "score_x0.97", "no_corrector", "sigma_min_1e-2"], ["sigma_max_0.2"])])
 def test_the_criterion_has_teeth(fixture, caught, missed):
     """The reference's own wrong samplers against the criterion: a zeroed score, a halved score and a run without correctors
@@ -237,6 +260,36 @@ def test_egnn_graph_loop_samples_the_reference_distribution(cuda, precision):
             calls.append(out.X.cpu().numpy())
     assert gen.f16_range_fallbacks == 0
     assert all(layer._chain[1] is not None and layer._chain[1].precision == precision for layer in inner.egnn.graph_layers)
+    assert judge(g, calls) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,greedy_one", [("dist_egnn_types.npz", False), ("dist_egnn_types_greedy.npz", True)])
+def test_two_atom_types_graph_loop_samples_the_reference_distribution(cuda, fixture, greedy_one):
+    """Two atom types (configs[3]'s cell) in the fast mode: the atom-type update kernel with in-kernel Philox uniforms (Gumbel
+    draws; or configs[3]'s greedy + one-transition settings) inside the captured iteration, around the small two-type EGNN with
+    score x 100 and logits x 10 on both sides.  Held to the reference: the position scalars, the pair distances by equal /
+    different type, the nearest atom of the own type, and the fraction of atoms that end as type 0; 6 calls of 64 structures."""
+    from test_generator_gpu import _pkg
+    import warnings
+    P = _pkg()
+    g = load_golden(fixture)
+    noise_kw = cases.noise_ns(100, **cases.LIN)
+    sampling_kw = cases.sampling_ns(64, 2, M=2, one=greedy_one, greedy=greedy_one, cell=[11.084] * 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = P["Noise"](**noise_kw)
+        spar = P["Sampling"](**sampling_kw, rng_mode="device", seed=999, use_hip_graph=True)
+    inner = nets.load_fixture_weights(nets.egnn_net(2, "radial_cutoff", 7.5), load_golden("net_egnn_rc.npz"))
+    net = nets.ScaledScore(inner, float(g["score_factor"]), float(g["logit_factor"])).to(cuda)
+    gen = P["Langevin"](npar, spar, net)
+    calls = []
+    with torch.no_grad():
+        for _ in range(len(g["seeds"])):
+            out = gen.sample(int(g["batch"]), cuda)
+            assert (out.A < 2).all()
+            calls.append((out.X.cpu().numpy(), out.A.cpu().numpy()))
+    assert gen.f16_range_fallbacks == 0
     assert judge(g, calls) == []
 
 
