@@ -297,6 +297,50 @@ def test_egnn_forward_edge_chain_modes(cuda, hidden, n_layers, n_hidden):
     assert errs["plain"][0] < 1.5e-5 and errs["plain"][1] < 1e-5, errs
 
 
+@pytest.mark.parametrize("rc,expect_edges,N", [(3.0, True, 16), (0.5, False, 16), (3.0, False, 1)])
+@pytest.mark.parametrize("two_call", [False, True])
+def test_egnn_forward_sparse_and_empty_graphs(cuda, rc, expect_edges, two_call, N):
+    """Dilute structures (16 atoms in a 30 A cell): most atoms have no neighbour inside the cutoff, whole structures have no
+    edge, and with rc = 0.5 the batch's graph is EMPTY.  The reference's segment sums then add nothing and every layer reduces
+    to the node MLP on [h | 0]; the fused path (radius graph with zero counts, edge chain on zero tiles, piece sums of empty
+    segments) must return what the plain PyTorch module returns, in every arithmetic mode, with the capacity-sized edge list
+    and with the two-call radius graph."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
+                                                                              NOISY_AXL_COMPOSITION, TIME)
+    torch.manual_seed(11)
+    net = nets.egnn_net(2, "radial_cutoff", rc, hidden=64, n_layers=2, n_hidden=2).to(cuda)
+    if two_call:
+        net.static_edge_list_max_fraction = 0.0
+    B = 5                                                                     # (N = 1: a structure of a single atom)
+    batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.randint(0, 3, (B, N), device=cuda), X=torch.rand(B, N, 3, device=cuda),
+                                        L=torch.tensor([30.0] * 3 + [0.0] * 3, device=cuda).repeat(B, 1)),
+             TIME: torch.rand(B, 1, device=cuda), NOISE: torch.rand(B, 1, device=cuda) * 0.2,
+             CARTESIAN_FORCES: torch.zeros(B, N, 3, device=cuda)}
+    x = batch[NOISY_AXL_COMPOSITION].X.double()
+    delta = x[:, :, None, :] - x[:, None, :, :]
+    r = ((delta - delta.round()) * 30.0).norm(dim=-1)
+    degree = ((r <= rc) & (r > 0)).sum(-1)                                    # brute-force minimum-image degrees
+    assert (int(degree.sum()) > 0) == expect_edges and int((degree == 0).sum()) >= B * N // 2
+    outs = {}
+    for mode in ("f32", "f16x3", None, "plain"):
+        net.edge_chain_precision = None if mode == "plain" else mode
+        for layer in net.egnn.graph_layers:
+            layer.use_fused_ops = mode != "plain"
+        with torch.no_grad():
+            outs[mode] = net(batch, conditional=False)
+        net.check_status()
+        assert torch.isfinite(outs[mode].X).all() and torch.isfinite(outs[mode].A[..., :-1]).all(), mode
+    plain = outs["plain"]
+    if not expect_edges:                         # no edge, no coordinate update: the score is an exact zero on both paths
+        assert (plain.X == 0).all()
+    for mode in ("f32", "f16x3", None):
+        assert _rel_l2(outs[mode].A[..., :-1], plain.A[..., :-1]) < 1e-5, mode
+        if expect_edges:
+            assert _rel_l2(outs[mode].X, plain.X) < 1e-5, mode
+        else:
+            assert (outs[mode].X == 0).all(), mode
+
+
 def test_egnn_conditional_forward_keeps_the_mask_logit(cuda):
     """ScoreNetwork.forward(conditional=True) blends two evaluations (score_network.py:187-223); on the fused path each of them
     already carries the MASK logit at -inf (mdx_egnn_outputs), and -inf times a zero weight is a NaN: the base class's
