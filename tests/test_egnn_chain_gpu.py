@@ -429,7 +429,7 @@ def test_radius_graph_static_equals_two_call(cuda):
     assert torch.equal(guard[:small], ref["edges"][:small]) and (guard[small:] == -5).all()
 
 
-@pytest.mark.parametrize("B,N", [(3, 5), (7, 64), (70, 64), (2, 200), (257, 65), (520, 64)])
+@pytest.mark.parametrize("B,N", [(3, 5), (7, 64), (70, 64), (2, 200), (257, 65), (520, 64), (2, 513), (1, 1000)])
 def test_egnn_radius_graph_from_relative_coordinates(cuda, B, N):
     """mdx_egnn_radius_graph (relative coordinates + lattice parameters in, clip / diagonal cell / positions / scan inside: three
     launches) gives bit for bit what the score network built before from torch.clip, diag_embed, matmul, the two radius-graph

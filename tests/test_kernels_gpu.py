@@ -359,7 +359,7 @@ def test_radius_graph_golden(K, oracle, cuda):
 
 
 @pytest.mark.parametrize("B,N,box,rc", [(1, 1, 5.0, 2.0), (3, 2, 4.0, 1.9), (2, 65, 9.0, 4.0), (5, 130, 12.0, 3.0),
-                                        (2, 216, 16.5, 7.5), (16, 64, 16.5, 7.5), (2, 17, 6.0, 5.9)])
+                                        (2, 216, 16.5, 7.5), (16, 64, 16.5, 7.5), (2, 17, 6.0, 5.9), (1, 700, 25.0, 5.0)])
 def test_radius_graph_random(K, oracle, cuda, B, N, box, rc):
     rng = np.random.default_rng(N)
     X = rng.random((B, N, 3), dtype=np.float32)
@@ -370,7 +370,7 @@ def test_radius_graph_random(K, oracle, cuda, B, N, box, rc):
 
 
 @pytest.mark.parametrize("B,N,box,rc", [(4, 64, 16.5, 7.5), (3, 216, 16.5, 7.5), (5, 8, 5.43, 2.4), (2, 100, 11.0, 5.0),
-                                        (2, 33, 10.0, 4.6)])
+                                        (2, 33, 10.0, 4.6), (1, 1000, 27.2, 7.5)])
 def test_radius_graph_orthorhombic_fast_path(K, oracle, cuda, B, N, box, rc):
     """Diagonal cells with rc <= L/2.2 take the nearest-image path (one image evaluated instead of 27); rc > L/2.2
     (last case) and the triclinic cases above take the 27-image path.  Both must equal the oracle's brute force."""
