@@ -243,18 +243,18 @@ def test_coord_aggregate_against_torch(cuda):
         assert _rel_l2(got, want) < 1e-6
 
 
-@pytest.mark.parametrize("hidden,n_layers,n_hidden", [(32, 2, 2), (128, 3, 3), (256, 4, 4)])
-def test_egnn_forward_edge_chain_modes(cuda, hidden, n_layers, n_hidden):
-    """EGNNScoreNetwork.forward (radius graph, N = 64, two atom types) with the fused MFMA edge chain -- exact binary32
+@pytest.mark.parametrize("hidden,n_layers,n_hidden,B,N,box", [(32, 2, 2, 6, 64, 11.084), (128, 3, 3, 6, 64, 11.084),
+                                                              (256, 4, 4, 6, 64, 11.084), (64, 2, 2, 2, 500, 22.0)])
+def test_egnn_forward_edge_chain_modes(cuda, hidden, n_layers, n_hidden, B, N, box):
+    """EGNNScoreNetwork.forward (radius graph, N = 64 and one 500-atom case, two atom types) with the fused MFMA edge chain -- exact binary32
     and split-f16 -- against the per-layer library-GEMM path and against the plain PyTorch module: scores and logits
     within 1e-5 of the output scale; fp64 evaluation of the same module as the common yardstick."""
     from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
                                                                               NOISY_AXL_COMPOSITION, TIME)
     torch.manual_seed(7)
     net = nets.egnn_net(2, "radial_cutoff", 7.5, hidden=hidden, n_layers=n_layers, n_hidden=n_hidden).to(cuda)
-    B, N = 6, 64
     batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.randint(0, 3, (B, N), device=cuda), X=torch.rand(B, N, 3, device=cuda),
-                                        L=torch.tensor([11.084] * 3 + [0.0] * 3, device=cuda).repeat(B, 1)),
+                                        L=torch.tensor([box] * 3 + [0.0] * 3, device=cuda).repeat(B, 1)),
              TIME: torch.rand(B, 1, device=cuda), NOISE: torch.rand(B, 1, device=cuda) * 0.2,
              CARTESIAN_FORCES: torch.zeros(B, N, 3, device=cuda)}
     outs = {}
@@ -285,16 +285,20 @@ def test_egnn_forward_edge_chain_modes(cuda, hidden, n_layers, n_hidden):
     print("EGNN forward rel-L2 vs fp64 (scores, logits):", {str(k): tuple(f"{e:.2e}" for e in v) for k, v in errs.items()})
     # (1) against the REFERENCE ARITHMETIC -- the plain PyTorch fp32 module on the same device: north_star's 1e-5.  (The
     # reference-made fixture at the production shape is tests/test_egnn_c3_reference_gpu.py; this test sweeps widths.)
+    # In the 22 A cell of the 500-atom case binary32 itself is the limit: the plain module sits 3.3e-5 from its own fp64
+    # evaluation (the update x + trans rounds at the magnitude of x; DESIGN.md section 5, the configs[4] forward), and two
+    # binary32 evaluations in different orders cannot be held closer to each other than that floor.
     plain = outs["plain"]
+    tolerance = max(1e-5, errs["plain"][0])
     for mode in ("f32", "f16x3", "f16x3_32x32", None):
         vs_plain = (_rel_l2(outs[mode].X, plain.X), _rel_l2(outs[mode].A[..., :-1], plain.A[..., :-1]))
-        assert vs_plain[0] < 1e-5 and vs_plain[1] < 1e-5, (mode, vs_plain)
+        assert vs_plain[0] < tolerance and vs_plain[1] < 1e-5, (mode, vs_plain)
     # (2) against fp64: every fp32 evaluation of this network -- the reference's included (1.4e-5 at the production shape,
     # DESIGN.md section 3a) -- carries the same rounding of the coordinate update `x + trans` (x of order one, the score is
     # extracted from the small update), 3e-6 .. 9e-6 here.  The fused paths must not be further from fp64 than plain fp32 is.
     for mode in ("f32", "f16x3", "f16x3_32x32", None):
         assert errs[mode][0] < 1.25 * errs["plain"][0] + 1e-7 and errs[mode][1] < 1.25 * errs["plain"][1] + 1e-7, (mode, errs)
-    assert errs["plain"][0] < 1.5e-5 and errs["plain"][1] < 1e-5, errs
+    assert errs["plain"][0] < (1.5e-5 if box < 12 else 5e-5) and errs["plain"][1] < 1e-5, errs
 
 
 @pytest.mark.parametrize("rc,expect_edges,N", [(3.0, True, 16), (0.5, False, 16), (3.0, False, 1)])
