@@ -213,7 +213,10 @@ def egnn_two_types(greedy_one):
         "other_type_update": lambda: make(one=not greedy_one, greedy=not greedy_one),
     }
     name = "dist_egnn_types_greedy" if greedy_one else "dist_egnn_types"
-    run(make, seeds=[51, 52, 53, 54, 55, 56], batch=64, per_atom=False, name=name, probes=probes, with_types=True,
+    # (12 seeds under the greedy settings: its first six happened to lie within 0.0018 .. 0.0021 of each other on `pair` -- the
+    # same scalar spreads over 0.0019 .. 0.0035 in dist_egnn_rc / dist_egnn_types -- and six draws do not show the tail)
+    seeds = list(range(51, 63)) if greedy_one else [51, 52, 53, 54, 55, 56]
+    run(make, seeds=seeds, batch=64, per_atom=False, name=name, probes=probes, with_types=True,
         extra={"score_factor": np.array(EGNN_SCORE_FACTOR), "logit_factor": np.array(LOGIT_FACTOR)})
 
 

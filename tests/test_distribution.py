@@ -128,11 +128,13 @@ def probe_fails(g, probe):
     ("dist_egnn_c3_wide.npz", ["zero_score", "score_x0.5", "no_corrector"], []),
     ("dist_egnn_repaint.npz", ["zero_score", "score_x0.5", "no_corrector", "no_repaint"], []),
     ("dist_egnn_types.npz", ["zero_score", "uniform_types", "logits_x0.5", "other_type_update"], []),
+    ("dist_egnn_types_greedy.npz", ["zero_score", "other_type_update"], ["uniform_types", "logits_x0.5"]),
     ("dist_analytic.npz", ["zero_score", "score_x0.9", "score_x0.97", "no_corrector", "sigma_min_1e-2"], ["sigma_max_0.2"])])
 def test_the_criterion_has_teeth(fixture, caught, missed):
     """The reference's own wrong samplers against the criterion: a zeroed score, a halved score and a run without correctors
     are rejected; what the criterion cannot see at this sample size is listed too (a 10 % error of the MLP's score, a 20 %
-    smaller sigma_max: inside the seed-to-seed spread of 1024 structures) -- the check guards against gross errors of the fast
+    smaller sigma_max: inside the seed-to-seed spread of 1024 structures; under greedy type sampling the size of the logits:
+    the argmax does not move) -- the check guards against gross errors of the fast
     mode, not against percent-level ones.  And the tables' own resolution is fine: a seed against the table is no further than
     against the exact pool of the other seeds."""
     g = load_golden(fixture)
