@@ -43,7 +43,11 @@ __device__ __forceinline__ float act(float a, float neg_c, float k)
     return a * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(a * neg_c), k, k));
 }
 
-template <int SHAPE, int ORDER>
+// ABL (energy ablations of SHAPE 1, round 4; results meaningless): bit 0 = no LDS fragment reads (eight fragment pairs read once
+// after the prime and cycled, so consecutive MFMAs still see different operand registers), bit 1 = no weight-stream requests
+// inside the loop (the ring keeps the primed chunks).  Time x sensor power of each against the full kernel = what the LDS
+// reads / the L2 -> LDS stream cost in joules.
+template <int SHAPE, int ORDER, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void probe_kernel(const char* image, int image_chunks, const float* x0, int chunks, float* out,
                                                        float neg_c, float k)
 {
@@ -84,6 +88,16 @@ __global__ __launch_bounds__(256, 1) void probe_kernel(const char* image, int im
     for (int i = 0; i < 4; ++i) issue_chunk_piece(2, 2, i);
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    half8 fh[8], fl[8];
+    if constexpr ((ABL & 1) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            fh[i] = *(const __attribute__((address_space(3))) half8*)(ring + i * 2048 + lane * 16);
+            fl[i] = *(const __attribute__((address_space(3))) half8*)(ring + i * 2048 + 1024 + lane * 16);
+        }
+    }
 
     f32x16 pend = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x16 bias;
@@ -102,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void probe_kernel(const char* image, int im
                 __builtin_amdgcn_s_barrier();
             }
             // weight-stream requests: chunk c + 2's second half in steps 0..6, chunk c + 3's first half in steps 8..14
-            if ((s & 1) == 0) {
+            if ((s & 1) == 0 && (ABL & 2) == 0) {
                 const int i = s >> 1;
                 if (i < 4) issue_chunk_piece(c + 2, (c + 2) & 3, 4 + i);
                 else issue_chunk_piece(c + 3, (c + 3) & 3, i - 4);
@@ -128,8 +142,14 @@ __global__ __launch_bounds__(256, 1) void probe_kernel(const char* image, int im
                 // k-step of 32 = s >> 1, row tile = s & 1: fragments of 16 rows x 32 k; column groups 0 / 1 = operand sets
                 // xh[0..7] / xh[8..15]; accumulators: acc[4 (2 rt + cg) .. +3]
                 const int ks = s >> 1, rt = s & 1;
-                const half8 ah = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + lane * 16);
-                const half8 al = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + 1024 + lane * 16);
+                half8 ah, al;
+                if constexpr ((ABL & 1) != 0) {
+                    ah = fh[(s + tp) & 7];
+                    al = fl[(s + tp) & 7];
+                } else {
+                    ah = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + lane * 16);
+                    al = *(const __attribute__((address_space(3))) half8*)(w + s * 2048 + 1024 + lane * 16);
+                }
 #pragma unroll
                 for (int cg = 0; cg < 2; ++cg) {
                     f32x4 a4 = {acc[4 * (2 * rt + cg)], acc[4 * (2 * rt + cg) + 1], acc[4 * (2 * rt + cg) + 2], acc[4 * (2 * rt + cg) + 3]};
@@ -396,16 +416,16 @@ __global__ __launch_bounds__(512, 2) void probe_kernel_ksplit(const char* image,
     atomicAdd(&out[(size_t)blockIdx.x * 256 + (threadIdx.x & 255)], sum);
 }
 
-template <int SHAPE, int ORDER>
+template <int SHAPE, int ORDER, int ABL = 0>
 static int launch_one(const void* image, int image_chunks, const float* x0, int chunks, float* out, int grid, float neg_c, float k,
                       hipStream_t st)
 {
     static bool granted = false;
     if (!granted) {
-        if (hipFuncSetAttribute((const void*)probe_kernel<SHAPE, ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)probe_kernel<SHAPE, ORDER, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
         granted = true;
     }
-    hipLaunchKernelGGL((probe_kernel<SHAPE, ORDER>), dim3(grid), dim3(256), 4 * (size_t)kChunk, st, (const char*)image, image_chunks, x0, chunks, out, neg_c, k);
+    hipLaunchKernelGGL((probe_kernel<SHAPE, ORDER, ABL>), dim3(grid), dim3(256), 4 * (size_t)kChunk, st, (const char*)image, image_chunks, x0, chunks, out, neg_c, k);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -416,6 +436,9 @@ extern "C" int probe_launch(int shape, const void* image, int image_chunks, cons
     switch (shape) {                     // shape = 0 / 1: the two MFMA shapes; 10 + o: 32x32x16 with product order o
         case 0: return launch_one<0, 0>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);
         case 1: return launch_one<1, 0>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);
+        case 101: return launch_one<1, 0, 1>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);      // no LDS fragment reads
+        case 102: return launch_one<1, 0, 2>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);      // no weight-stream requests
+        case 103: return launch_one<1, 0, 3>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);      // neither
         case 11: return launch_one<0, 1>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);
         case 12: return launch_one<0, 2>(image, image_chunks, x0, chunks, out, grid, neg_c, k, st);
         case 2: {
