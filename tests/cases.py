@@ -83,3 +83,47 @@ def diamond_sites(n_cells):
 # N = 216, cell 16.29, T = 2000 linear, M = 2, ConstrainedLangevinGenerator with K = 108 pinned diamond sites, B = 2
 C5_SHAPE = (noise_ns(2000, **LIN), sampling_ns(216, 1, M=2, one=False, greedy=False, cell=[16.29] * 3),
             lambda eb: nets.egnn_c3_net(1, edge_builder=eb))
+
+
+def periodic_well_mlp_state(sites, amplitude=4.0, offset=24.0, factor=1.0, reference_shapes=None):
+    """Weights for the MLP template (N = 8, one atom type, hidden 64 x 3: tests/nets.py::mlp_net(8, 1) and the reference's
+    MLPScoreNetwork of tests/golden/make_golden.py::_mlp(8, 1)) that make it a KNOWN function with a strong, structured score:
+
+        out.X[i] = - factor * amplitude * sin(2 pi (x_i - site_i)),     logits and lattice output zero
+
+    -- a periodic well around every site.  The network's own input features are cos / sin of 2 pi x
+    (src/.../models/score_networks/mlp_score_network.py:286-293), of which the target is a linear function; the two SiLUs between
+    the three layers are passed in their linear regime: the 24 live neurons carry e_i + offset >= 20, where SiLU(z) = z (1 - e^-z)
+    differs from z by < 5e-8.  Every other weight and bias is zero.  Returns {parameter name: float32 array}; `reference_shapes`
+    (name -> shape, e.g. of a state_dict) is checked when given."""
+    import numpy as np
+    s = np.asarray(sites, np.float64).reshape(-1)                      # 24 = (atom, axis) in the network's flattening order
+    n = s.size
+    z = lambda *shape: np.zeros(shape, np.float32)                     # noqa: E731
+    state = {"relative_coordinates_embedding_layer.weight": z(32, 2 * n), "relative_coordinates_embedding_layer.bias": z(32),
+             "noise_embedding_layer.weight": z(16, 1), "noise_embedding_layer.bias": z(16),
+             "time_embedding_layer.weight": z(16, 1), "time_embedding_layer.bias": z(16),
+             "atom_type_embedding_layer.weight": z(1, 2), "atom_type_embedding_layer.bias": z(1),
+             "lattice_parameters_embedding_layer.weight": z(1, 6), "lattice_parameters_embedding_layer.bias": z(1),
+             "condition_embedding_layer.weight": z(64, n), "condition_embedding_layer.bias": z(64),
+             "output_A_layer.weight": z(2 * (n // 3), 64), "output_A_layer.bias": z(2 * (n // 3)),
+             "output_X_layer.weight": z(n, 64), "output_X_layer.bias": z(n),
+             "output_L_layer.weight": z(6, 64), "output_L_layer.bias": z(6)}
+    width_in = 32 + 16 + 16 + (n // 3) + 1
+    for k in range(3):
+        state[f"mlp_layers.{k}.weight"] = z(64, width_in if k == 0 else 64)
+        state[f"mlp_layers.{k}.bias"] = z(64)
+        state[f"conditional_layers.{k}.weight"] = z(64, 64)
+        state[f"conditional_layers.{k}.bias"] = z(64)
+    a = factor * amplitude
+    for i in range(n):                                                 # input = [cos(2 pi x) (n) | sin(2 pi x) (n)]
+        state["relative_coordinates_embedding_layer.weight"][i, i] = a * np.sin(2 * np.pi * s[i])
+        state["relative_coordinates_embedding_layer.weight"][i, n + i] = -a * np.cos(2 * np.pi * s[i])
+        for k in range(3):
+            state[f"mlp_layers.{k}.weight"][i, i] = 1.0
+        state["mlp_layers.0.bias"][i] = offset
+        state["mlp_layers.2.bias"][i] = -offset
+        state["output_X_layer.weight"][i, i] = 1.0
+    if reference_shapes is not None:
+        assert {k: tuple(v.shape) for k, v in state.items()} == {k: tuple(v) for k, v in reference_shapes.items()}
+    return state

@@ -1,6 +1,6 @@
 """Reference-made DISTRIBUTIONS of whole sampling jobs (container-only: imports /root/reference through make_golden's stubs).
 
-    PYTHONPATH=/root/reference/src python tests/golden/make_distributions.py [analytic|mlp|egnn|egnn_c3_wide|egnn_repaint|egnn_types|egnn_types_greedy]
+    PYTHONPATH=/root/reference/src python tests/golden/make_distributions.py [analytic|mlp|mlp_well|egnn|egnn_c3_wide|egnn_repaint|egnn_types|egnn_types_greedy]
 
 Runs the REFERENCE's LangevinGenerator for complete trajectories where that is cheap, several seeds each, and stores summary
 statistics only -- quantile tables of the pooled final structures' scalars (tests/distribution_stats.py), the reference-vs-
@@ -10,6 +10,8 @@ and the KS distance of deliberately WRONG samplers to the pool (the power of the
   dist_mlp_c2.npz   BASELINE configs[1]: the MLP template (weights = tests/golden/net_mlp_c1.npz: `_mlp(8, 1)`), N = 8, T = 1000,
                     sigma 1e-4 .. 0.25 exponential, M = 1, greedy + one-transition defaults, 1024 structures per seed
                     (src/.../generators/langevin_generator.py:27-831 through src/.../sampling/diffusion_sampling.py:16-73)
+  dist_mlp_well.npz the same job with the MLP template turned into a periodic well by its weights (tests/cases.py::
+                    periodic_well_mlp_state): the case with power for the MLP samplers, 1024 structures x 16 seeds
   dist_analytic.npz the reference's AnalyticalScoreNetwork (exact score of Gaussians of width 0.05 around the diamond sites of
                     Si 1x1x1), T = 200, sigma 1e-4 .. 0.25 exponential, M = 1, 1024 structures x 48 seeds: the case with POWER
   dist_egnn_rc.npz  a small radial-cutoff EGNN (hidden 32, 2 graph layers; weights = tests/golden/traj_egnn_rc.npz), N = 64,
@@ -137,6 +139,52 @@ def mlp_c2():
         "sigma_max_0.2": lambda: make(noise_kw=dict(sigma_min=1e-4, sigma_max=0.2)),
     }
     run(make, seeds=list(range(11, 27)), batch=1024, per_atom=True, name="dist_mlp_c2", probes=probes)
+
+
+WELL = dict(amplitude=0.3, offset=24.0)
+
+
+def mlp_well():
+    """BASELINE configs[1]'s job (N = 8, T = 1000, sigma 1e-4 .. 0.25 exponential, M = 1, 1024 structures per seed) with the MLP
+    template made a KNOWN function by its weights (tests/cases.py::periodic_well_mlp_state: out.X = -0.3 sin(2 pi (x - site)),
+    the diamond sites of Si 1x1x1): where the random-init template's chaotic map leaves the criterion blind to a 10 % error of
+    the score (dist_mlp_c2), this one contracts every atom onto its site with a width set by the last ~150 corrector steps --
+    the case with power for samplers that take an MLP (the persistent fused kernel).  16 seeds; the wrong samplers 8 calls each."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from cases import diamond_sites, periodic_well_mlp_state
+    sites = diamond_sites(1)
+    kw = dict(T=1000, N=8, num_atom_types=1, M=1, noise_kw=dict(sigma_min=1e-4, sigma_max=0.25))
+
+    def network(factor=1.0):
+        net = G._mlp(8, 1)
+        state = periodic_well_mlp_state(sites.numpy(), factor=factor, reference_shapes={k: v.shape for k, v in net.state_dict().items()},
+                                        **WELL)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+        return net
+
+    def make(factor=1.0, **over):
+        return G.make_generator(net=network(factor), **dict(kw, **over))[0]
+    probes = {
+        "zero_score": lambda: make(factor=0.0),
+        "score_x0.9": lambda: make(factor=0.9),
+        "score_x0.97": lambda: make(factor=0.97),
+        "no_corrector": lambda: make(M=0),
+        "sigma_min_1e-3": lambda: make(noise_kw=dict(sigma_min=1e-3, sigma_max=0.25)),
+    }
+    g = torch.Generator().manual_seed(5050)
+    B = 6
+    x = torch.rand(B, 8, 3, generator=g)
+    batch = {G.NOISY_AXL_COMPOSITION: G.AXL(A=torch.zeros(B, 8, dtype=torch.long), X=x,
+                                            L=torch.tensor([5.43, 5.43, 5.43, 0, 0, 0.0]).repeat(B, 1)),
+             G.TIME: torch.rand(B, 1, generator=g), G.NOISE: torch.rand(B, 1, generator=g) * 0.25,
+             G.CARTESIAN_FORCES: torch.zeros(B, 8, 3)}
+    with torch.no_grad():
+        out = network()(batch, conditional=False)
+    extra = {"forward/X": G._np(x), "forward/time": G._np(batch[G.TIME]), "forward/sigma": G._np(batch[G.NOISE]),
+             "forward/out_X": G._np(out.X), "forward/out_A": G._np(out.A), "sites": G._np(sites),
+             "well": np.array([WELL["amplitude"], WELL["offset"]], dtype=np.float64)}
+    run(make, seeds=list(range(201, 217)), batch=1024, per_atom=False, name="dist_mlp_well", probes=probes, extra=extra,
+        sites=G._np(sites), probe_calls=8)
 
 
 def egnn_rc():
@@ -304,6 +352,8 @@ if __name__ == "__main__":
         analytic()
     if which in ("all", "mlp"):
         mlp_c2()
+    if which in ("all", "mlp_well"):
+        mlp_well()
     if which in ("all", "egnn"):
         egnn_rc()
     if which in ("all", "egnn_c3_wide"):

@@ -140,3 +140,20 @@ with torch.no_grad(), warnings.catch_warnings():
         for probe in ("zero_score", "uniform_types", "logits_x0.5", "other_type_update"):
             print(f"   reference-side wrong sampler {probe:18s}: " + ", ".join(f"{k} {float(g[f'probe/{probe}/{k}']):.4f}" for k in T.scalars_of(g)) +
                   f", type fraction {float(g[f'probe_type_fraction/{probe}']):.4f}  -> {'rejected' if T.probe_fails(g, probe) else 'not seen'}")
+
+    g = load_golden("dist_mlp_well.npz")
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip
+    noise_kw, sampling_kw, net = T.periodic_well_case(g)
+    for variant, options in (("register-resident exact family (bench.py's C2 path)", 0), ("padded family", _hip.MLP_SAMPLE_PADDED_FAMILY),
+                             ("generic kernel, folded forward", _hip.MLP_SAMPLE_GENERIC_KERNEL),
+                             ("generic kernel, layer by layer", _hip.MLP_SAMPLE_GENERIC_KERNEL | _hip.MLP_SAMPLE_UNFOLDED)):
+        gen = P["Langevin"](P["Noise"](**noise_kw), P["Sampling"](**sampling_kw, rng_mode="device", seed=3131, fused_score_network=True),
+                            net.to(cuda))
+        gen.fused_sampler_options = options
+        summary(f"periodic-well MLP (out.X = -0.3 sin 2 pi (x - site)), configs[1]'s job, persistent fused kernel: {variant}", g,
+                [gen.sample(int(g["batch"]), cuda).X.cpu().numpy() for _ in range(len(g["seeds"]))])
+    for probe in ("zero_score", "score_x0.9", "score_x0.97", "no_corrector", "sigma_min_1e-3"):
+        keys = T.scalars_of(g)
+        print(f"   reference-side wrong sampler {probe:14s}: first call " + ", ".join(f"{k} {float(g[f'probe/{probe}/{k}']):.4f}" for k in keys) +
+              f" | {int(g['probe_calls'])} calls pooled " + ", ".join(f"{k} {float(g[f'probe_pooled/{probe}/{k}']):.4f}" for k in keys) +
+              f"  -> {'rejected' if T.probe_fails(g, probe) else 'not seen'}")
