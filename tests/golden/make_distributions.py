@@ -288,6 +288,7 @@ def egnn_c3_wide():
     probes = {
         "zero_score": lambda: make(factor=0.0),
         "score_x0.5": lambda: make(factor=0.5 * C3_WIDE_SCORE_FACTOR),
+        "score_x0.9": lambda: make(factor=0.9 * C3_WIDE_SCORE_FACTOR),
         "no_corrector": lambda: make(M=0),
     }
     run(make, seeds=[31, 32, 33, 34, 35, 36], batch=16, per_atom=False, name="dist_egnn_c3_wide", probes=probes,

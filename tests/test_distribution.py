@@ -126,7 +126,7 @@ def probe_fails(g, probe):
     ("dist_mlp_c2.npz", ["zero_score", "no_corrector"], ["score_x0.9", "sigma_max_0.2"]),
     ("dist_mlp_well.npz", ["zero_score", "score_x0.9", "score_x0.97", "no_corrector", "sigma_min_1e-3"], []),
     ("dist_egnn_rc.npz", ["zero_score", "score_x0.5", "no_corrector"], []),
-    ("dist_egnn_c3_wide.npz", ["zero_score", "score_x0.5", "no_corrector"], []),
+    ("dist_egnn_c3_wide.npz", ["zero_score", "score_x0.5", "score_x0.9", "no_corrector"], []),
     ("dist_egnn_repaint.npz", ["zero_score", "score_x0.5", "no_corrector", "no_repaint"], []),
     ("dist_egnn_types.npz", ["zero_score", "uniform_types", "logits_x0.5", "other_type_update"], []),
     ("dist_egnn_types_greedy.npz", ["zero_score", "other_type_update"], ["uniform_types", "logits_x0.5"]),

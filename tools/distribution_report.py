@@ -97,7 +97,7 @@ with torch.no_grad(), warnings.catch_warnings():
         summary(f"production EGNN 4 x 256 x 4 (configs[2]'s network), N = 64, T = 100, score x {float(g['score_factor']):.0f}, "
                 f"hipGraph loop, edge chain {precision}", g,
                 [gen.sample(int(g["batch"]), cuda).X.cpu().numpy() for _ in range(len(g["seeds"]))])
-    for probe in ("zero_score", "score_x0.5", "no_corrector"):
+    for probe in ("zero_score", "score_x0.5", "score_x0.9", "no_corrector"):
         print(f"   reference-side wrong sampler {probe:14s}: " + ", ".join(f"{k} {float(g[f'probe/{probe}/{k}']):.4f}" for k in T.POOLED) +
               f"  (judged on {', '.join(T.scalars_of(g))})  -> {'rejected' if T.probe_fails(g, probe) else 'not seen'}")
 
