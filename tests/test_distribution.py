@@ -7,10 +7,20 @@ sin / cos in the persistent MLP kernel, split-f16 MFMA products and a hipGraph l
 samples?  The reference's own measure for that question is the two-sample Kolmogorov-Smirnov distance
 (src/.../metrics/kolmogorov_smirnov_metrics.py:7-75).
 
-tests/golden/dist_mlp_c2.npz / dist_egnn_rc.npz (tests/golden/make_distributions.py, reference runs in the build container)
-hold, per scalar of tests/distribution_stats.py, the quantile table of the reference's pooled final structures, the
-reference-vs-reference KS distances (every seed against the pool of the others; pooled halves against each other) and the KS
-distance of deliberately WRONG samplers (score zeroed or scaled, correctors dropped) to the pool.  A sampler passes when
+tests/golden/dist_*.npz (tests/golden/make_distributions.py, reference runs in the build container) hold, per scalar of
+tests/distribution_stats.py, the quantile table of the reference's pooled final structures, the reference-vs-reference KS distances
+(every seed against the pool of the others; pooled halves against each other) and the KS distance of deliberately WRONG samplers
+(score zeroed or scaled, correctors dropped, ...) to the pool.  The cases:
+
+  dist_mlp_c2            BASELINE configs[1]: the random-init MLP template, T = 1000, 1024 structures x 16 seeds
+  dist_mlp_well          the same job, the template's weights making it a known periodic well: 3 % of the score's weight is seen
+  dist_analytic          the reference's AnalyticalScoreNetwork as a plugin: the per-step kernels' case with 3 % power
+  dist_egnn_rc           small radial-cutoff EGNN (score x 100), hipGraph loop, both MFMA modes
+  dist_egnn_c3_wide      configs[2]'s production EGNN 4 x 256 x 4 (score x 150): the benchmarked kernel instantiation
+  dist_egnn_repaint      the reference's ConstrainedLangevinGenerator: the free atoms around 32 pinned ones
+  dist_egnn_types[_greedy]  two atom types, Gumbel-drawn and configs[3]'s greedy + one-transition settings
+
+A sampler passes when
 
   * every one of its calls (the reference's batch per seed) is within MARGIN x the largest leave-one-out distance of the
     reference's own seeds, for every scalar;
