@@ -478,6 +478,83 @@ __device__ __forceinline__ PcStep make_step(const PcArgs& p)
     return make_step(p, p.mode, (p.d_index ? *p.d_index : 0) + p.index_i, p.rng.draw_offset);
 }
 
+// The persistent sampler requests a step's schedule entries ONE SUB-STEP AHEAD, as VECTOR loads (every lane the same four
+// addresses: one transaction each): a scalar load would share the LDS counter, and the first LDS wait of the forward would
+// expose its latency; the vector counter is only waited on at the top of the next sub-step.  step_from_request() then builds
+// the very StepScalars of step_scalars() from them (same loaded values, same operations).  (Four loads, not one load of a
+// per-lane selected pointer: selecting among the addresses of fields of the argument structure makes the compiler keep the
+// whole structure in scratch memory.)
+struct StepRequest {
+    float time, sigma, third, g;
+};
+
+__device__ __forceinline__ StepRequest step_request(const SchedDev& s, int mode, int index, int vzero)
+{
+    const bool corrector_at_zero = mode != MDX_PREDICTOR && index == 0;
+    const int idx = (corrector_at_zero ? 0 : index - 1) + vzero;          // (vzero: a zero held in a vector register, so that
+    StepRequest q;                                                        //  these are vector memory loads, scalar base + lane offset)
+    q.time = s.time[idx];
+    q.sigma = s.sigma[idx];
+    q.third = mode == MDX_PREDICTOR ? s.g2[idx] : s.eps[index + vzero];
+    q.g = s.g[idx];
+    return q;
+}
+
+__device__ __forceinline__ StepScalars step_from_request(const SchedDev& s, int mode, int index, double atoms_pow, const StepRequest& q)
+{
+    StepScalars o;
+    o.index = index;
+    auto uniform = [](float v) {       // the value of the first active lane, as a scalar (bit pattern through the int builtin)
+        return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+    };
+    const float time = uniform(q.time), sigma = uniform(q.sigma), third = uniform(q.third), g = uniform(q.g);
+    if (mode == MDX_PREDICTOR) {
+        o.idx = index - 1;
+        o.time = time;
+        o.sigma = sigma;
+        o.w = third;
+        o.n = g;
+        o.sigma_n = o.sigma / (float)atoms_pow;
+    } else {
+        if (index == 0) {
+            o.idx = 0;
+            o.time = 0.0f;
+            o.sigma = (float)s.sigma_min;
+            o.sigma_n = (float)(s.sigma_min / atoms_pow);
+        } else {
+            o.idx = index - 1;
+            o.time = time;
+            o.sigma = sigma;
+            o.sigma_n = o.sigma / (float)atoms_pow;
+        }
+        o.w = third;
+        o.n = __builtin_sqrtf(2.0f * o.w);
+    }
+    return o;
+}
+
+// make_step() of the persistent sampler (schedule tables always in use there): the scalars come from the request made a
+// sub-step earlier, the Philox call word is read once per launch
+__device__ __forceinline__ PcStep make_step_from_request(const PcArgs& p, int mode, int index, uint32_t draw_offset,
+                                                         const StepRequest& q, uint32_t call8)
+{
+    PcStep st;
+    const int C = p.C;
+    st.sc = step_from_request(p.sched, mode, index, p.atoms_pow, q);
+    st.q = p.sched.q + (int64_t)st.sc.idx * C * C;
+    st.qbar = p.sched.qbar + (int64_t)st.sc.idx * C * C;
+    st.qbar_tm1 = p.sched.qbar_tm1 + (int64_t)st.sc.idx * C * C;
+    st.one = p.one_transition;
+    st.last_predictor_step = (mode == MDX_PREDICTOR && st.sc.idx == 0);
+    if (st.last_predictor_step) st.one = 0;                 // generators/langevin_generator.py:601-604
+    st.draw = (uint32_t)index * p.rng.draw_stride + draw_offset;
+    st.k0 = (uint32_t)p.rng.seed;
+    st.k1 = (uint32_t)(p.rng.seed >> 32);
+    st.call8 = call8;
+    st.fixed_c2 = FixedSoftmaxC2{0.0f, 0.0f, 0};
+    return st;
+}
+
 // The update of one structure by the G lanes of its group (P2, P1, P3).  Used by pc_step_kernel on global memory and
 // by the fused MLP sampler kernel on its LDS-resident state: one body, one arithmetic.
 template <int G>
@@ -1546,17 +1623,35 @@ __global__ __launch_bounds__(kMlpWaves* kWave) void mlp_pc_sample_kernel(MlpSamp
             pc_types_only.do_coords = 0;
             constexpr int kPre = SPEC >= 1 && SPEC < 200 ? 1 : (spec_padded(SPEC) ? 2 : MDX_MAX_CLASSES + 5);   // 64-lane fetches covering N (d + C + 1) + 8 floats (padded family: N <= 8, C <= 8 -> <= 104)
             const int rec_total = p.rec0 + p.M * p.rec1;
+            // A sub-step's schedule entries do not depend on the state: they are REQUESTED one sub-step ahead, as vector loads (the
+            // vector counter is waited on behind the forward, where the noise record is due anyway), instead of as scalar loads at
+            // the top of the sub-step whose latency the forward's first instruction waited for (0.25 us of a 2.3 us sub-step).
+            // Issued BEFORE the record's load: the counter is in order, and the wait for the record then covers them.
+            const uint32_t call8_launch = rng_call(p.pc.rng) << 8;
+            [[maybe_unused]] float pre[kPre];
+            // (a zero the compiler cannot see through, in a vector register: with it in the index the table loads are not scalar loads)
+            int vzero;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+            StepRequest req_next = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (p.n_iterations > 0) req_next = step_request(p.pc.sched, MDX_PREDICTOR, p.start_index, vzero);   // the first sub-step's
             for (int it = 0; it < p.n_iterations; ++it) {
                 const int i = p.start_index - 1 - it;               // loop variable of the reference (:147)
                 for (int sub = 0; sub <= p.M; ++sub) {
                     const int mode = sub == 0 ? MDX_PREDICTOR : MDX_CORRECTOR;
-                    PcStep st = make_step(p.pc, mode, sub == 0 ? i + 1 : i, (uint32_t)sub);
+                    PcStep st = make_step_from_request(p.pc, mode, sub == 0 ? i + 1 : i, (uint32_t)sub, req_next, call8_launch);
                     st.fixed_c2 = fixed_c2;
                     const int types = sub == 0 ? 1 : p.types_in_corrector;
+                    const int rec_len = types ? p.rec0 : N * d;
+                    {                                                // the NEXT sub-step's schedule entries
+                        const bool wraps = sub == p.M;
+                        const int nit = wraps ? it + 1 : it, nsub = wraps ? 0 : sub + 1;
+                        if (nit < p.n_iterations) {
+                            const int ni = p.start_index - 1 - nit;
+                            req_next = step_request(p.pc.sched, nsub == 0 ? MDX_PREDICTOR : MDX_CORRECTOR, nsub == 0 ? ni + 1 : ni, vzero);
+                        }
+                    }
                     // this step's pre-drawn noise: fetched now, needed after the forward (the load's latency is hidden
                     // behind it), handed to the update through LDS
-                    [[maybe_unused]] float pre[kPre];
-                    const int rec_len = types ? p.rec0 : N * d;
                     if (p.noise) {
                         const float* rec = p.noise + ((int64_t)it * p.pc.B + b) * rec_total +
                                            (sub == 0 ? 0 : p.rec0 + (sub - 1) * p.rec1);

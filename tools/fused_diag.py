@@ -6,7 +6,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
-from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
+from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
+if len(sys.argv) > 1:                      # a diagnostics build under another name (tools/_ablate/libmdx_diag.so)
+    _hip.LIB_PATH = os.path.abspath(sys.argv[1])
 dev = torch.device("cuda:0")
 w = bench.WORKLOADS["C2"]
 gen, *_ = bench.build_generator(w, dev, 0, w["batch"], False)
