@@ -58,6 +58,20 @@ __global__ __launch_bounds__(kBlock) void egnn_message_input_kernel(const float*
 //   h[i, :]  = b + sigma_{s(i)} W[:, 0] + W[:, 1 + a_i]                         embedding_in applied to [sigma | one_hot(a_i)]
 // (the reference builds [sigma | one_hot] and multiplies by W^T; with a one-hot input that is a column pick -- the same
 // binary32 operations in the same order: fl(fl(b + fl(sigma w0)) + w_a), every other term an exact zero).
+// (cos kr, sin kr) of the binary32 angle, CORRECTLY ROUNDED: evaluated in binary64 and rounded once.  Why it matters for parity:
+// the score is z . Gamma . (z + sum of the layers' translations), a small difference of numbers of magnitude 1, so the rounding
+// of every layer's x + trans (half an ulp of 1 = 3e-8 against scores of 2e-3) IS the binary32 noise floor of this network -- and
+// two evaluations share that rounding only where their z agree in every bit.  The reference's z are torch's CPU cos / sin
+// (<= 1 ulp, 95.5 % of them correctly rounded); ocml's binary32 cosf / sinf differ from those in ~30 % of the entries, which
+// alone put every GPU evaluation 1.1e-5 (rel-L2) from the reference's scores instead of 6e-6 (measured: tests/golden/
+// net_egnn_c3_wide.npz; 98 k (cos, sin) pairs per forward at C3 -- the cost of binary64 here is nothing).
+__device__ __forceinline__ void uplift(float kr, float& c, float& s)
+{
+    const double a = (double)kr;
+    c = (float)cos(a);
+    s = (float)sin(a);
+}
+
 __global__ __launch_bounds__(kBlock) void egnn_node_inputs_kernel(const float* __restrict__ x, const float* __restrict__ k_vectors,
                                                                   int n_k, const float* __restrict__ sigma, int atoms_per_structure,
                                                                   const int64_t* __restrict__ atom_types,
@@ -94,8 +108,7 @@ __global__ __launch_bounds__(kBlock) void egnn_node_inputs_kernel(const float* _
         const int k = (int)(t - i * n_k);
         float kr = 0.0f;
         for (int d = 0; d < 3; ++d) kr = kr + (6.2831855f * x[3 * i + d]) * k_vectors[3 * k + d];
-        z[2 * t] = cosf(kr);
-        z[2 * t + 1] = sinf(kr);
+        uplift(kr, z[2 * t], z[2 * t + 1]);
     }
 }
 
@@ -156,8 +169,7 @@ __global__ __launch_bounds__(kBlock) void egnn_node_inputs_rows_kernel(const flo
         for (int k = lane; k < n_k; k += 64) {
             float kr = 0.0f;
             for (int d = 0; d < 3; ++d) kr = kr + (6.2831855f * x[3 * i + d]) * k_vectors[3 * k + d];
-            z[2 * (i * n_k + k)] = cosf(kr);
-            z[2 * (i * n_k + k) + 1] = sinf(kr);
+            uplift(kr, z[2 * (i * n_k + k)], z[2 * (i * n_k + k) + 1]);
         }
     }
 }

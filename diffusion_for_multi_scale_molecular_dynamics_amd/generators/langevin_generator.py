@@ -9,8 +9,11 @@ Same class name, constructor, step methods and behaviour as the reference's Lang
     (mdx_pc_step_update), with per-structure reductions done by wavefront shuffles;
   * no per-step host synchronisation: the reference's asserts are collected in a device status word that is read
     once at the end of sample().  (A score network that runs split-f16 MFMA kernels also has its f16-range report
-    watched per iteration -- through asynchronous copies to page-locked memory read two iterations behind the queue,
-    so the device never waits for the host: IterationLoop._advance_watched);
+    watched per ITERATION: in the device-resident loop through asynchronous copies to page-locked memory read two
+    iterations behind the queue, so the device never waits for the host -- IterationLoop._advance_watched; in the eager
+    loop -- reference-order RNG, recording runs, callers without a hipGraph -- by ONE blocking 4-byte read per iteration
+    (_take_range_report): that loop already uploads the iteration's draws from the host, it is the parity path, not the
+    fast one);
   * rng_mode="device" removes the per-step CPU draws + PCIe uploads, and use_hip_graph=True replays one captured
     predictor+correctors iteration T times with the step index living on the device.
 
@@ -457,6 +460,21 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         if adapt is not None:
             adapt()
 
+    def _begin_f16_fallback(self):
+        """Before the exact-f32 pass of a fallback: the network forgets the activation maxima earlier f32 launches left (plain
+        f32 use, other inputs), so the exponents adapt() derives afterwards describe THIS iteration."""
+        begin = getattr(self.axl_network, "begin_f16_range_fallback", None)
+        if begin is not None:
+            begin()
+
+    def _clear_stale_range_report(self):
+        """A range bit left in the network's word by something that was not an iteration of this loop (the warm-up iterations
+        before a capture, a caller stepping by hand) must not be read as the first iteration's report."""
+        from .._hip import STATUS_EGNN_F16_RANGE
+        status = getattr(self.axl_network, "graph_status", None)
+        if status is not None and self._range_guarded():
+            status.bitwise_and_(~STATUS_EGNN_F16_RANGE)
+
     def _count_fallback(self, index_i: int):
         import warnings
         self.f16_range_fallbacks += 1
@@ -499,7 +517,11 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
             if keeps:
                 self.noise_source = self.noise_source.replay()
                 self._share_noise_source()
+            # what the dropped attempt raised in the generator's own word goes with it (non-finite logits at time index 0 leave
+            # MASKs behind: MDX_STATUS_MASK_AT_LAST_STEP) -- the exact-f32 pass raises it again if it is real
+            self._status.bitwise_and_(~STATUS_MASK_AT_LAST_STEP)
             precision = net.edge_chain_precision
+            self._begin_f16_fallback()
             net.edge_chain_precision = "f32"
             try:
                 return self._iteration(composition, i, forces)
@@ -532,6 +554,7 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
             return self._sample_with_graph(starting_noisy_composition, starting_step_index, ending_step_index)
         composition = starting_noisy_composition
         forces = torch.zeros_like(composition.X)
+        self._clear_stale_range_report()
         for i in range(starting_step_index - 1, max(ending_step_index, 0) - 1, -1):
             composition = self._guarded_iteration(composition, i, forces)
         return composition
@@ -679,6 +702,7 @@ class IterationLoop:
             comp.X.copy_(saved.X)
             comp.L.copy_(saved.L)
             gen._status.zero_()
+            gen._clear_stale_range_report()      # (the warm-up ran the split-f16 network from an arbitrary state)
             self.graph = torch.cuda.CUDAGraph()
             # Objects whose finaliser calls HIP must not be collected while the stream is capturing: an older loop's
             # torch.cuda.CUDAGraph (hipGraphExecDestroy) and kernels.BlasContext (hipblasLtDestroy).  The first kind is
@@ -756,6 +780,7 @@ class IterationLoop:
         from .._hip import STATUS_EGNN_F16_RANGE
         gen, w = self.generator, self._watch_buffers()
         net, slots = gen.axl_network, self.LAG + 1
+        gen._clear_stale_range_report()                 # (nothing of this call is queued yet: a set bit is someone else's)
         first = self.remaining                          # iteration k of this call starts with `first - k` indices remaining
         k = checked = 0                                 # iterations queued / iterations whose report has been read
         while checked < iterations:
@@ -788,6 +813,7 @@ class IterationLoop:
             gen._status.zero_()                         # (bits the dropped iterations may have raised)
             gen._count_fallback(self.remaining - 1)
             precision = net.edge_chain_precision
+            gen._begin_f16_fallback()
             net.edge_chain_precision = "f32"
             try:
                 self._one(visits=1 + gen.resampling_steps)      # eager launches of the same iteration, exact-f32 kernels

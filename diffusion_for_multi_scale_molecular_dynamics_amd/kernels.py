@@ -717,6 +717,14 @@ class ActivationScales:
                                                                   C.c_void_p(self.exponents.data_ptr()), stream_handle()),
                   "mdx_egnn_chain_adapt_activation_exponents")
 
+    def reset(self):
+        """The state of a new object: default exponents, no maxima.  (The exponents only ever go DOWN otherwise -- after a
+        fallback the split-f16 kernels carry the hot positions with more headroom and fewer low bits, so a later sample() with
+        the same (seed, call index) can differ in the last bits from one made before the fallback: results are a function of
+        (seed, call index, exponents), and reset() restores the exponents' initial value.)"""
+        self.exponents.fill_(F16_ACTIVATION_EXPONENT)
+        self.maxima.zero_()
+
     def pointers(self, precision: str):
         """(activation_exponents, activation_maxima) of a pack of `precision`: the split kernels read the exponents, the
         exact-f32 kernels write the maxima."""

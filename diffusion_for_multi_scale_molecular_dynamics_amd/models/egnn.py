@@ -118,6 +118,7 @@ class E_GCL(nn.Module):
         state["_node_mlp"] = (None, None)
         state.pop("_chain_kept", None)
         state.pop("_node_mlp_kept", None)
+        state.pop("_node_chain_kept", None)
         state.pop("_activation_scales", None)
         return state
 
@@ -137,6 +138,16 @@ class E_GCL(nn.Module):
         activation exponents for the split-f16 kernels (device-side, no host read)."""
         for scales in self.__dict__.get("_activation_scales", {}).values():
             scales.adapt()
+
+    def begin_f16_range_fallback(self):
+        """Before the exact-f32 pass of a fallback: forget the maxima earlier f32 launches have left."""
+        for scales in self.__dict__.get("_activation_scales", {}).values():
+            scales.maxima.zero_()
+
+    def reset_f16_range(self):
+        """Back to the default activation exponents (and no collected maxima): what a freshly built layer has."""
+        for scales in self.__dict__.get("_activation_scales", {}).values():
+            scales.reset()
 
     def _messages(self, h: torch.Tensor, edge_index: torch.Tensor, radial: torch.Tensor, fused: bool) -> torch.Tensor:
         first = self.message_mlp[0]
@@ -217,8 +228,13 @@ class E_GCL(nn.Module):
             return None
         stamp = (self.edge_chain_precision,) + tuple((t.data_ptr(), t._version) for lin in rest for t in (lin.weight, lin.bias))
         if self._node_chain[0] != stamp:
-            self._node_chain = (stamp, kernels.RowChainPack(rest, self.edge_chain_precision,
-                                                            scales=self._scales("rows", len(rest), rest[0].weight.device)))
+            # one image per precision is KEPT, like the other two packs: a captured iteration has the split-f16 image's
+            # pointers in its kernel arguments, and the generator's one-iteration switch to "f32" and back must not free it
+            kept = self.__dict__.setdefault("_node_chain_kept", {})
+            if kept.get(self.edge_chain_precision, (None, None))[0] != stamp:
+                kept[self.edge_chain_precision] = (stamp, kernels.RowChainPack(
+                    rest, self.edge_chain_precision, scales=self._scales("rows", len(rest), rest[0].weight.device)))
+            self._node_chain = kept[self.edge_chain_precision]
         return self._node_chain[1]
 
     def _node_mlp_pack(self, next_layer=None):

@@ -132,6 +132,19 @@ class EGNNScoreNetwork(ScoreNetwork):
         for layer in self.egnn.graph_layers:
             layer.adapt_f16_range()
 
+    def begin_f16_range_fallback(self):
+        """Called by a generator right before it recomputes an iteration with the exact-f32 kernels: the maxima those kernels
+        collect start from zero, so adapt_f16_range() afterwards sees this iteration and not every f32 launch since start-up."""
+        for layer in self.egnn.graph_layers:
+            layer.begin_f16_range_fallback()
+
+    def reset_f16_range(self):
+        """Default activation exponents again.  The exponents are the one piece of state a fallback leaves behind: they only go
+        down, so after a fallback the split-f16 results of the same (seed, call index) can differ in the last bits from before
+        it; reset_f16_range() restores bit-reproducibility with a fresh process."""
+        for layer in self.egnn.graph_layers:
+            layer.reset_f16_range()
+
     def check_status(self):
         """Raise for any MDX_STATUS_* bit the forward passes have collected (one host read); clears the word."""
         if self.graph_status is not None:
@@ -280,7 +293,11 @@ class EGNNScoreNetwork(ScoreNetwork):
             kr = ((2.0 * math.pi * flat)[:, None, :] * k_vectors[None, :, :]).sum(dim=-1)          # [nodes, n_k]
         else:
             kr = (2.0 * math.pi * flat) @ k_vectors.t()
-        z = torch.stack([kr.cos(), kr.sin()], dim=2).reshape(bsz * n, -1)                        # (k, two) interleaved
+        if flat.is_cuda:      # correctly rounded, like mdx_egnn.hip::uplift (why: see there); the CPU path is the reference's own op
+            kr64 = kr.double()
+            z = torch.stack([kr64.cos().to(kr.dtype), kr64.sin().to(kr.dtype)], dim=2).reshape(bsz * n, -1)
+        else:
+            z = torch.stack([kr.cos(), kr.sin()], dim=2).reshape(bsz * n, -1)                    # (k, two) interleaved
 
         sigmas = batch[NOISE].to(x.device).repeat_interleave(n, dim=0)
         one_hot = torch.nn.functional.one_hot(comp.A.reshape(-1).long(), self.num_atom_types + 1).to(x.dtype)

@@ -52,6 +52,16 @@ class ForceFieldAugmentedScoreNetwork(torch.nn.Module):
         if adapt is not None:
             adapt()
 
+    def begin_f16_range_fallback(self):
+        begin = getattr(self._score_network, "begin_f16_range_fallback", None)
+        if begin is not None:
+            begin()
+
+    def reset_f16_range(self):
+        reset = getattr(self._score_network, "reset_f16_range", None)
+        if reset is not None:
+            reset()
+
     def forward(self, batch: Dict[AnyStr, torch.Tensor], conditional: Optional[bool] = None) -> AXL:
         raw = self._score_network(batch, conditional)
         return AXL(A=raw.A, X=raw.X + self.get_relative_coordinates_pseudo_force(batch), L=raw.L)

@@ -69,6 +69,22 @@ C4_SHAPE = (noise_ns(1000, **LIN), sampling_ns(64, 2, M=2, one=True, greedy=True
             lambda eb: nets.egnn_c3_net(2, edge_builder=eb))
 
 
+# The same two settings with the "live" network (formula weights at 2 x the default range, where a 256 x 256 hidden matrix
+# matters to the output: tests/golden/make_golden.py::golden_live): traj_egnn_c3_live.npz (500 -> 498),
+# traj_egnn_c4_live_bottom.npz (2 -> 0: the last predictor step with C = 3)
+C3_LIVE_SHAPE = (C3_SHAPE[0], C3_SHAPE[1], lambda eb: nets.egnn_c3_net(1, edge_builder=eb, scale=nets.LIVE_SCALE))
+C4_LIVE_SHAPE = (C4_SHAPE[0], C4_SHAPE[1], lambda eb: nets.egnn_c3_net(2, edge_builder=eb, scale=nets.LIVE_SCALE))
+
+
+def shape_of(name):
+    """(noise, sampling, network factory) of a production-width trajectory fixture, by its name."""
+    if "_c4_live" in name:
+        return C4_LIVE_SHAPE
+    if "_c3_live" in name:
+        return C3_LIVE_SHAPE
+    return C4_SHAPE if "_c4_" in name else C3_SHAPE
+
+
 def diamond_sites(n_cells):
     """The 8 n^3 sites of the diamond structure in an n x n x n supercell, relative coordinates, cell-major order (the
     constraint of BASELINE configs[4]: the first 108 of the 216 sites of Si 3x3x3 are pinned)."""

@@ -773,7 +773,7 @@ def golden_c1_exact():
     save("traj_c1_exact.npz", **out)
 
 
-def _egnn_c3(num_atom_types=1):
+def _egnn_c3(num_atom_types=1, scale=1.0):
     """The reference's production EGNN (experiments/.../Si_2x2x2/config_diffusion_egnn.yaml:44-60): 4 graph layers, 256 wide,
     4 hidden layers per MLP, radial cutoff 7.5 -- with every trainable parameter filled from tests/formula_weights.py
     (the fixture then needs no 19 MB state_dict: the tests evaluate the same formula)."""
@@ -785,7 +785,29 @@ def _egnn_c3(num_atom_types=1):
                                    node_hidden_dimensions_size=256, node_n_hidden_dimensions=4,
                                    coords_agg="mean", message_agg="mean", attention=False, normalize=False, residual=True,
                                    tanh=False, edges="radial_cutoff", radial_cutoff=7.5)
-    return fill_with_formula(EGNNScoreNetwork(p).eval())
+    return fill_with_formula(EGNNScoreNetwork(p).eval(), scale=scale)
+
+
+def _reordered_copy(net, seed=77):
+    """The SAME function with another binary32 summation order: the hidden units of every MLP of every graph layer permuted
+    (rows of a Linear and its bias, columns of the Linear that follows).  Mathematically the identity; in binary32 every inner
+    product adds its terms in another order -- the distance between `net` and this copy is what "the reference's output" is
+    defined up to by the reference's own arithmetic (what another BLAS, thread count or device changes)."""
+    import copy as _copy
+    other = _copy.deepcopy(net)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for layer in other.egnn.graph_layers:
+            for mlp in (layer.message_mlp, layer.coord_mlp, layer.node_mlp):
+                linears = [m for m in mlp if isinstance(m, torch.nn.Linear)]
+                # outputs of every Linear that feeds another Linear of the same Sequential
+                for a, b in zip(linears[:-1], linears[1:]):
+                    perm = torch.randperm(a.out_features, generator=g)
+                    a.weight.copy_(a.weight[perm].clone())
+                    if a.bias is not None:
+                        a.bias.copy_(a.bias[perm].clone())
+                    b.weight.copy_(b.weight[:, perm].clone())
+    return other
 
 
 def golden_c3_shape(only=None):
@@ -823,6 +845,9 @@ def golden_c3_shape(only=None):
     for name, start, end, masked_fraction, run_kw, run_net, run_cell, nat in (
             ("traj_egnn_c3_top", 1000, 998, 1.0, kw, net, 10.86, 1), ("traj_egnn_c3_bottom", 2, 0, 0.1, kw, net, 10.86, 1),
             ("traj_egnn_c4_top", 1000, 998, 1.0, kw4, net4, 11.084, 2), ("traj_egnn_c4_mid", 500, 498, 0.5, kw4, net4, 11.084, 2)):
+        # (configs[3]'s LAST indices, 2 -> 0, are in golden_live(): with these scale-1 weights the logits of one structure's atoms
+        # agree to 1e-7, and with greedy sampling on a partly unmasked structure the Gumbel term is zeroed -- which atom the
+        # one-transition rule picks is then decided by the last bit of the logits, i.e. by rounding noise)
         if name not in only:
             continue
         cell = run_cell
@@ -838,6 +863,152 @@ def golden_c3_shape(only=None):
                    start_A=_np(A0), start_X=_np(X0), start_L=_np(L0), start_index=np.array(start), end_index=np.array(end))
         out.update(rec.pack())
         out.update(_pack_records(gen))
+        save(name + ".npz", **out)
+
+
+def _fp64_forward(net64, composition, time, sigma):
+    """The REFERENCE's module in binary64 on one batch (the graph from the binary32 search, as in the fp32 run: the reference's
+    neighbour search builds float32 lattice vectors)."""
+    from diffusion_for_multi_scale_molecular_dynamics.models.score_networks import egnn_score_network as _mod
+    B = composition.X.shape[0]
+    batch64 = {NOISY_AXL_COMPOSITION: AXL(A=composition.A, X=composition.X.double(), L=composition.L.double()),
+               TIME: torch.full((B, 1), time, dtype=torch.float64), NOISE: torch.full((B, 1), sigma, dtype=torch.float64),
+               CARTESIAN_FORCES: torch.zeros_like(composition.X).double()}
+    search = _mod.get_edges_with_radial_cutoff
+    _mod.get_edges_with_radial_cutoff = lambda x, cell, *a, **k: search(x.float(), cell.float(), *a, **k)
+    try:
+        with torch.no_grad():
+            return net64(batch64, conditional=False)
+    finally:
+        _mod.get_edges_with_radial_cutoff = search
+
+
+def _forward_fixture(name, net, net64, A, X, L, time, noise):
+    batch = {NOISY_AXL_COMPOSITION: AXL(A=A, X=X, L=L), TIME: time, NOISE: noise, CARTESIAN_FORCES: torch.zeros_like(X)}
+    from diffusion_for_multi_scale_molecular_dynamics.models.score_networks import egnn_score_network as _mod
+    with torch.no_grad():
+        o = net(batch, conditional=False)
+        batch64 = {NOISY_AXL_COMPOSITION: AXL(A=A, X=X.double(), L=L.double()), TIME: time.double(), NOISE: noise.double(),
+                   CARTESIAN_FORCES: torch.zeros_like(X).double()}
+        search = _mod.get_edges_with_radial_cutoff
+        _mod.get_edges_with_radial_cutoff = lambda x, cell, *a, **k: search(x.float(), cell.float(), *a, **k)
+        try:
+            o64 = net64(batch64, conditional=False)
+        finally:
+            _mod.get_edges_with_radial_cutoff = search
+    with torch.no_grad():
+        o_perm = _reordered_copy(net)(batch, conditional=False)
+    save(name, A=_np(A), X=_np(X), L=_np(L), time=_np(time), noise=_np(noise), out_A=_np(o.A), out_X=_np(o.X), out_L=_np(o.L),
+         out_X_fp64=_np(o64.X), out_A_fp64=_np(o64.A), out_X_reordered=_np(o_perm.X), out_A_reordered=_np(o_perm.A))
+
+
+def golden_c3_wide():
+    """More forwards of the production network (models/score_networks/egnn_score_network.py:226-303), the inputs a sampler really
+    meets included -- net_egnn_c3.npz holds eight uniform-random structures at sigma in [0.036, 0.176]:
+      net_egnn_c3_wide.npz  32 structures of N = 64 (cell 10.86, one atom type): 8 uniform-random at sigma = 1e-4, 1e-3, 1e-2 and
+                            0.2; 16 = the diamond sites of Si 2x2x2 displaced by sigma z at sigma = 1e-4 (x4), 1e-3 (x4),
+                            1e-2 (x4), 5e-2 (x4) (what the end of a trajectory looks like), unmasked; 8 random with half the
+                            atoms MASKed, sigma uniform in [1e-4, 0.2]
+      net_egnn_c4.npz       the two-atom-type network of BASELINE configs[3] (cell 11.084): 8 structures, A in {0, 1, MASK},
+                            four uniform-random and four displaced diamond sites
+    Both with the module's binary64 output on the same inputs (out_X_fp64)."""
+    _c3_wide_fixtures("net_egnn_c3_wide.npz", "net_egnn_c4.npz", 1.0, 1913)
+
+
+def _c3_wide_fixtures(name_c3, name_c4, scale, seed):
+    g = torch.Generator().manual_seed(seed)
+    N = 64
+    sites = _diamond_sites(2)
+    net, net64 = _egnn_c3(1, scale), _egnn_c3(1, scale).double()
+    X, A, sig = [], [], []
+    for s in (1e-4, 1e-3, 1e-2, 0.2):
+        for _ in range(2):
+            X.append(torch.rand(N, 3, generator=g))
+            A.append(torch.randint(0, 2, (N,), generator=g))
+            sig.append(s)
+    for s in (1e-4, 1e-3, 1e-2, 5e-2):
+        for _ in range(4):
+            X.append(torch.remainder(sites + s * torch.randn(N, 3, generator=g), 1.0))
+            A.append(torch.zeros(N, dtype=torch.long))
+            sig.append(s)
+    for _ in range(8):
+        X.append(torch.rand(N, 3, generator=g))
+        A.append((torch.rand(N, generator=g) < 0.5).long())
+        sig.append(float(1e-4 + (0.2 - 1e-4) * torch.rand(1, generator=g)))
+    X, A = torch.stack(X), torch.stack(A)
+    noise = torch.tensor(sig, dtype=torch.float32).reshape(-1, 1)
+    B = X.shape[0]
+    L = torch.tensor([10.86, 10.86, 10.86, 0, 0, 0.0]).repeat(B, 1)
+    _forward_fixture(name_c3, net, net64, A, X, L, torch.rand(B, 1, generator=g), noise)
+
+    net4, net4_64 = _egnn_c3(2, scale), _egnn_c3(2, scale).double()
+    X = torch.stack([torch.rand(N, 3, generator=g) for _ in range(4)] +
+                    [torch.remainder(sites + s * torch.randn(N, 3, generator=g), 1.0) for s in (1e-4, 1e-3, 1e-2, 5e-2)])
+    A = torch.cat([torch.randint(0, 3, (4, N), generator=g), torch.randint(0, 2, (4, N), generator=g)])
+    noise = torch.tensor([0.2, 0.1, 1e-2, 1e-3, 1e-4, 1e-3, 1e-2, 5e-2]).reshape(-1, 1)
+    L = torch.tensor([11.084, 11.084, 11.084, 0, 0, 0.0]).repeat(8, 1)
+    _forward_fixture(name_c4, net4, net4_64, A, X, L, torch.rand(8, 1, generator=g), noise)
+
+
+LIVE_SCALE = 2.0
+
+
+def golden_live():
+    """The production network shape with formula weights at LIVE_SCALE x nn.Linear's default range.
+
+    Why: at the default range a 4 x 256 x 4 stack of SiLU layers attenuates its signal -- measured on net_egnn_c3's inputs, a
+    0.1 % change of a whole 256 x 256 matrix of the message MLP moves the scores by 3e-6 (rel-L2), below the 1e-5 bar, and the
+    logits of the atoms of one structure agree to 1e-7: the scale-1 fixtures hold the graph, the coordinate path and the
+    biases to the reference, but barely see the hidden layers (and the one-transition argmax over nearly equal logits is
+    decided by rounding noise).  At 2 x the range the same perturbation moves the scores by 1.4e-4 and the logits differ between
+    atoms by 1e-3: what a trained network looks like to the arithmetic.  (2.5 x is past the edge: |score| ~ 2.5, chaotic.)
+      net_egnn_c3_live.npz, net_egnn_c4_live.npz   the inputs of golden_c3_wide (own seed) through the live networks
+      traj_egnn_c3_live.npz       C3 settings, 500 -> 498, half the atoms MASKed
+      traj_egnn_c4_live_bottom.npz  C4 settings (greedy + one transition per step), 2 -> 0: the one-transition rule is off in
+                                  the LAST predictor step, which asserts that no MASK remains
+                                  (generators/langevin_generator.py:601-604,616-620)
+    Trajectories: every draw, every step's input / output composition and network output, and the module's binary64 output
+    on every step's input."""
+    _c3_wide_fixtures("net_egnn_c3_live.npz", "net_egnn_c4_live.npz", LIVE_SCALE, 2913)
+    g = torch.Generator().manual_seed(2914)
+    B, N = 4, 64
+    base = dict(T=1000, N=64, M=2, noise_kw=dict(sigma_min=1e-4, sigma_max=0.2, schedule_type="linear",
+                                                  corrector_step_epsilon=2.5e-8))
+    for name, nat, start, end, masked_fraction, cell, extra in (
+            ("traj_egnn_c3_live", 1, 500, 498, 0.5, 10.86, dict(one=False, greedy=False)),
+            ("traj_egnn_c4_live_bottom", 2, 2, 0, 0.1, 11.084, dict(one=True, greedy=True))):
+        net, net64 = _egnn_c3(nat, LIVE_SCALE), _egnn_c3(nat, LIVE_SCALE).double()
+        gen, npar, spar = make_generator(record=True, net=net, num_atom_types=nat, cell=[cell] * 3, **base, **extra)
+        X0 = torch.rand(B, N, 3, generator=g)
+        masked = torch.rand(B, N, generator=g) < masked_fraction
+        A0 = torch.where(masked, torch.full((B, N), nat), torch.randint(0, nat, (B, N), generator=g))
+        L0 = torch.tensor([cell, cell, cell, 0, 0, 0.0]).repeat(B, 1)
+        forwards = []
+        predictions0 = gen._get_model_predictions
+
+        def get_model_predictions(composition, time, sigma_noise, cartesian_forces):
+            out = predictions0(composition, time, sigma_noise, cartesian_forces)
+            forwards.append((AXL(A=composition.A.clone(), X=composition.X.clone(), L=composition.L.clone()),
+                             float(time), float(sigma_noise)))
+            return out
+
+        gen._get_model_predictions = get_model_predictions
+        torch.manual_seed(2900 + start)
+        with torch.no_grad(), DrawRecorder() as rec:
+            axl = gen.sample_from_noisy_composition(AXL(A=A0, X=X0, L=L0), start, end)
+        out = dict(final_A=_np(axl.A), final_X=_np(axl.X), final_L=_np(axl.L), batch=np.array(B),
+                   start_A=_np(A0), start_X=_np(X0), start_L=_np(L0), start_index=np.array(start), end_index=np.array(end),
+                   formula_scale=np.array(LIVE_SCALE))
+        out.update(rec.pack())
+        out.update(_pack_records(gen))
+        M = base["M"]
+        order = [("pred" if k % (M + 1) == 0 else "corr") for k in range(len(forwards))]
+        for kind in ("pred", "corr"):
+            mine = [f for f, o in zip(forwards, order) if o == kind]
+            assert len(mine) == len(out[f"{kind}_index"])
+            for k, f in enumerate(mine):
+                assert np.array_equal(_np(f[0].X), out[f"{kind}_composition_i_X"][k])
+            out[f"{kind}_model_predictions_i_X_fp64"] = np.stack([_np(_fp64_forward(net64, *f).X) for f in mine])
         save(name + ".npz", **out)
 
 
@@ -923,6 +1094,17 @@ def golden_c5_shape():
             return out
 
         gen.predictor_step, gen.corrector_step = predictor_step, corrector_step
+        # what the network returned in every step (generators/langevin_generator.py:113-153: one call per predictor / corrector
+        # step, in order), and the same module in binary64 on the same inputs (the floor any binary32 evaluation shares)
+        forwards = []
+        predictions0 = gen._get_model_predictions
+
+        def get_model_predictions(composition, time, sigma_noise, cartesian_forces):
+            out = predictions0(composition, time, sigma_noise, cartesian_forces)
+            forwards.append((copy(composition), float(time), float(sigma_noise), copy(out)))
+            return out
+
+        gen._get_model_predictions = get_model_predictions
         torch.manual_seed(1500 + start)
         with torch.no_grad(), DrawRecorder() as rec:
             axl = gen.sample_from_noisy_composition(AXL(A=A0.clone(), X=X0.clone(), L=L0.clone()), start, end)
@@ -937,6 +1119,20 @@ def golden_c5_shape():
             for field in ("A", "X", "L"):
                 out[f"{key_in}_{field}"] = np.stack([_np(getattr(s[1], field)) for s in steps[kind]])
                 out[f"{key_out}_{field}"] = np.stack([_np(getattr(s[2], field)) for s in steps[kind]])
+        # the forwards in call order: predictor(i+1), corrector(i) x M per time index -> split like the step records
+        M = kw["M"]
+        order = [("pred" if k % (M + 1) == 0 else "corr") for k in range(len(forwards))]
+        for kind in ("pred", "corr"):
+            mine = [f for f, o in zip(forwards, order) if o == kind]
+            assert len(mine) == len(steps[kind])
+            for (index_i, before, _), (comp, _, _, _) in zip(steps[kind], mine):
+                assert torch.equal(comp.X, before.X) and torch.equal(comp.A, before.A)
+            for field in ("A", "X", "L"):
+                out[f"{kind}_model_predictions_i_{field}"] = np.stack([_np(getattr(f[3], field)) for f in mine])
+            out[f"{kind}_time"] = np.array([f[1] for f in mine], dtype=np.float64)
+            out[f"{kind}_sigma"] = np.array([f[2] for f in mine], dtype=np.float64)
+            out[f"{kind}_model_predictions_i_X_fp64"] = np.stack(
+                [_np(_fp64_forward(net64, f[0], f[1], f[2]).X) for f in mine])
         save(name + ".npz", **out)
 
 
@@ -1000,6 +1196,10 @@ if __name__ == "__main__":
         golden_c3_shape()
     if which in ("all", "c4"):
         golden_c3_shape(only=("traj_egnn_c4_top", "traj_egnn_c4_mid"))
+    if which in ("all", "c3wide"):
+        golden_c3_wide()
+    if which in ("all", "live"):
+        golden_live()
     if which in ("all", "c5"):
         golden_c5_shape()
     if which in ("all", "variants"):

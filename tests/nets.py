@@ -46,13 +46,16 @@ def egnn_net(num_atom_types, edges, rc, hidden=32, n_layers=2, n_hidden=2, edge_
         edges=edges, radial_cutoff=rc), edge_builder=edge_builder).eval()
 
 
-def egnn_c3_net(num_atom_types=1, edge_builder=None):
+LIVE_SCALE = 2.0     # tests/golden/make_golden.py::LIVE_SCALE (the "live" fixtures: formula weights at 2 x nn.Linear's range)
+
+
+def egnn_c3_net(num_atom_types=1, edge_builder=None, scale=1.0):
     """The reference's production EGNN (4 graph layers x 256 wide x 4 hidden layers, radial cutoff 7.5:
     experiments/.../Si_2x2x2/config_diffusion_egnn.yaml:44-60) -- the shape bench.py's C3-C5 run -- with the formula
     weights the net_egnn_c3 / traj_egnn_c3_* fixtures were generated with (tests/formula_weights.py)."""
     from formula_weights import fill_with_formula
     return fill_with_formula(egnn_net(num_atom_types, "radial_cutoff", 7.5, hidden=256, n_layers=4, n_hidden=4,
-                                      edge_builder=edge_builder))
+                                      edge_builder=edge_builder), scale=scale)
 
 
 def load_fixture_weights(net, fixture):

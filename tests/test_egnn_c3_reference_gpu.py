@@ -21,6 +21,7 @@ import nets
 from conftest import load_golden, torus_rel_l2
 from oracle import reference_sampler as RS
 from test_generator_gpu import _pkg, _replayed
+import teacher_forced
 
 pytestmark = pytest.mark.gpu
 
@@ -50,6 +51,32 @@ def test_c3_network_forward_against_reference(cuda, precision):
     np.testing.assert_allclose(out.A.cpu().numpy()[..., :-1], g["out_A"][..., :-1], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(out.L.cpu().numpy(), g["out_L"], rtol=1e-5, atol=1e-7)
     if precision is not None:        # the fused chain really ran: every graph layer holds a packed image for this mode
+        assert all(layer._chain[1] is not None and layer._chain[1].precision == precision
+                   for layer in net.egnn.graph_layers)
+
+
+@pytest.mark.parametrize("precision", MODES)
+@pytest.mark.parametrize("fixture,num_atom_types", [("net_egnn_c3_wide", 1), ("net_egnn_c4", 2), ("net_egnn_c3_live", 1),
+                                                    ("net_egnn_c4_live", 2)])
+def test_production_network_forward_on_sampler_like_inputs(cuda, fixture, num_atom_types, precision):
+    """The production network on the inputs a sampler meets (tests/golden/make_golden.py::golden_c3_wide): 32 structures at
+    sigma = 1e-4 ... 0.2 -- uniform-random ones, the diamond sites of Si 2x2x2 displaced by sigma z (the end of a trajectory),
+    half-MASKed ones -- and 8 structures of the two-atom-type network of configs[3]: scores <= 1e-5 rel-L2 against the
+    reference's output over the batch, per structure max(2e-5, the reference's own floor) and 1e-5 of the rms score in absolute
+    terms (tests/teacher_forced.py::forward_check explains the floor: near the diamond sites the score nearly cancels);
+    logits close."""
+    g = load_golden(fixture + ".npz")
+    net = nets.egnn_c3_net(num_atom_types, scale=nets.LIVE_SCALE if fixture.endswith("_live") else 1.0).to(cuda)
+    net.edge_chain_precision = precision
+    with torch.no_grad():
+        out = net(_batch(g, cuda), conditional=False)
+    net.check_status()
+    assert torch.isinf(out.A[..., -1]).all() and (out.A[..., -1] < 0).all()
+    err, worst, where, floor = teacher_forced.forward_check(out.X.cpu().numpy(), g, f"{fixture} / {precision}")
+    print(f"{fixture} / {precision}: batch {err:.2e}, worst structure {worst:.2e} (#{where}, sigma "
+          f"{float(g['noise'][where, 0]):.1e}); the reference's own distance from binary64 over the batch: {floor:.2e}")
+    np.testing.assert_allclose(out.A.cpu().numpy()[..., :-1], g["out_A"][..., :-1], rtol=1e-4, atol=1e-5)
+    if precision is not None:
         assert all(layer._chain[1] is not None and layer._chain[1].precision == precision
                    for layer in net.egnn.graph_layers)
 
@@ -154,48 +181,102 @@ def _generator(cuda, precision, shape=None, **extra):
     return P["Langevin"](npar, spar, net), spar
 
 
-C3_C4_TRAJECTORIES = ["traj_egnn_c3_top", "traj_egnn_c3_bottom", "traj_egnn_c4_top", "traj_egnn_c4_mid"]
+C3_C4_TRAJECTORIES = ["traj_egnn_c3_top", "traj_egnn_c3_bottom", "traj_egnn_c4_top", "traj_egnn_c4_mid",
+                      "traj_egnn_c3_live", "traj_egnn_c4_live_bottom"]
 
 
 def _shape_of(name):
-    """configs[2] (Si, one atom type) or configs[3] (SiGe: two atom types, greedy sampling + one transition per step)"""
-    return cases.C4_SHAPE if "_c4_" in name else cases.C3_SHAPE
+    """configs[2] (Si, one atom type) or configs[3] (SiGe: two atom types, greedy sampling + one transition per step), with
+    the scale-1 or the "live" formula weights"""
+    return cases.shape_of(name)
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("name", C3_C4_TRAJECTORIES)
-def test_c3_teacher_forced_steps(cuda, name, precision):
+def test_c3_teacher_forced_steps(cuda, name, precision, record_property):
+    """Every recorded step of the reference at production width, from the reference's composition with the reference's draws:
+    atom types exact, coordinates <= 1e-5 (torus) -- and, because those two cannot see the network at these step sizes (module
+    docstring of tests/teacher_forced.py), the NETWORK'S OUTPUT of every step against the reference's recorded
+    `model_predictions_i`: scores <= 1e-5 rel-L2 per step, logits close.  36 forwards x 4 structures at 4 x 256 x 4, sigma from
+    0.2 down to sigma_min, the two-atom-type network of configs[3] included.  The two `live` fixtures run the network with
+    formula weights at 2 x the default range, where the hidden layers matter to the output (a 0.1 % error in one 256 x 256
+    matrix moves the scores by 1.4e-4: test_live_fixtures_see_the_hidden_layers); traj_egnn_c4_live_bottom ends at time index 0
+    with C = 3: the one-transition rule is off in the last predictor step and no MASK may remain
+    (src/.../generators/langevin_generator.py:601-604,616-620 -- the status word read by check_status())."""
     g = load_golden(name + ".npz")
     gen, spar = _generator(cuda, precision, shape=_shape_of(name))
     gen.noise_source = _replayed(g)
-    B, M = int(g["batch"]), spar.number_of_corrector_steps
+    records = teacher_forced.run(gen, spar, g, cuda)
+    record_property("steps", teacher_forced.summary(records))
+    print(f"{name} / {precision}: {teacher_forced.summary(records)}")
+    teacher_forced.check(records, f"{name} / {precision}")
+    if name == "traj_egnn_c4_live_bottom":
+        mask = spar.num_atom_types
+        assert (g["pred_composition_i_A"][0] == mask).any() and not (g["pred_composition_im1_A"][-1] == mask).any()
+        # the first predictor (index 2) obeys the one-transition rule, the last one (index 1) does not
+        changed = [(g["pred_composition_i_A"][k] != g["pred_composition_im1_A"][k]).sum(axis=1) for k in range(2)]
+        assert changed[0].max() <= 1 and changed[1].max() > 1
 
-    def axl(prefix, k):
-        return RS.AXL(A=torch.from_numpy(g[prefix + "_A"][k]).to(cuda), X=torch.from_numpy(g[prefix + "_X"][k]).to(cuda),
-                      L=torch.from_numpy(g[prefix + "_L"][k]).to(cuda))
 
-    worst = 0.0
-    with torch.no_grad():
-        gen._prepare(cuda)
-        gen._begin_call(cuda)
-        forces = torch.zeros(B, spar.number_of_atoms, 3, device=cuda)
-        for k, index in enumerate(g["pred_index"]):
-            out = gen.predictor_step(axl("pred_composition_i", k), int(index), forces)
-            assert np.array_equal(out.A.cpu().numpy(), g["pred_composition_im1_A"][k]), (name, "pred", k)
-            worst = max(worst, torus_rel_l2(out.X.cpu().numpy(), g["pred_composition_im1_X"][k]))
-            for m in range(M):
-                kk = k * M + m
-                out = gen.corrector_step(axl("corr_composition_i", kk), int(index) - 1, forces, m)
-                assert np.array_equal(out.A.cpu().numpy(), g["corr_corrected_composition_i_A"][kk]), (name, "corr", kk)
-                worst = max(worst, torus_rel_l2(out.X.cpu().numpy(), g["corr_corrected_composition_i_X"][kk]))
-    gen.check_status()
-    assert gen.noise_source.inner.exhausted()
-    assert worst < 1e-5, f"{name} / {precision}: worst per-step rel-L2 {worst:.2e}"
+@pytest.mark.parametrize("name,factor,logit_factor,message", [
+    ("traj_egnn_c3_top", 0.0, 1.0, "scores"), ("traj_egnn_c3_bottom", 0.0, 1.0, "scores"),
+    ("traj_egnn_c4_mid", 0.0, 1.0, "scores"), ("traj_egnn_c4_mid", 1.0, 0.0, "atom types|logits"),
+    ("traj_egnn_c3_top", 1.0 + 3e-5, 1.0, "scores")])
+def test_teacher_forced_steps_fail_with_a_wrong_network(cuda, name, factor, logit_factor, message):
+    """NEGATIVE CONTROL.  The same teacher-forced replay with the network's scores zeroed (or its logits zeroed, or its scores
+    off by 3e-5 relative) must FAIL -- and it is the network-output assertion that catches it at the 1e-5 level: with zeroed
+    scores the atom types still match, every predictor output is still within 1e-5, and a corrector output is off by < 1e-3
+    (asserted here: it is the blindness the output assertion exists for)."""
+    g = load_golden(name + ".npz")
+    gen, spar = _generator(cuda, "f16x3", shape=_shape_of(name))
+    gen.axl_network = nets.ScaledScore(gen.axl_network, factor, logit_factor)
+    gen.noise_source = _replayed(g)
+    records = teacher_forced.run(gen, spar, g, cuda)
+    with pytest.raises(AssertionError, match=message):
+        teacher_forced.check(records, name)
+    if logit_factor == 1.0:
+        # what the step outputs alone see of a zeroed score: atom types nothing; the PREDICTOR's coordinates nothing (g^2 s / sigma
+        # = 1.4e-6 of |X|); the correctors' coordinates 4e-4 .. 1e-3 at the top and middle of the schedule (their step
+        # eps_i s / sigma grows with sigma_i^2) and nothing at the bottom -- i.e. X <= 1e-5 holds the score to a few per cent in
+        # the correctors of large sigma and not at all elsewhere
+        assert all(r["a_equal"] for r in records)
+        assert all(r["x_err"] < 1e-5 for r in records if r["kind"] == "pred" or "bottom" in name), \
+            [(r["kind"], r["k"], r["x_err"]) for r in records]
+        assert all(r["x_err"] < 5e-3 for r in records)
+        assert min(r["score_err"] for r in records) > (0.99 if factor == 0.0 else 2e-5)
+
+
+@pytest.mark.parametrize("which", ["message", "coordinate", "node"])
+def test_live_fixtures_see_the_hidden_layers(cuda, which):
+    """NEGATIVE CONTROL for the hidden layers: ONE 256 x 256 matrix of the first graph layer off by 0.1 % -- the teacher-forced
+    replay of traj_egnn_c3_live must FAIL on the network output (with the scale-1 weights of traj_egnn_c3_top the same error
+    moves the scores by 3e-6 and passes: asserted too, it is why the live fixtures exist)."""
+    def worst(name):
+        g = load_golden(name + ".npz")
+        gen, spar = _generator(cuda, "f16x3", shape=_shape_of(name))
+        layer = gen.axl_network.egnn.graph_layers[0]
+        mlp = dict(message=layer.message_mlp, coordinate=layer.coord_mlp, node=layer.node_mlp)[which]
+        with torch.no_grad():
+            mlp[2].weight.mul_(1.001)
+        gen.noise_source = _replayed(g)
+        records = teacher_forced.run(gen, spar, g, cuda)
+        return records, max(max(r["score_err"] for r in records), 0.0 if all(r["logits_close"] for r in records) else 1.0)
+
+    records, live = worst("traj_egnn_c3_live")
+    with pytest.raises(AssertionError, match="network output"):
+        teacher_forced.check(records, "perturbed")
+    assert live > 2e-5
+    if which != "node":          # (the node MLP feeds the logits and the next layers' messages, not this layer's coordinates)
+        _, plain = worst("traj_egnn_c3_top")
+        assert plain < 1.5e-5 and plain < live / 3, (plain, live)       # scale 1: at most marginal (8e-6 + 3e-6 .. 9e-6)
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("name", C3_C4_TRAJECTORIES)
 def test_c3_free_run_against_reference(cuda, name, precision):
+    """The same indices without teacher forcing (each step starts from the HIP path's own previous output).  Holds the LOOP --
+    step order, draw order, index handling, the status word -- to the reference; like the per-step coordinates it cannot see the
+    network at these step sizes (that is test_c3_teacher_forced_steps' network-output assertion)."""
     g = load_golden(name + ".npz")
     gen, spar = _generator(cuda, precision, shape=_shape_of(name))
     gen.noise_source = _replayed(g)

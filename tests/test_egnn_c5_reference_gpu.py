@@ -28,6 +28,7 @@ from conftest import load_golden, torus_rel_l2
 from oracle import reference_sampler as RS
 from test_egnn_c3_reference_gpu import _batch
 from test_generator_gpu import _pkg, _replayed
+import teacher_forced
 
 pytestmark = pytest.mark.gpu
 
@@ -85,39 +86,35 @@ def _generator(cuda, precision, g=None, noise_kw=None, **extra):
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("name", ["traj_egnn_c5_top", "traj_egnn_c5_bottom"])
 def test_c5_teacher_forced_steps(cuda, name, precision):
+    """Every predictor (+ repaint) and corrector step from the reference's composition with the reference's draws: atom types
+    exact, coordinates <= 1e-5, the pinned rows of each predictor output bit for bit -- and the network's output of every step
+    (12 forwards x 2 structures of 216 atoms) against the reference's recorded one under the floor rule of
+    test_c5_network_forward_against_reference (tests/teacher_forced.py::check, floor_rule=True)."""
     g = load_golden(name + ".npz")
     assert np.array_equal(g["constrained_relative_coordinates"], cases.diamond_sites(3)[:K].numpy())
     gen, spar = _generator(cuda, precision, g)
     gen.noise_source = _replayed(g)
-    B, M = int(g["batch"]), spar.number_of_corrector_steps
-
-    def axl(prefix, k):
-        return RS.AXL(A=torch.from_numpy(g[prefix + "_A"][k]).to(cuda), X=torch.from_numpy(g[prefix + "_X"][k]).to(cuda),
-                      L=torch.from_numpy(g[prefix + "_L"][k]).to(cuda))
-
-    worst = 0.0
-    with torch.no_grad():
-        gen._prepare(cuda)
-        gen._begin_call(cuda)
-        forces = torch.zeros(B, spar.number_of_atoms, 3, device=cuda)
-        for k, index in enumerate(g["pred_index"]):
-            out = gen.predictor_step(axl("pred_composition_i", k), int(index), forces)
-            want = g["pred_composition_im1_X"][k]
-            assert np.array_equal(out.A.cpu().numpy(), g["pred_composition_im1_A"][k]), (name, "pred", k)
-            got = out.X.cpu().numpy()
-            assert np.array_equal(got[:, :K].view(np.int32), want[:, :K].view(np.int32)), "repainted rows differ in bits"
-            worst = max(worst, torus_rel_l2(got, want))
-            for m in range(M):
-                kk = k * M + m
-                out = gen.corrector_step(axl("corr_composition_i", kk), int(index) - 1, forces, m)
-                assert np.array_equal(out.A.cpu().numpy(), g["corr_corrected_composition_i_A"][kk]), (name, "corr", kk)
-                worst = max(worst, torus_rel_l2(out.X.cpu().numpy(), g["corr_corrected_composition_i_X"][kk]))
-    gen.check_status()
-    assert gen.noise_source.inner.exhausted()
-    assert worst < 1e-5, f"{name} / {precision}: worst per-step rel-L2 {worst:.2e}"
+    records = teacher_forced.run(gen, spar, g, cuda, pinned=K)
+    print(f"{name} / {precision}: {teacher_forced.summary(records)}; floor {max(r['floor'] for r in records):.2e}, "
+          f"worst distance from binary64 {max(r['score_exact'] for r in records):.2e}")
+    teacher_forced.check(records, f"{name} / {precision}", floor_rule=True)
     if int(g["end_index"]) == 0:
         last = g["pred_composition_im1_X"][-1][:, :K]
         assert np.array_equal(last, np.broadcast_to(g["constrained_relative_coordinates"], last.shape))
+
+
+def test_c5_teacher_forced_steps_fail_with_a_zeroed_network(cuda):
+    """NEGATIVE CONTROL: with zeroed scores the atom types, the pinned rows and every predictor output still match (the
+    correctors' outputs at sigma = 0.2 are off by < 1e-3); the network-output assertion is what fails at the 1e-5 level."""
+    g = load_golden("traj_egnn_c5_top.npz")
+    gen, spar = _generator(cuda, "f16x3", g)
+    gen.axl_network = nets.ScaledScore(gen.axl_network, 0.0)
+    gen.noise_source = _replayed(g)
+    records = teacher_forced.run(gen, spar, g, cuda, pinned=K)
+    assert all(r["a_equal"] and r.get("pinned_equal", True) for r in records)
+    assert all(r["x_err"] < 1e-5 for r in records if r["kind"] == "pred") and all(r["x_err"] < 5e-3 for r in records)
+    with pytest.raises(AssertionError, match="scores"):
+        teacher_forced.check(records, "zeroed", floor_rule=True)
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])

@@ -1066,3 +1066,175 @@ def test_node_mlp_rows_against_fp64(cuda, precision, H, n_inner, M, with_residua
     got3, proj3 = kernels.node_mlp_rows(pack_p, xd[:, :H].contiguous(), with_residual, status=status, agg=xd[:, H:].contiguous())
     torch.cuda.synchronize()
     assert int(status.item()) == 0 and torch.equal(got3, got) and torch.equal(proj3, proj)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round-5 regressions around the f16-range fallback
+# ---------------------------------------------------------------------------------------------------------------------
+def _unequal_width_net(cuda, precision="f16x3"):
+    """message / coordinate width 64, node width 32: h and the messages differ in width, so the node MLP takes the
+    Linear(2H -> H) library GEMM + kernels.RowChainPack path (models/egnn.py::_forward_edge_chain) and not NodeMlpPack."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import (
+        EGNNScoreNetwork, EGNNScoreNetworkParameters)
+    torch.manual_seed(23)
+    net = EGNNScoreNetwork(EGNNScoreNetworkParameters(
+        num_atom_types=1, n_layers=2, coordinate_hidden_dimensions_size=64, coordinate_n_hidden_dimensions=2,
+        message_hidden_dimensions_size=64, message_n_hidden_dimensions=2, node_hidden_dimensions_size=32,
+        node_n_hidden_dimensions=2, edges="radial_cutoff", radial_cutoff=7.5)).eval().to(cuda)
+    net.edge_chain_precision = precision
+    return net
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_f16_range_fallback_with_the_row_chain_pack_keeps_the_captured_images(cuda, use_graph):
+    """A captured iteration holds the split-f16 RowChainPack's image pointers in its kernel arguments; the f32 iteration of a
+    fallback used to REPLACE (and free) that pack, so every replay after it read freed memory.  One image per precision is kept
+    now: the watched hipGraph run with one flagged iteration equals, bit for bit, the run with exactly that iteration computed
+    by the f32 kernels by hand."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.predictor_corrector_axl_generator import \
+        PredictorCorrectorSamplingParameters
+    from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters
+    import cases
+    import warnings
+    T, B, k = 9, 5, 5
+
+    def build(wrap):
+        net = _unequal_width_net(cuda)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            npar = NoiseParameters(**cases.noise_ns(T, **cases.LIN))
+            spar = PredictorCorrectorSamplingParameters(**cases.sampling_ns(64, 1, M=0, greedy=False, one=False, cell=[10.86] * 3),
+                                                        rng_mode="device", seed=5, use_hip_graph=use_graph and wrap)
+        gen = LangevinGenerator(npar, spar, net)
+        gen._prepare(cuda)
+        if wrap:
+            gen.axl_network = _RangeReportAt(net, float(gen.noise.time[k])).to(cuda)
+        return gen, net
+
+    gen, net = build(wrap=True)
+    with torch.no_grad(), pytest.warns(UserWarning, match="f16 range"):
+        got = gen.sample(B, cuda)
+    assert gen.f16_range_fallbacks == 1
+    layer = net.egnn.graph_layers[0]
+    assert layer._node_chain[1] is not None and layer._node_mlp[1] is None, "the RowChainPack path did not run"
+    assert set(layer._node_chain_kept) == {"f16x3", "f32"}, "one image per precision is kept"
+    # graph replays after the fallback still run the split image (a second call replays the same captured iteration)
+    with torch.no_grad(), pytest.warns(UserWarning, match="f16 range"):
+        again = gen.sample(B, cuda)
+    ref, ref_net = build(wrap=False)
+    with torch.no_grad():
+        outs = []
+        for _ in range(2):
+            ref._begin_call(cuda)
+            comp = ref.initialize(B, cuda)
+            forces = torch.zeros_like(comp.X)
+            for i in range(T - 1, -1, -1):
+                ref_net.edge_chain_precision = "f32" if i == k else "f16x3"
+                comp = ref._iteration(comp, i, forces)
+            ref.check_status()
+            outs.append(comp)
+    assert torch.equal(got.A, outs[0].A) and torch.equal(got.X, outs[0].X)
+    assert torch.equal(again.A, outs[1].A) and torch.equal(again.X, outs[1].X)
+
+
+class _OverflowAtTimeZeroIndex(_RangeReportAt):
+    """As _RangeReportAt, and the forward's LOGITS come out non-finite as well -- what a real overflow in the node path gives."""
+
+    def forward(self, batch, conditional=None):
+        from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import AXL, TIME
+        out = super().forward(batch, conditional)
+        if self.net.edge_chain_precision in ("f16x3", "f16x3_32x32"):
+            hit = (batch[TIME][:1, 0:1] == self.time_values).any()
+            out = AXL(A=torch.where(hit, torch.full_like(out.A, float("nan")), out.A), X=out.X, L=out.L)
+        return out
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_overflow_in_the_last_iteration_is_redone_without_a_stale_mask_report(cuda, use_graph):
+    """An overflow in the LAST predictor step (time index 1 -> 0, every atom still MASKed, non-finite logits AND scores from the
+    split-f16 attempt): the exact-f32 redo is clean and nothing the dropped attempt raised in either status word survives it --
+    both loops; check_status() inside sample_from_noisy_composition() does not raise, every atom ends unmasked and finite.
+    (With NaN logits this kernel, like torch.max in the reference, takes class 0: the MASK-at-last-step bit is not raised by
+    such an attempt today; the eager loop clears it before the redo all the same, as the watched loop always did.)"""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.predictor_corrector_axl_generator import \
+        PredictorCorrectorSamplingParameters
+    from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import AXL
+    import cases
+    import warnings
+    T, B = 4, 5
+    torch.manual_seed(21)
+    net = nets.egnn_net(1, "radial_cutoff", 7.5, hidden=32, n_layers=2, n_hidden=2).to(cuda)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = NoiseParameters(**cases.noise_ns(T, **cases.LIN))
+        spar = PredictorCorrectorSamplingParameters(**cases.sampling_ns(64, 1, M=1, greedy=False, one=False, cell=[10.86] * 3),
+                                                    rng_mode="device", seed=5, use_hip_graph=use_graph)
+    gen = LangevinGenerator(npar, spar, net)
+    gen._prepare(cuda)
+    gen.axl_network = _OverflowAtTimeZeroIndex(net, float(gen.noise.time[0])).to(cuda)
+    start = AXL(A=torch.ones(B, 64, dtype=torch.long, device=cuda), X=torch.rand(B, 64, 3, device=cuda),
+                L=torch.tensor([10.86, 10.86, 10.86, 0, 0, 0], device=cuda).repeat(B, 1))      # every atom still MASKed
+    with torch.no_grad(), pytest.warns(UserWarning, match="f16 range"):
+        gen._begin_call(cuda)
+        out = gen.sample_from_noisy_composition(start, 2, 0)          # check_status() inside: must not raise
+    assert gen.f16_range_fallbacks >= 1 and (out.A == 0).all() and torch.isfinite(out.X).all()
+    assert int(gen._status.item()) == 0 and int(net.graph_status.item()) == 0
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_a_stale_range_bit_is_not_read_as_the_first_iterations_report(cuda, use_graph):
+    """A range bit left in the network's status word by something outside the loop (the warm-up iterations before a capture, a
+    caller stepping by hand) used to cost a spurious f32 iteration, a warning and lowered exponents."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.predictor_corrector_axl_generator import \
+        PredictorCorrectorSamplingParameters
+    from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters
+    import cases
+    import warnings
+    torch.manual_seed(21)
+    net = nets.egnn_net(1, "radial_cutoff", 7.5, hidden=32, n_layers=2, n_hidden=2).to(cuda)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        npar = NoiseParameters(**cases.noise_ns(5, **cases.LIN))
+        spar = PredictorCorrectorSamplingParameters(**cases.sampling_ns(64, 1, M=1, greedy=False, one=False, cell=[10.86] * 3),
+                                                    rng_mode="device", seed=5, use_hip_graph=use_graph)
+    gen = LangevinGenerator(npar, spar, net)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        first = gen.sample(4, cuda)
+        gen._call_counter = 0
+        net.graph_status.bitwise_or_(_hip.STATUS_EGNN_F16_RANGE)          # stale: nothing of the next call has run
+        second = gen.sample(4, cuda)
+    assert gen.f16_range_fallbacks == 0
+    assert torch.equal(first.X, second.X) and torch.equal(first.A, second.A)
+    scales = [s for layer in net.egnn.graph_layers for s in layer._activation_scales.values()]
+    assert scales and all(int(s.exponents.min()) == 6 for s in scales)
+
+
+def test_activation_scale_state_can_be_reset(cuda):
+    """The exponents are the one piece of state a fallback leaves behind (they only go down): begin_f16_range_fallback() zeroes
+    the collected maxima, reset_f16_range() restores the defaults."""
+    torch.manual_seed(21)
+    net = nets.egnn_net(1, "radial_cutoff", 7.5, hidden=32, n_layers=2, n_hidden=2).to(cuda)
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
+                                                                              NOISY_AXL_COMPOSITION, TIME)
+    X = torch.rand(3, 64, 3, device=cuda)
+    batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.zeros(3, 64, dtype=torch.long, device=cuda), X=X,
+                                        L=torch.tensor([10.86, 10.86, 10.86, 0, 0, 0], device=cuda).repeat(3, 1)),
+             TIME: torch.full((3, 1), 0.5, device=cuda), NOISE: torch.full((3, 1), 0.1, device=cuda),
+             CARTESIAN_FORCES: torch.zeros_like(X)}
+    net.edge_chain_precision = "f32"
+    with torch.no_grad():
+        net(batch, conditional=False)
+    scales = [s for layer in net.egnn.graph_layers for s in layer._activation_scales.values()]
+    assert any(int(s.maxima.max()) != 0 for s in scales), "the exact-f32 kernels collect activation maxima"
+    net.begin_f16_range_fallback()
+    assert all(int(s.maxima.abs().max()) == 0 for s in scales)
+    for s in scales:
+        s.exponents.fill_(2)
+    net.reset_f16_range()
+    assert all(int(s.exponents.min()) == 6 and int(s.exponents.max()) == 6 for s in scales)
