@@ -348,6 +348,9 @@ def time_edge_chain(net, n_edges, n_nodes, device, launches=5):
                  "mean of its 1400 W cap during these launches, clock level 2141 MHz (profiles/r04_chain_power.json)"
                  if shape16 else "1.80-1.82 GHz on the 32x32x16 shape: power-bound (profiles/r03_chain_ablation.md)"))
     return dict(bound="mfma", achieved=round(executed, 2), peak=peak, unit="TFLOP/s", frac=round(executed / peak, 4),
+                # the strict figure: ALGORITHMIC flops (one product per multiply-add of the reference's layers) against the
+                # same peak -- `frac` counts the three executed f16 products per algorithmic one in the split mode
+                frac_algorithmic=round(flops / (ms * 1e-3) / 1e12 / peak, 4),
                 traffic=traffic, traffic_from=traffic_from,
                 kernel=f"egnn_edge_chain_kernel<{H},{prec_index},{2 if pieces else 0}> ({mfma}"
                 f" per product; {n_layers} fused H->H layers + per-node message sums, {edges.shape[0]} edges per launch; 4 launches per "
@@ -390,19 +393,29 @@ def cpu_baseline(w, name, budget_s=15.0, resampling=0):
     elapsed = run(T - 1 - probe, count)
     per_iter = elapsed / count
     value = batch / (T * per_iter)
-    # the port against the REFERENCE ITSELF, both timed on one host (the reference cannot run on the GPU box): the committed
-    # calibration of tools/time_reference.py --port; a reported context figure, like the baseline itself
-    ratio = {"C2": 1.0}.get(name, 1.30)
-    return dict(value=value, unit="structures/s", cores=cores, kind="port",
-                sample=f"{count} of {T} iterations of workload {name} at batch {batch} "
-                       f"({elapsed:.1f} s, {per_iter * 1e3:.2f} ms/iteration), extrapolated to the {T}-step job",
-                reference_equivalent=dict(value=value / ratio, port_over_reference=ratio,
-                                          source="profiles/r04_reference_cpu_timing.json: the reference and this port timed on "
-                                                 "the build container's 8 cores (C3: 0.01415 vs 0.0184 structures/s; C2: 238.4 vs "
-                                                 "240.1; round 3 measured 1.45 and 1.37)"))
+    out = dict(value=value, unit="structures/s", cores=cores, kind="port",
+               sample=f"{count} of {T} iterations of workload {name} at batch {batch} "
+                      f"({elapsed:.1f} s, {per_iter * 1e3:.2f} ms/iteration), extrapolated to the {T}-step job")
+    # the port against the REFERENCE ITSELF, both timed on one host (the reference cannot run on the GPU box): read from the
+    # committed calibration (tools/time_reference.py --port), and only for the workloads it was measured on
+    try:
+        calibration = json.load(open(os.path.join(ROOT, "profiles", REFERENCE_TIMING_FILE)))
+        ratio = float(calibration["port"][name]["port_over_reference"])
+        out["reference_equivalent"] = dict(
+            value=value / ratio, port_over_reference=ratio,
+            source=f"profiles/{REFERENCE_TIMING_FILE}: the reference and this port timed on the build container's "
+                   f"{calibration['host']['cores']} cores, workload {name}")
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
+    return out
+
+
+REFERENCE_TIMING_FILE = "r04_reference_cpu_timing.json"
 
 
 import contextlib
+import datetime
+import threading
 
 
 @contextlib.contextmanager
@@ -420,15 +433,187 @@ def stdout_to_stderr():
         os.close(saved)
 
 
+RENDEZVOUS_TIMEOUT = datetime.timedelta(seconds=120)     # process-group set-up and every collective: fail, do not hang
+
+
+class CardSensor:
+    """Socket power (W), power cap (W) and current shader-clock level (MHz) of the card THIS rank computes on, polled from
+    sysfs (hwmon power1_average / power1_cap, pp_dpm_sclk of the device's PCI address) by a thread while the timed regions
+    run: 10 polls per second, a few microseconds each.  Why it is on the bench line: the dominant kernel of the EGNN workloads
+    runs at the card's power cap (profiles/r04_chain_power.json: 1 346 W of 1 400 W, 2.14 GHz), so on a node of eight cards a
+    rank that is given less power or runs hotter is slower -- the per-rank record shows which, without a second run.
+    Values are None where the sensor files are absent or unreadable (nothing is guessed)."""
+
+    def __init__(self, device_index):
+        import ctypes
+        import glob
+        self.power, self.cap, self.sclk, self.bdf = None, None, None, None
+        self.samples, self.clocks, self._stop, self._thread = [], [], False, None
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0:
+                self.bdf = buf.value.decode().lower()
+        except OSError:
+            pass
+        if self.bdf is None:
+            return
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") +
+                        glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")):
+            if os.path.realpath(f.split("/hwmon/")[0]).lower().endswith(self.bdf):
+                self.power = f
+                self.cap = f.rsplit("/", 1)[0] + "/power1_cap"
+                self.sclk = f.split("/hwmon/")[0] + "/pp_dpm_sclk"
+                break
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read()
+        except (OSError, TypeError):
+            return None
+
+    def _poll(self):
+        while not self._stop:
+            v = self._read(self.power)
+            if v and v.strip().isdigit() and int(v) > 0:
+                self.samples.append(int(v) / 1e6)
+            for line in (self._read(self.sclk) or "").splitlines():
+                if line.rstrip().endswith("*"):
+                    try:
+                        self.clocks.append(float(line.split(":")[1].replace("Mhz", "").replace("*", "").strip()))
+                    except (IndexError, ValueError):
+                        pass
+            time.sleep(0.1)
+
+    def start(self):
+        if self.power is not None and self._thread is None:
+            self._stop = False
+            self._thread = threading.Thread(target=self._poll, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop = True
+            self._thread.join()
+            self._thread = None
+
+    def summary(self):
+        """(mean shader clock MHz, mean power W, cap W, number of samples); nan where unknown."""
+        nan = float("nan")
+        cap = self._read(self.cap)
+        return (sum(self.clocks) / len(self.clocks) if self.clocks else nan,
+                sum(self.samples) / len(self.samples) if self.samples else nan,
+                int(cap) / 1e6 if cap and cap.strip().isdigit() else nan, float(len(self.samples)))
+
+
+PER_RANK_FIELDS = ("rank", "ms_per_step", "trajectory_ms", "sclk_mhz_mean", "power_w_mean", "power_cap_w", "sensor_samples",
+                   "f16_range_fallbacks")
+
+
+def gather_per_rank(dist, world, record, device=None):
+    """ONE small all-gather (len(PER_RANK_FIELDS) doubles per rank) after the timed regions -> the list of per-rank records
+    of rank 0's line, with nan -> None."""
+    mine = torch.tensor([float(v) for v in record], dtype=torch.float64, device=device)
+    if dist is not None and world > 1:
+        out = torch.empty(world * mine.numel(), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(out, mine)
+    else:
+        out = mine
+    rows = out.cpu().reshape(-1, len(PER_RANK_FIELDS)).tolist()
+    clean = []
+    for row in rows:
+        d = {k: (None if v != v else v) for k, v in zip(PER_RANK_FIELDS, row)}
+        d["rank"], d["f16_range_fallbacks"] = int(d["rank"]), int(d["f16_range_fallbacks"] or 0)
+        d["sensor_samples"] = int(d["sensor_samples"] or 0)
+        for k in ("ms_per_step", "trajectory_ms", "sclk_mhz_mean", "power_w_mean", "power_cap_w"):
+            d[k] = None if d[k] is None else round(d[k], 4)
+        clean.append(d)
+    return clean
+
+
+def per_rank_summary(per_rank, batch, T, gather_ms):
+    """slowest_rank and the N = 1 equivalents of an N-rank line: what ONE card of this job did, to be held against the
+    N = 1 line of the same bench (BENCH_rNN.json): if the FASTEST rank's figure equals the N = 1 value, the loss at N is the
+    spread between cards (power, temperature); if every rank is slower than N = 1, it is the node."""
+    def job_ms(r):
+        return (r["trajectory_ms"] if r["trajectory_ms"] is not None else T * r["ms_per_step"]) + gather_ms
+    slowest = max(per_rank, key=job_ms)
+    fastest = min(per_rank, key=job_ms)
+    return slowest["rank"], dict(
+        value_per_gpu_slowest_rank=round(batch / (job_ms(slowest) * 1e-3), 4),
+        value_per_gpu_fastest_rank=round(batch / (job_ms(fastest) * 1e-3), 4),
+        fastest_rank=fastest["rank"], spread=round(job_ms(slowest) / job_ms(fastest) - 1.0, 5),
+        note="structures/s of ONE card over its own timed regions; compare with the N = 1 line's value")
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`--gpus N` with N > 1 and no WORLD_SIZE: start the ranks as a CHILD process.  Nothing in this process has initialised
+    the GPU (importing torch and this package does not) and it never will -- it only relays: the child's stdout and stderr are
+    inherited, its return code becomes this process's, and when it is not zero the rank that failed is named on stderr
+    (every rank reports its own exception as a `bench_error` line before it dies; torch.distributed.run ends the other ranks as
+    soon as one has failed, and every collective carries RENDEZVOUS_TIMEOUT, so a dead rank cannot hold the job)."""
+    import subprocess
+    import tempfile
+    port = args.master_port if args.master_port else free_port()
+    errors = tempfile.mkdtemp(prefix="bench_errors_")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               BENCH_ERROR_DIR=errors)
+    t0 = time.perf_counter()
+    code = subprocess.call(cmd, env=env)
+    if code != 0:
+        reports = []
+        for name in sorted(os.listdir(errors)):
+            with open(os.path.join(errors, name)) as f:
+                reports.append(json.loads(f.read())["bench_error"])
+        print(json.dumps({"bench_launcher": {"exit_code": code, "elapsed_s": round(time.perf_counter() - t0, 1),
+                                             "rank_errors": reports or ["no rank left a report (killed by a signal?)"]}}),
+              file=sys.stderr, flush=True)
+    import shutil
+    shutil.rmtree(errors, ignore_errors=True)
+    raise SystemExit(code if code else 0)
+
+
+def report_rank_error(rank, exc):
+    """A rank's own account of why it is about to die: one line on stderr, and a file the launcher reads."""
+    import traceback
+    text = json.dumps({"bench_error": {"rank": rank, "error": repr(exc),
+                                       "where": traceback.format_exception(type(exc), exc, exc.__traceback__)[-2].strip()}})
+    print(text, file=sys.stderr, flush=True)
+    folder = os.environ.get("BENCH_ERROR_DIR")
+    if folder and os.path.isdir(folder):
+        with open(os.path.join(folder, f"rank{rank}.json"), "w") as f:
+            f.write(text)
+
+
 def rehearse_launch(args, w, world, rank):
-    """The multi-rank control flow of the job on host tensors: what the CPU test of `--gpus N` exercises."""
+    """The multi-rank control flow of the job on host tensors: what the CPU tests of `--gpus N` exercise -- rendezvous with
+    the time-out, the packed all-gather of synthetic compositions, the MAX reduction, the per-rank record's all-gather,
+    rank 0's JSON line; `--rehearse-fail` makes one rank raise or die in the middle."""
     import torch.distributed as dist
     from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import AXL
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if world > 1:
         with stdout_to_stderr():
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=RENDEZVOUS_TIMEOUT)
             dist.barrier()
+    if args.rehearse_fail:
+        kind, who = args.rehearse_fail.split(":")
+        if int(who) == rank:
+            if kind == "raise":
+                raise RuntimeError(f"rehearsal: rank {rank} was asked to fail")
+            import signal
+            os.kill(os.getpid(), signal.SIGKILL)
     batch, n = 4, w["n_atoms"]
     gen = torch.Generator().manual_seed(BASE_SEED + rank)
     comp = AXL(A=torch.randint(0, 2, (batch, n), generator=gen), X=torch.rand(batch, n, 3, generator=gen),
@@ -440,7 +625,8 @@ def rehearse_launch(args, w, world, rank):
         dist.all_gather_into_tensor(out, rows)
     else:
         out.copy_(rows)
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    local_ms = (time.perf_counter() - t0) * 1e3
+    t = torch.tensor([local_ms], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     gathered = unpack_compositions(out, n, 3)
@@ -451,14 +637,264 @@ def rehearse_launch(args, w, world, rank):
         x = torch.rand(batch, n, 3, generator=g)
         ok = ok and torch.equal(gathered.A[r * batch:(r + 1) * batch], a) and \
             torch.equal(gathered.X[r * batch:(r + 1) * batch], x)
+    # the per-rank record of the real job, with this rank's rehearsal figures (no card: the sensor fields are nan)
+    nan = float("nan")
+    per_rank = gather_per_rank(dist if world > 1 else None, world, (rank, 1.0 + rank, local_ms + 10.0 * rank, nan, nan, nan, 0, 0))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"rehearsal": True, "n_gpus": world, "gather_ok": bool(ok), "gather_ms": float(t[0]) * 1e3,
-                          "collectives": 1, "workload": args.workload}), flush=True)
+        slowest, n1 = per_rank_summary(per_rank, batch, w["noise"]["total_time_steps"], 0.0)
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "gather_ok": bool(ok), "gather_ms": float(t[0]),
+                          "collectives": 1, "workload": args.workload, "per_rank": per_rank, "slowest_rank": slowest,
+                          "n1_equivalent": n1}), flush=True)
     if not ok:
         raise SystemExit(1)
+
+
+class Job:
+    """What one process of the bench shares between the workloads it measures: its device, its process group and the timing
+    protocol (barrier + synchronize | work | each rank stamps its clock | barrier; MAX over ranks)."""
+
+    def __init__(self, args, device, dist, world, rank):
+        self.args, self.device, self.dist, self.world, self.rank = args, device, dist, world, rank
+        self.coll = (lambda t: t) if args.backend == "nccl" else (lambda t: t.cpu())   # gloo rehearsal: host copies
+
+    def wait_for_gpu(self):
+        """The GPU is awaited by polling an event before the blocking synchronize: a blocking synchronize alone wakes
+        the host tens of microseconds late, which matters when K steps take ~1 ms."""
+        done = torch.cuda.Event()
+        done.record()
+        while not done.query():
+            pass
+        torch.cuda.synchronize(self.device)
+
+    def barrier(self):
+        """torch.cuda.synchronize + dist.barrier + torch.cuda.synchronize."""
+        self.wait_for_gpu()
+        if self.dist is not None:
+            self.dist.barrier()
+            torch.cuda.synchronize(self.device)
+
+    def timed(self, fn):
+        """(MAX over ranks, this rank's own) elapsed seconds of fn: barrier + synchronize | fn | each rank stamps its clock
+        when its own work is complete | barrier.  The time is the MAX over ranks (= when the last rank finished), so the
+        closing barrier's own latency -- an RCCL all-reduce of ~50 us -- is not booked as sampling time."""
+        self.barrier()
+        t0 = time.perf_counter()
+        fn()
+        self.wait_for_gpu()
+        local = time.perf_counter() - t0
+        self.barrier()
+        elapsed = local
+        if self.dist is not None:
+            t = self.coll(torch.tensor([local], dtype=torch.float64, device=self.device))
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+        return elapsed, local
+
+
+def measure_workload(job, name, steps, warmup, whole_job_budget_s, egnn_precision, resampling_arg=None, batch_arg=None,
+                     no_graph=False, forward_arg=None, other_mode=True, families=True, sensor=None):
+    """One workload on this process's card: the K-step region, the whole-job region where it fits the budget, the job's one
+    collective, the dominant kernels' launch durations.  Returns the pieces of a JSON line (every rank runs it; rank 0 alone
+    times the stand-alone kernel launches)."""
+    args, device, dist, world, rank = job.args, job.device, job.dist, job.world, job.rank
+    w = WORKLOADS[name]
+    batch = batch_arg or w["batch"]
+    T = w["noise"]["total_time_steps"]
+    mlp = w["net"] == "mlp"
+    # defaults: the MLP workload runs its whole T-step trajectory (what the product does in one launch); the EGNN ones 3
+    steps = steps if steps is not None else (T if mlp else 3)
+    warmup = warmup if warmup is not None else (T if mlp else 1)
+    forward = forward_arg or ("fused" if mlp else "pytorch")
+    assert forward == "pytorch" or mlp, "the fused forward exists for the MLP score network only"
+    # the EGNN iteration is capturable when its radius graph needs no host read: the fused edge chain in every layer
+    use_graph = w["graph"] and not no_graph and forward == "pytorch" and (mlp or egnn_precision != "library")
+    resampling = (resampling_arg if resampling_arg is not None else w.get("resampling", 0)) if "repaint" in w else 0
+    gen, noise, sampling, net = build_generator(w, device, rank, batch, use_graph, resampling=resampling)
+    gen.fused_score_network = forward == "fused"
+    if not mlp:
+        net.edge_chain_precision = None if egnn_precision == "library" else egnn_precision
+    timed = job.timed
+
+    with torch.no_grad():
+        gen._prepare(device)
+        gen._begin_call(device)                      # Philox seed = BASE_SEED + rank
+        start = gen.initialize(batch, device)
+
+        def new_loop():
+            return FusedLoop(gen, start, T) if forward == "fused" else IterationLoop(gen, start, T, use_graph=use_graph)
+        loop = new_loop()
+        advance(loop, warmup, T)
+        if sensor is not None:
+            sensor.start()
+        elapsed, local = timed(lambda: advance(loop, steps, T))
+        ms_per_step, ms_per_step_local = elapsed * 1e3 / steps, local * 1e3 / steps
+        # MLP workloads: the product runs the whole trajectory as ONE launch (4 ms); K iterations of it pay the launch's
+        # fixed cost once per K.  So the job time is measured directly: one whole T-iteration trajectory, timed the same way.
+        trajectory_ms = trajectory_ms_local = None
+        if not mlp and 0 < T * ms_per_step * 1e-3 <= whole_job_budget_s:
+            # EGNN workloads: the job itself, measured -- a fresh loop over the same start (capture of the iteration is a
+            # one-off of the process and stays outside, like the warm-up), T replays, then the one host read of the status word
+            loop = new_loop()
+
+            def whole_job():
+                advance(loop, T, T)
+                gen.check_status()
+            trajectory_ms, trajectory_ms_local = (1e3 * t for t in timed(whole_job))
+        if mlp:
+            # (one untimed trajectory first: the first T-iteration launch of a process also sizes and first-touches its
+            # 328-MB noise workspace)
+            loop = new_loop()
+            advance(loop, T, T)
+            loop = new_loop()
+            trajectory_ms, trajectory_ms_local = (1e3 * t for t in timed(lambda: advance(loop, T, T)))
+        if sensor is not None:
+            sensor.stop()
+        # the single collective of the job: ONE all-gather of the packed final compositions
+        comp = loop.composition
+        gather_ms = 0.0
+        if dist is not None:
+            rows = job.coll(pack_compositions(comp))
+            out = torch.empty((world * rows.shape[0], rows.shape[1]), dtype=torch.uint8, device=rows.device)
+            dist.all_gather_into_tensor(out, rows)      # untimed: RCCL sets up its rings / channels at the first collective
+            gather_ms = timed(lambda: dist.all_gather_into_tensor(out, rows))[0] * 1e3
+            gathered = unpack_compositions(out, w["n_atoms"], 3)
+            mine = slice(rank * batch, (rank + 1) * batch)
+            assert torch.equal(gathered.A[mine].to(device), comp.A) and torch.equal(gathered.X[mine].to(device), comp.X)
+        gen.check_status()
+        job_ms = (trajectory_ms if trajectory_ms is not None else T * ms_per_step) + gather_ms
+        value = (batch * world) / (job_ms * 1e-3)
+        other = None
+        if other_mode and not mlp and egnn_precision in ("f32", "f16x3", "f16x3_32x32"):
+            # the same job through the other arithmetic mode of the edge chain (2 iterations, same timing protocol)
+            other_name = "f32" if egnn_precision != "f32" else "f16x3"
+            net.edge_chain_precision = other_name
+            loop_o = new_loop()
+            advance(loop_o, 1, T)
+            ms_o = timed(lambda: advance(loop_o, 2, T))[0] * 1e3 / 2
+            net.edge_chain_precision = egnn_precision
+            other = dict(egnn_edge_chain=other_name, ms_per_step=round(ms_o, 5),
+                         value=round((batch * world) / ((T * ms_o + gather_ms) * 1e-3), 4), unit="structures/s")
+            del loop_o
+        generic_path = None
+        if families and forward == "fused":
+            # the same job through the generic instantiation of the persistent kernel (any MLP shape takes this path;
+            # the dimension-specialised, folded instantiation above is selected when the network matches a template)
+            from diffusion_for_multi_scale_molecular_dynamics_amd import _hip
+            generic = {}
+            for key, options in (("folded", _hip.MLP_SAMPLE_GENERIC_KERNEL),
+                                 ("layer_by_layer", _hip.MLP_SAMPLE_GENERIC_KERNEL | _hip.MLP_SAMPLE_UNFOLDED),
+                                 ("padded_family", _hip.MLP_SAMPLE_PADDED_FAMILY)):
+                gen.fused_sampler_options = options
+                loop_g = new_loop()
+                advance(loop_g, T, T)
+                loop_g = new_loop()
+                generic[key] = timed(lambda: advance(loop_g, T, T))[0] * 1e3
+            gen.fused_sampler_options = 0
+            generic_path = dict(kernel="mlp_pc_sample_kernel<G,true,0> (generic instantiation: any MLP shape; folded input / output "
+                                       "layers + hardware sin / cos, what shapes outside the register-resident family run)",
+                                trajectory_ms=round(generic["folded"], 4),
+                                value=round((batch * world) / ((generic["folded"] + gather_ms) * 1e-3), 2), unit="structures/s",
+                                layer_by_layer=dict(trajectory_ms=round(generic["layer_by_layer"], 4),
+                                                    value=round((batch * world) / ((generic["layer_by_layer"] + gather_ms) * 1e-3), 2)),
+                                # the same network through the PADDED register-resident family (mlp_pc_sample_kernel<8,true,213>:
+                                # run-time structure dimensions, fixed padded layer sizes): what every MLP configuration of the
+                                # reference outside the exact template runs (hidden <= 64, N <= 8, <= 192 folded inputs)
+                                padded_family=dict(trajectory_ms=round(generic["padded_family"], 4),
+                                                   value=round((batch * world) / ((generic["padded_family"] + gather_ms) * 1e-3), 2)))
+
+        roofline = forward_gemm = None
+        if rank == 0:
+            if forward == "fused":
+                m = time_fused_kernel(gen, loop, batch, w, device)
+            elif w["dominant"] == "pc_step_kernel":
+                m = time_update_kernel(gen, batch, w, device)
+            else:
+                m = time_radius_graph(batch, w, device)
+                n_e = int(round(m["edges_per_atom"] * batch * w["n_atoms"]))
+                if egnn_precision == "library":
+                    forward_gemm = time_edge_gemm(n_e, device)
+                else:
+                    forward_gemm = time_edge_chain(net, n_e, batch * w["n_atoms"], device)
+            achieved = m["bytes"] / (m["ms"] * 1e-3) / 1e9
+            traffic = None          # HBM bytes per launch measured with PMC counters in a separate rocprofv3 pass
+            try:
+                table = {}
+                for fname in ("traffic_r01.json", "traffic_r02.json"):        # later rounds override
+                    path = os.path.join(ROOT, "profiles", fname)
+                    if os.path.exists(path):
+                        table.update(json.load(open(path)))
+                entry = table[f"{name}/{forward}"]
+                if entry["kernel"] == m["kernel"].split()[0].split("<")[0] and batch == w["batch"]:
+                    traffic = entry["bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
+            roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, kernel=m["kernel"],
+                            avg_launch_us=round(m["ms"] * 1e3, 3), algorithmic_bytes_per_launch=m["bytes"])
+            if "compute" in m:
+                roofline["compute"] = m["compute"]
+
+    out = dict(
+        name=name, w=w, T=T, mlp=mlp, batch=batch, steps=steps, warmup=warmup, forward=forward, use_graph=use_graph,
+        resampling=resampling, ms_per_step=ms_per_step, ms_per_step_local=ms_per_step_local, trajectory_ms=trajectory_ms,
+        trajectory_ms_local=trajectory_ms_local, gather_ms=gather_ms, job_ms=job_ms, value=value, other_mode=other,
+        generic_path=generic_path, roofline=roofline, forward_gemm=forward_gemm,
+        f16_range_fallbacks=int(gen.f16_range_fallbacks), peak_memory=int(torch.cuda.max_memory_allocated(device)))
+    del loop, gen, net
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def as_line(m, world, egnn_precision, backend):
+    """The JSON fields of one measured workload (the whole line for the primary one; an `also_measured` entry otherwise)."""
+    w, T, mlp = m["w"], m["T"], m["mlp"]
+    line = {
+        "metric": "sampled structures/sec (%d-step predictor-corrector SDE sampling)" % T,
+        "value": round(m["value"], 4), "unit": "structures/s", "n_gpus": world, "steps": m["steps"], "warmup": m["warmup"],
+        "ms_per_step": round(m["ms_per_step"], 5), "job_ms": round(m["job_ms"], 4),
+        "value_from": ("one whole %d-iteration trajectory timed end to end (trajectory_ms %.4f) + gather" % (T, m["trajectory_ms"]))
+        if m["trajectory_ms"] is not None else "total_time_steps x ms_per_step + gather",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if mlp or egnn_precision not in ("f16x3", "f16x3_32x32") else
+        "f32 (per-edge matrix products as split-f16 hi/lo x3 MFMA terms with f32 accumulation: 22-bit products; state, "
+        "updates, reductions and every other layer in f32)", "data": "synthetic (random-init score network, uniform-random initial structures)",
+        "config": {"workload": f"{m['name']}: {w['desc']}", "batch_per_gpu": m["batch"], "global_batch": m["batch"] * world,
+                   "number_of_atoms": w["n_atoms"], "total_time_steps": T, "corrector_steps": w["M"],
+                   "repaint_resampling_steps": m["resampling"],
+                   "rng": "device Philox4x32-10", "hip_graph": bool(m["use_graph"]),
+                   "score_network_forward": "fused HIP (one persistent kernel per launch of K iterations)"
+                   if m["forward"] == "fused" else "PyTorch-ROCm module (plugin API)", "gather_ms": round(m["gather_ms"], 4),
+                   "parallelism": f"independent batches x{world}, one all-gather at the end",
+                   "collective_backend": backend,
+                   # every switch of the library is an explicit argument; MDX_* variables are not read by the product
+                   # and are listed only so that a stray one is visible
+                   "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MDX_")},
+                   "peak_device_memory_bytes": m["peak_memory"],
+                   "f16_range_fallbacks": m["f16_range_fallbacks"]},
+        "roofline": m["roofline"],
+    }
+    if m["generic_path"] is not None:
+        line["generic_path"] = m["generic_path"]
+    if m["other_mode"] is not None:
+        line["other_edge_chain_mode"] = m["other_mode"]
+    if m["forward_gemm"] is not None:
+        # EGNN workloads: the step is the per-edge MLP chain (matrix cores); the streaming kernels are < 1 % of it.  The
+        # dominant kernel's roofline is `roofline`; the largest HBM-bound kernel (radius graph, N1) is `roofline_hbm`.
+        line["roofline_hbm"], line["roofline"] = m["roofline"], m["forward_gemm"]
+        line["config"]["egnn_edge_chain"] = egnn_precision
+    return line
+
+
+# The other BASELINE configurations, measured after the primary workload on the same card when the bench is run with its
+# defaults at N = 1: (workload, steps, warmup, resampling, whole-job budget in seconds).  C2's job is one 4 ms launch and is
+# timed whole, with its three kernel families; C4 is a 20-iteration region (its whole job is C3's, 31 s); C5 a 3-iteration
+# region without and with the resampling pass (its whole jobs take 6 and 11 minutes: profiles/r04_bench_c5_whole_job.json).
+ALSO_MEASURED = (("C2", None, None, None, 0.0), ("C4", 20, 2, None, 0.0), ("C5", 3, 1, 0, 0.0), ("C5", 3, 1, 1, 0.0))
 
 
 def main():
@@ -488,25 +924,34 @@ def main():
                          "split-f16 three-product form with binary32 accumulation, binary32-level accuracy (error against fp64 "
                          "equal to the f32 paths': tests/test_egnn_chain_gpu.py); 'f32' exact binary32 MFMA; 'library' = "
                          "per-layer hipBLASLt GEMMs (round-1 path).  The other MFMA mode is timed too and reported beside it.")
-    ap.add_argument("--master-port", type=int, default=29541, help="rendezvous port when bench.py starts its own ranks")
+    ap.add_argument("--master-port", type=int, default=None,
+                    help="rendezvous port when bench.py starts its own ranks (default: a free port of 127.0.0.1)")
+    ap.add_argument("--also-measured", choices=["auto", "yes", "no"], default="auto",
+                    help="after the primary workload, measure the other BASELINE configurations (ALSO_MEASURED) on the same card "
+                         "and report them under `also_measured`; auto = at N = 1 with the default workload")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="no GPU work: the ranks only run the job's control flow on host tensors (gloo) -- rendezvous, the "
-                         "packed all-gather of synthetic compositions, the MAX reduction, rank 0's JSON line; used by the "
-                         "CPU test of the launcher")
+                         "packed all-gather of synthetic compositions, the MAX reduction, the per-rank record, rank 0's JSON "
+                         "line; used by the CPU tests of the launcher")
+    ap.add_argument("--rehearse-fail", default=None, metavar="raise:R|kill:R",
+                    help="rehearsal only: rank R raises an exception (raise) or is killed by a signal (kill) after the rendezvous")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # Start the ranks as a CHILD process.  Nothing in this process has initialised the GPU yet (importing torch and
-        # this package does not), and it never will: it only relays the child's output and return code.
-        import subprocess
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        raise SystemExit(subprocess.call(cmd, env=env))
+        return launch_ranks(args)
 
     w = WORKLOADS[args.workload]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    try:
+        run_rank(args, w, world, rank)
+    except BaseException as exc:                     # noqa: BLE001  (report, then die with the same exception)
+        if not isinstance(exc, SystemExit) or exc.code not in (0, None):
+            report_rank_error(rank, exc)
+        raise
+
+
+def run_rank(args, w, world, rank):
     if args.rehearse_launch:
         return rehearse_launch(args, w, world, rank)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -520,218 +965,50 @@ def main():
         # job's RCCL calls -- group set-up, the packed all-gather, the MAX all-reduce, barriers, teardown -- on one GPU)
         import torch.distributed as dist
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)      # RCCL over xGMI
+            dist.init_process_group(backend="nccl", device_id=device, timeout=RENDEZVOUS_TIMEOUT)      # RCCL over xGMI
         else:
             with stdout_to_stderr():
-                dist.init_process_group(backend="gloo")
+                dist.init_process_group(backend="gloo", timeout=RENDEZVOUS_TIMEOUT)
                 dist.barrier()
-    coll = (lambda t: t) if args.backend == "nccl" else (lambda t: t.cpu())   # gloo rehearsal: collectives on host copies
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    job = Job(args, device, dist, world, rank)
+    sensor = CardSensor(device.index)
 
-    batch = args.batch or w["batch"]
-    T = w["noise"]["total_time_steps"]
-    mlp = w["net"] == "mlp"
-    # defaults: the MLP workload runs its whole T-step trajectory (what the product does in one launch); the EGNN ones 3
-    steps = args.steps if args.steps is not None else (T if mlp else 3)
-    warmup = args.warmup if args.warmup is not None else (T if mlp else 1)
-    forward = args.forward or ("fused" if mlp else "pytorch")
-    assert forward == "pytorch" or mlp, "the fused forward exists for the MLP score network only"
-    # the EGNN iteration is capturable when its radius graph needs no host read: the fused edge chain in every layer
-    use_graph = w["graph"] and not args.no_graph and forward == "pytorch" and (mlp or args.egnn_precision != "library")
+    m = measure_workload(job, args.workload, args.steps, args.warmup, args.whole_job_budget_s, args.egnn_precision,
+                         resampling_arg=args.resampling, batch_arg=args.batch, no_graph=args.no_graph,
+                         forward_arg=args.forward, sensor=sensor)
+    # the per-rank record: ONE small all-gather after the timed regions
+    nan = float("nan")
+    record = (rank, m["ms_per_step_local"], m["trajectory_ms_local"] if m["trajectory_ms_local"] is not None else nan,
+              *sensor.summary(), m["f16_range_fallbacks"])
+    per_rank = gather_per_rank(dist, world, record, device=device if args.backend == "nccl" else None)
 
-    resampling = (args.resampling if args.resampling is not None else w.get("resampling", 0)) if "repaint" in w else 0
-    gen, noise, sampling, net = build_generator(w, device, rank, batch, use_graph, resampling=resampling)
-    gen.fused_score_network = forward == "fused"
-    if not mlp:
-        net.edge_chain_precision = None if args.egnn_precision == "library" else args.egnn_precision
-
-    def wait_for_gpu():
-        """The GPU is awaited by polling an event before the blocking synchronize: a blocking synchronize alone wakes
-        the host tens of microseconds late, which matters when K steps take ~1 ms."""
-        done = torch.cuda.Event()
-        done.record()
-        while not done.query():
-            pass
-        torch.cuda.synchronize(device)
-
-    def barrier():
-        """torch.cuda.synchronize + dist.barrier + torch.cuda.synchronize."""
-        wait_for_gpu()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(device)
-
-    def timed(fn):
-        """barrier + synchronize | fn | each rank stamps its clock when its own work is complete | barrier; the time is
-        the MAX over ranks (= when the last rank finished), so the closing barrier's own latency -- an RCCL all-reduce of
-        ~50 us -- is not booked as sampling time."""
-        barrier()
-        t0 = time.perf_counter()
-        fn()
-        wait_for_gpu()
-        elapsed = time.perf_counter() - t0
-        barrier()
-        if dist is not None:
-            t = coll(torch.tensor([elapsed], dtype=torch.float64, device=device))
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t[0])
-        return elapsed
-
-    with torch.no_grad():
-        gen._prepare(device)
-        gen._begin_call(device)                      # Philox seed = BASE_SEED + rank
-        start = gen.initialize(batch, device)
-
-        def new_loop():
-            return FusedLoop(gen, start, T) if forward == "fused" else IterationLoop(gen, start, T, use_graph=use_graph)
-        loop = new_loop()
-        advance(loop, warmup, T)
-        elapsed = timed(lambda: advance(loop, steps, T))
-        ms_per_step = elapsed * 1e3 / steps
-        # MLP workloads: the product runs the whole trajectory as ONE launch (4 ms); K iterations of it pay the launch's
-        # fixed cost once per K.  So the job time is measured directly: one whole T-iteration trajectory, timed the same way.
-        trajectory_ms = None
-        if not mlp and 0 < T * ms_per_step * 1e-3 <= args.whole_job_budget_s:
-            # EGNN workloads: the job itself, measured -- a fresh loop over the same start (capture of the iteration is a
-            # one-off of the process and stays outside, like the warm-up), T replays, then the one host read of the status word
-            loop = new_loop()
-
-            def whole_job():
-                advance(loop, T, T)
-                gen.check_status()
-            trajectory_ms = timed(whole_job) * 1e3
-        if mlp:
-            # (one untimed trajectory first: the first T-iteration launch of a process also sizes and first-touches its
-            # 328-MB noise workspace)
-            loop = new_loop()
-            advance(loop, T, T)
-            loop = new_loop()
-            trajectory_ms = timed(lambda: advance(loop, T, T)) * 1e3
-        # the single collective of the job: ONE all-gather of the packed final compositions
-        comp = loop.composition
-        gather_ms = 0.0
-        if dist is not None:
-            rows = coll(pack_compositions(comp))
-            out = torch.empty((world * rows.shape[0], rows.shape[1]), dtype=torch.uint8, device=rows.device)
-            dist.all_gather_into_tensor(out, rows)      # untimed: RCCL sets up its rings / channels at the first collective
-            gather_ms = timed(lambda: dist.all_gather_into_tensor(out, rows)) * 1e3
-            gathered = unpack_compositions(out, w["n_atoms"], 3)
-            mine = slice(rank * batch, (rank + 1) * batch)
-            assert torch.equal(gathered.A[mine].to(device), comp.A) and torch.equal(gathered.X[mine].to(device), comp.X)
-        gen.check_status()
-        job_ms = (trajectory_ms if trajectory_ms is not None else T * ms_per_step) + gather_ms
-        value = (batch * world) / (job_ms * 1e-3)
-        other_mode = None
-        if not mlp and args.egnn_precision in ("f32", "f16x3", "f16x3_32x32"):
-            # the same job through the other arithmetic mode of the edge chain (2 iterations, same timing protocol)
-            other = "f32" if args.egnn_precision != "f32" else "f16x3"
-            net.edge_chain_precision = other
-            loop_o = new_loop()
-            advance(loop_o, 1, T)
-            ms_o = timed(lambda: advance(loop_o, 2, T)) * 1e3 / 2
-            net.edge_chain_precision = args.egnn_precision
-            other_mode = dict(egnn_edge_chain=other, ms_per_step=round(ms_o, 5),
-                              value=round((batch * world) / ((T * ms_o + gather_ms) * 1e-3), 4), unit="structures/s")
-        generic_path = None
-        if forward == "fused":
-            # the same job through the generic instantiation of the persistent kernel (any MLP shape takes this path;
-            # the dimension-specialised, folded instantiation above is selected when the network matches a template)
-            from diffusion_for_multi_scale_molecular_dynamics_amd import _hip
-            generic = {}
-            for key, options in (("folded", _hip.MLP_SAMPLE_GENERIC_KERNEL),
-                                 ("layer_by_layer", _hip.MLP_SAMPLE_GENERIC_KERNEL | _hip.MLP_SAMPLE_UNFOLDED),
-                                 ("padded_family", _hip.MLP_SAMPLE_PADDED_FAMILY)):
-                gen.fused_sampler_options = options
-                loop_g = new_loop()
-                advance(loop_g, T, T)
-                loop_g = new_loop()
-                generic[key] = timed(lambda: advance(loop_g, T, T)) * 1e3
-            gen.fused_sampler_options = 0
-            generic_path = dict(kernel="mlp_pc_sample_kernel<G,true,0> (generic instantiation: any MLP shape; folded input / output "
-                                       "layers + hardware sin / cos, what shapes outside the register-resident family run)",
-                                trajectory_ms=round(generic["folded"], 4),
-                                value=round((batch * world) / ((generic["folded"] + gather_ms) * 1e-3), 2), unit="structures/s",
-                                layer_by_layer=dict(trajectory_ms=round(generic["layer_by_layer"], 4),
-                                                    value=round((batch * world) / ((generic["layer_by_layer"] + gather_ms) * 1e-3), 2)),
-                                # the same network through the PADDED register-resident family (mlp_pc_sample_kernel<8,true,213>:
-                                # run-time structure dimensions, fixed padded layer sizes): what every MLP configuration of the
-                                # reference outside the exact template runs (hidden <= 64, N <= 8, <= 192 folded inputs)
-                                padded_family=dict(trajectory_ms=round(generic["padded_family"], 4),
-                                                   value=round((batch * world) / ((generic["padded_family"] + gather_ms) * 1e-3), 2)))
-
-        roofline = forward_gemm = roofline_hbm = None
-        if rank == 0:
-            if forward == "fused":
-                m = time_fused_kernel(gen, loop, batch, w, device)
-            elif w["dominant"] == "pc_step_kernel":
-                m = time_update_kernel(gen, batch, w, device)
-            else:
-                m = time_radius_graph(batch, w, device)
-                n_e = int(round(m["edges_per_atom"] * batch * w["n_atoms"]))
-                if args.egnn_precision == "library":
-                    forward_gemm = time_edge_gemm(n_e, device)
-                else:
-                    forward_gemm = time_edge_chain(net, n_e, batch * w["n_atoms"], device)
-            achieved = m["bytes"] / (m["ms"] * 1e-3) / 1e9
-            traffic = None          # HBM bytes per launch measured with PMC counters in a separate rocprofv3 pass
-            try:
-                table = {}
-                for name in ("traffic_r01.json", "traffic_r02.json"):        # later rounds override
-                    path = os.path.join(ROOT, "profiles", name)
-                    if os.path.exists(path):
-                        table.update(json.load(open(path)))
-                entry = table[f"{args.workload}/{forward}"]
-                if entry["kernel"] == m["kernel"].split()[0].split("<")[0] and batch == w["batch"]:
-                    traffic = entry["bytes_per_launch"]
-            except (OSError, KeyError, ValueError):
-                pass
-            roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, kernel=m["kernel"],
-                            avg_launch_us=round(m["ms"] * 1e3, 3), algorithmic_bytes_per_launch=m["bytes"])
-            if "compute" in m:
-                roofline["compute"] = m["compute"]
+    also = None
+    wanted = args.also_measured == "yes" or (args.also_measured == "auto" and world == 1 and args.workload == "C3"
+                                             and args.batch is None and args.forward is None and not args.no_graph)
+    if wanted:
+        also = []
+        for name, steps, warmup, resampling, budget in ALSO_MEASURED:
+            t0 = time.perf_counter()
+            other = measure_workload(job, name, steps, warmup, budget, args.egnn_precision, resampling_arg=resampling,
+                                     other_mode=False, families=True)
+            if rank == 0:
+                entry = as_line(other, world, args.egnn_precision, args.backend if dist is not None else None)
+                entry["measured_in_s"] = round(time.perf_counter() - t0, 1)
+                also.append(entry)
 
     if rank != 0:
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
-    result = {
-        "metric": "sampled structures/sec (%d-step predictor-corrector SDE sampling)" % T,
-        "value": round(value, 4), "unit": "structures/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": round(ms_per_step, 5), "job_ms": round(job_ms, 4),
-        "value_from": ("one whole %d-iteration trajectory timed end to end (trajectory_ms %.4f) + gather" % (T, trajectory_ms))
-        if trajectory_ms is not None else "total_time_steps x ms_per_step + gather",
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if mlp or args.egnn_precision not in ("f16x3", "f16x3_32x32") else
-        "f32 (per-edge matrix products as split-f16 hi/lo x3 MFMA terms with f32 accumulation: 22-bit products; state, "
-        "updates, reductions and every other layer in f32)", "data": "synthetic (random-init score network, uniform-random initial structures)",
-        "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": batch, "global_batch": batch * world,
-                   "number_of_atoms": w["n_atoms"], "total_time_steps": T, "corrector_steps": w["M"],
-                   "repaint_resampling_steps": resampling,
-                   "rng": "device Philox4x32-10", "hip_graph": bool(use_graph),
-                   "score_network_forward": "fused HIP (one persistent kernel per launch of K iterations)"
-                   if forward == "fused" else "PyTorch-ROCm module (plugin API)", "gather_ms": round(gather_ms, 4),
-                   "parallelism": f"independent batches x{world}, one all-gather at the end",
-                   "collective_backend": args.backend if dist is not None else None,
-                   # every switch of the library is an explicit argument; MDX_* variables are not read by the product
-                   # and are listed only so that a stray one is visible
-                   "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MDX_")},
-                   "peak_device_memory_bytes": int(torch.cuda.max_memory_allocated(device)),
-                   "f16_range_fallbacks": int(gen.f16_range_fallbacks)},
-        "roofline": roofline,
-    }
-    if generic_path is not None:
-        result["generic_path"] = generic_path
-    if other_mode is not None:
-        result["other_edge_chain_mode"] = other_mode
-    if forward_gemm is not None:
-        # EGNN workloads: the step is the per-edge MLP chain (matrix cores); the streaming kernels are < 1 % of it.  The
-        # dominant kernel's roofline is `roofline`; the largest HBM-bound kernel (radius graph, N1) is `roofline_hbm`.
-        result["roofline_hbm"], result["roofline"] = roofline, forward_gemm
-        result["config"]["egnn_edge_chain"] = args.egnn_precision
+    result = as_line(m, world, args.egnn_precision, args.backend if dist is not None else None)
+    slowest, n1 = per_rank_summary(per_rank, m["batch"], m["T"], m["gather_ms"])
+    result["per_rank"], result["slowest_rank"], result["n1_equivalent"] = per_rank, slowest, n1
+    if also is not None:
+        result["also_measured"] = also
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(w, args.workload, resampling=resampling)
+        result["cpu_baseline"] = cpu_baseline(w, args.workload, resampling=m["resampling"])
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -297,18 +297,50 @@ def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no WORLD_SIZE: the parent spawns torch.distributed.run as a child (before any GPU
     initialisation), relays rank 0's JSON line and exits with the child's code.  Rehearsal mode: host tensors, gloo."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch",
-                          "--master-port", "29547"], env=env, capture_output=True, text=True, timeout=240)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch"],
+                         env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
     import json
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["gather_ok"] and line["collectives"] == 1
+    # the per-rank record (one small all-gather after the timed region): every rank's own figures, the slowest rank named,
+    # and what one card did for comparison with an N = 1 line
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1]
+    assert all(set(r) == {"rank", "ms_per_step", "trajectory_ms", "sclk_mhz_mean", "power_w_mean", "power_cap_w",
+                          "sensor_samples", "f16_range_fallbacks"} for r in line["per_rank"])
+    assert [r["ms_per_step"] for r in line["per_rank"]] == [1.0, 2.0] and line["slowest_rank"] == 1
+    assert line["n1_equivalent"]["fastest_rank"] == 0 and line["n1_equivalent"]["spread"] > 0
+    assert line["n1_equivalent"]["value_per_gpu_fastest_rank"] > line["n1_equivalent"]["value_per_gpu_slowest_rank"] > 0
     # a failing child is reported through the exit code
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch",
                           "--workload", "nope"], env=env, capture_output=True, text=True, timeout=240)
     assert bad.returncode != 0
+
+
+@pytest.mark.parametrize("how", ["raise", "kill"])
+def test_bench_fails_fast_when_a_rank_dies(how):
+    """One of two ranks raises -- or is killed by a signal -- right after the rendezvous, while the other is on its way into the
+    job's collective: the launcher exits non-zero within seconds (torch.distributed.run ends the surviving rank; every
+    collective carries a 120 s time-out besides), names the failed rank with its message on stderr, and prints no JSON line.
+    No rendezvous port is given: a free one is picked."""
+    import json
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.perf_counter()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch",
+                          "--rehearse-fail", f"{how}:1"], env=env, capture_output=True, text=True, timeout=200)
+    elapsed = time.perf_counter() - t0
+    assert out.returncode != 0 and elapsed < 150, (out.returncode, elapsed)
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], out.stdout
+    report = [json.loads(ln) for ln in out.stderr.splitlines() if ln.startswith('{"bench_launcher"')]
+    assert len(report) == 1 and report[0]["bench_launcher"]["exit_code"] == out.returncode
+    errors = report[0]["bench_launcher"]["rank_errors"]
+    if how == "raise":
+        assert errors[0]["rank"] == 1 and "rank 1 was asked to fail" in errors[0]["error"]
+    else:
+        assert errors == ["no rank left a report (killed by a signal?)"]
 
 
 def test_cif_and_xyz_writers(tmp_path):

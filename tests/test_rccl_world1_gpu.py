@@ -42,6 +42,15 @@ def test_bench_distributed_branch_on_one_gpu(cuda):
     assert line["n_gpus"] == 1 and line["config"]["global_batch"] == line["config"]["batch_per_gpu"] == 1024
     assert line["config"]["gather_ms"] > 0 and line["config"]["collective_backend"] == "nccl"
     assert line["value"] > 0 and line["scaling"] == "weak"
+    # the per-rank record travelled through its own RCCL all-gather: this rank's own timings, its card's sensor readings
+    (mine,) = line["per_rank"]
+    assert mine["rank"] == 0 and line["slowest_rank"] == 0 and mine["ms_per_step"] > 0 and mine["trajectory_ms"] > 0
+    assert abs(mine["ms_per_step"] - line["ms_per_step"]) < 1e-3 * line["ms_per_step"] + 1e-4     # N = 1: MAX over ranks = own
+    assert line["n1_equivalent"]["spread"] == 0.0
+    assert abs(line["n1_equivalent"]["value_per_gpu_fastest_rank"] - line["value"]) < 0.02 * line["value"]
+    for key in ("sclk_mhz_mean", "power_w_mean", "power_cap_w"):      # None only if the box hides the sensor files
+        assert mine[key] is None or mine[key] > 0
+    assert "also_measured" not in line                                # (auto: only the default workload at N = 1)
 
 
 _WORKER = r'''
