@@ -284,17 +284,17 @@ MFMA_F32_PEAK_TFLOPS = 157.3    # dense fp32-input MFMA peak of MI355X (MI355X_M
 
 
 def time_edge_gemm(n_edges, device, hidden=256, launches=10):
-    """The library GEMM that dominates the EGNN workloads (87 % of a C3 step): one hidden layer of the edge MLPs,
-    out[E,256] = SiLU(x[E,256] W^T + b) in fp32 through mdx_linear_act (hipBLASLt, SWISH_BIAS epilogue)."""
+    """`--egnn-precision library`: one hidden layer of the edge MLPs as the per-layer PyTorch path runs it,
+    out[E,256] = SiLU(x[E,256] W^T + b) in fp32 -- torch.nn.functional.linear (torch's ROCm GEMM) + SiLU."""
     x = torch.randn(n_edges, hidden, device=device)
     wgt = torch.randn(hidden, hidden, device=device) / hidden ** 0.5
     bias = torch.zeros(hidden, device=device)
-    ms = time_launches(lambda: kernels.linear_act(x, wgt, bias, True), device, launches)
+    ms = time_launches(lambda: torch.nn.functional.silu(torch.nn.functional.linear(x, wgt, bias)), device, launches)
     tflops = 2.0 * n_edges * hidden * hidden / (ms * 1e-3) / 1e12
     return dict(bound="mfma", achieved=round(tflops, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                 frac=round(tflops / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
-                kernel=f"hipBLASLt fp32 GEMM {n_edges} x {hidden} x {hidden} + bias + SiLU epilogue (library kernel, via "
-                       "mdx_linear_act; 36 of these per network forward)", avg_launch_us=round(ms * 1e3, 2))
+                kernel=f"PyTorch fp32 linear + SiLU {n_edges} x {hidden} x {hidden} (library kernels through torch; 36 of these "
+                       "per network forward)", avg_launch_us=round(ms * 1e3, 2))
 
 
 TRAFFIC_FILE = "traffic_r04.json"      # the latest committed PMC record of the edge chain's HBM traffic
@@ -923,7 +923,7 @@ def main():
                     help="EGNN workloads: arithmetic of the fused per-edge MFMA kernel -- 'f16x3' (the product's default) "
                          "split-f16 three-product form with binary32 accumulation, binary32-level accuracy (error against fp64 "
                          "equal to the f32 paths': tests/test_egnn_chain_gpu.py); 'f32' exact binary32 MFMA; 'library' = "
-                         "per-layer hipBLASLt GEMMs (round-1 path).  The other MFMA mode is timed too and reported beside it.")
+                         "per-layer PyTorch modules (no hand-written chain).  The other MFMA mode is timed too and reported beside it.")
     ap.add_argument("--master-port", type=int, default=None,
                     help="rendezvous port when bench.py starts its own ranks (default: a free port of 127.0.0.1)")
     ap.add_argument("--also-measured", choices=["auto", "yes", "no"], default="auto",

@@ -16,12 +16,13 @@ LIB_PATH = os.path.join(CSRC, "libmdx_hip.so")
 MDX_OK = 0
 MDX_PREDICTOR, MDX_CORRECTOR = 0, 1
 STATUS_CUTOFF_TOO_LARGE, STATUS_MASK_AT_LAST_STEP, STATUS_EGNN_F16_RANGE, STATUS_GRAPH_CAPACITY = 1, 2, 4, 8
+EGNN_COORD_NORMALIZE, EGNN_COORD_TANH = 1, 2      # MDX_EGNN_COORD_* (coord_flags of mdx_egnn_node_gather / _coord_aggregate)
 EGNN_CHAIN_MAX_LAYERS = 16
 MAX_CLASSES = 8
 TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
     TAG_INIT_LATTICE, TAG_RESAMPLE_Z, TAG_RESAMPLE_U = range(11)
 
-ABI_VERSION = 12         # MDX_ABI_VERSION of include/mdx_hip.h
+ABI_VERSION = 13         # MDX_ABI_VERSION of include/mdx_hip.h
 ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
@@ -29,7 +30,7 @@ ABI_SYMBOLS = (
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types", "mdx_noise_relative_coordinates_sigmas", "mdx_noise_atom_types_per_atom",
     "mdx_noise_lattice_parameters",
     "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_radius_graph_fill_capped", "mdx_egnn_radius_graph", "mdx_mlp_forward",
-    "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_variant", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_blas_create", "mdx_blas_destroy", "mdx_linear_act", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
+    "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_variant", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
     "mdx_egnn_chain_image_bytes", "mdx_egnn_chain_pack", "mdx_egnn_chain_adapt_activation_exponents", "mdx_egnn_edge_chain", "mdx_egnn_piece_rows", "mdx_segment_combine", "mdx_egnn_node_gather", "mdx_mlp_chain_rows", "mdx_egnn_coord_aggregate",
     "mdx_egnn_node_inputs", "mdx_egnn_scores", "mdx_egnn_outputs", "mdx_node_mlp_rows", "mdx_node_mlp_rows_split",
     "mdx_rng_fill", "mdx_math_probe",
@@ -87,7 +88,7 @@ class EgnnChain(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("hidden", "n_message_layers", "n_coord_layers", "precision", "message_mode",
                                          "reserved")] + \
         [(n, C.c_void_p) for n in ("weight_image", "biases", "bias_in", "w_radial", "weight_exponents",
-                                   "activation_exponents", "activation_maxima")]
+                                   "activation_exponents", "activation_maxima", "attention_weight", "attention_bias")]
 
 
 def build(force=False):
@@ -181,12 +182,6 @@ def _declare(L):
     L.mdx_mlp_image_floats.argtypes = [C.POINTER(Mlp)]
     L.mdx_mlp_pack_image.restype = i32
     L.mdx_mlp_pack_image.argtypes = [C.POINTER(Mlp), vp, vp]
-    L.mdx_blas_create.restype = i32
-    L.mdx_blas_create.argtypes = [C.POINTER(vp)]
-    L.mdx_blas_destroy.restype = i32
-    L.mdx_blas_destroy.argtypes = [vp]
-    L.mdx_linear_act.restype = i32
-    L.mdx_linear_act.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, u64, vp]
     L.mdx_egnn_message_input.restype = i32
     L.mdx_egnn_message_input.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]
     L.mdx_egnn_coord_head.restype = i32
@@ -212,7 +207,7 @@ def _declare(L):
     L.mdx_segment_combine.restype = i32
     L.mdx_segment_combine.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp, vp]
     L.mdx_egnn_node_gather.restype = i32
-    L.mdx_egnn_node_gather.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp]
+    L.mdx_egnn_node_gather.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, i32, i32, vp, vp]
     L.mdx_egnn_chain_adapt_activation_exponents.restype = i32
     L.mdx_egnn_chain_adapt_activation_exponents.argtypes = [vp, i32, vp, vp]
     L.mdx_egnn_piece_rows.restype = i64
@@ -220,7 +215,7 @@ def _declare(L):
     L.mdx_mlp_chain_rows.restype = i32
     L.mdx_mlp_chain_rows.argtypes = [C.POINTER(EgnnChain), vp, vp, i64, vp, vp, vp, vp]
     L.mdx_egnn_coord_aggregate.restype = i32
-    L.mdx_egnn_coord_aggregate.argtypes = [vp, vp, i32, vp, vp, vp, i64, i32, vp, vp]
+    L.mdx_egnn_coord_aggregate.argtypes = [vp, vp, i32, vp, vp, vp, i64, i32, i32, vp, vp]
     L.mdx_rng_fill.restype = i32
     L.mdx_rng_fill.argtypes = [i32, u64, u32, u32, u32, i64, i32, vp, vp]
     L.mdx_math_probe.restype = i32

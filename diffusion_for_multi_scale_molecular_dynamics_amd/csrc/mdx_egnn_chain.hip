@@ -5,7 +5,10 @@
 //     y  = SiLU(y V_l^T + c_l),  l = 1 .. n_coord, y_0 = m                          E_GCL.coord_model    (models/egnn.py:162-200)
 //     s_e = y . w_out                                                               last layer Linear(H, 1, bias=False)
 //
-// in ONE launch: the [edges, H] activations never leave the register file between layers.
+// in ONE launch: the [edges, H] activations never leave the register file between layers.  With the layer's `attention` option
+// (models/egnn.py:148-160: m_e <- m_e sigmoid(m_e . w_att + b_att)) the gate is applied where the messages are complete --
+// between the last message layer and the first coordinate layer, on the operand registers -- so both the message sums and the
+// coordinate MLP see the gated messages (instantiations ATT = true; the others are compiled without a trace of it).
 //
 // Mapping (gfx950, 64-wide wavefronts, one wavefront per SIMD, 512 VGPRs):
 //   * a workgroup = 4 wavefronts = a tile of 128 consecutive edges; each wavefront owns 32 edges (columns).
@@ -87,6 +90,8 @@ struct ChainArgs {
     int64_t ld_in;              // row stride of rows_in and residual, in floats
     const float* rows_in2;      // MODE 3: the second H columns (agg) as rows of their own, row stride ld_in2
     int64_t ld_in2;
+    const float* att_w;         // ATT instantiations: [H] weight of E_GCL.att_mlp's Linear(H, 1); att_b: [1] its bias
+    const float* att_b;
     float* proj_out;            // MODE 3, nullable: [M][2H] = out W_p^T for the 2 H x H layers that follow the MLP in the image
     float* rows_out;            // [M][H]
     void* stamp_buf;            // -DMDX_CHAIN_STAMPS builds only (else null): see MDX_STAMP_WRITE
@@ -668,9 +673,10 @@ __device__ __forceinline__ f32x16 unpark(const Act<H, 1>& a, int t)
 
 // MODE 0: the EGNN edge chain (gathered first layer, messages + head out); MODE 2: the same with the messages added up per
 // node inside the kernel (piece sums out).  MODE 1: the same pipeline over the rows of a matrix -- out = residual + W_L (SiLU(W_{L-1} ... SiLU(W_1 x + b_1) ...)) + b_L -- used for the per-node MLP of an EGNN layer.
-template <int H, int PREC, int MODE>
+template <int H, int PREC, int MODE, bool ATT = false>
 __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(ChainArgs p)
 {
+    static_assert(!ATT || MODE == 0 || MODE == 2, "the attention gate belongs to the edge chain");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     // (GUARD: see issue_piece.  The production-size piece-sums instantiations <256, PREC, 2> skip the three extra wait states
     // in front of their requests -- 2.2 % of the launch, A/B in profiles/r03_chain_ablation.md -- which is safe only while they
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
 #ifdef MDX_CHAIN_GUARD_ALL
     using C = Chain<H, PREC, true>;
 #else
-    using C = Chain<H, PREC, !(MODE == 2 && H == 256)>;
+    using C = Chain<H, PREC, ATT || !(MODE == 2 && H == 256)>;      // (ATT: always guarded -- those instantiations may spill)
 #endif
     // MODE 3 = MODE 1 whose first layer is 2 H -> H: the rows are [h | agg]; chain "layers" 0 and 1 are the two H x H halves of
     // that layer's weight.  Pass A multiplies h by the first half and PARKS the raw accumulators (bias included) in the
@@ -710,6 +716,10 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     // exact-f32 kernels: the workgroup's maxima of |u| per position (ChainArgs::act_max), behind the source ids
     uint32_t* max_table = (uint32_t*)(lds_raw + kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H + 4 * kScaleSlots) +
                                       sizeof(int) * kWaves * 32);
+    // ATT: w_att ln 2 2^-c (c = the exponent the messages are carried with: the gate's logit straight from the carried values)
+    // and, behind it, b_att; 16-byte aligned, behind everything else
+    lds_f* par_att = (lds_f*)(lds_raw + ((kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H + 4 * kScaleSlots) +
+                                          sizeof(int) * kWaves * 32 + sizeof(uint32_t) * kMaxPositions + 15) & ~(size_t)15));
     constexpr int ACT = kActExp<PREC>;
     // the exponent of the activations carried at position q (see kActExp): the caller's, else ACT; exact-f32 kernels: 0
     auto act_exp = [&](int q) -> int {
@@ -779,6 +789,11 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
     }
     if constexpr (PREC == 0) {
         if (threadIdx.x < kMaxPositions) max_table[threadIdx.x] = 0u;
+    }
+    if constexpr (ATT) {
+        const float to_message = kLn2 * pow2_bits(-act_exp(p.n_message));
+        for (int i = threadIdx.x; i < H; i += kWaves * kWave) par_att[i] = p.att_w[i] * to_message;
+        if (threadIdx.x == 0) par_att[H] = p.att_b[0];
     }
     __syncthreads();
 
@@ -1028,6 +1043,11 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         auto run_tile = [&](const Act<H, PREC>& in, bool have, int tp, Act<H, PREC>& epi_dst, const lds_f* next_bias,
                             const Scale& epi_sc, bool linear = false) -> f32x16 {
             MDX_STAMP(4);
+            // ATT: the request addresses in scalar registers again at the top of EVERY tile (two v_readfirstlane).  The branch
+            // around the gate adds control-flow merges to the layer loop, and a value that reaches a request through such a
+            // merge is handed over in vector registers (see scalar_addresses); this way every request of a tile takes its
+            // addresses from a statement of the same straight-line stretch -- this one, or the acquire in the tile's middle.
+            if constexpr (ATT && C::SPREAD) ch.scalar_addresses();
             f32x16 acc = acc_next;
             constexpr bool STAGED = SPLIT && STEPS == 16;
             EpiloguePipe<H> pipe;
@@ -1118,6 +1138,47 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 }
             }
             sc_prev = sc;
+        };
+        // ATT.  The messages must be gated BEFORE the first coordinate layer reads them, so the pipelining across that one
+        // layer boundary is given up: the last message tile's epilogue is run at once (not beside the next layer's first
+        // tile), then per edge  a = m . w_att + b_att  (this lane's features, then the other lanes of the edge: 32x32 shapes
+        // lane ^ 32; 16x16 shape lanes ^ 16 and ^ 32),  g = 1 / (1 + e^-a),  and every carried value of the edge is multiplied
+        // by g and written back into the operand registers (split-f16: split again).  The first coordinate layer then starts
+        // like the chain's first layer (nothing outstanding).  H / 2 fused multiply-adds and as many products per lane: noise
+        // beside the layer's 2 H^2 MACs per edge.
+        auto gate_messages = [&](Act<H, PREC>& m, int l) {
+            if constexpr (!ATT) return;
+            epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, m, sc_prev, false, amax);
+            flush_max(l);
+            float part[NS];
+#pragma unroll
+            for (int es = 0; es < NS; ++es) part[es] = 0.0f;
+#pragma unroll
+            for (int q8 = 0; q8 < H / 8; ++q8) {
+                const int t = q8 >> 2, q = q8 & 3;
+                const f32x4 y = get4<H>(m, t, q);
+                const f32x4 w4 = *(const __attribute__((address_space(3))) f32x4*)(par_att + 32 * t + L::fb(q, h));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) part[L::es(q)] = __builtin_fmaf(y[i], w4[i], part[L::es(q)]);
+            }
+            float g[NS];
+#pragma unroll
+            for (int es = 0; es < NS; ++es) {
+                float a = part[es];
+                if constexpr (W16) a += __shfl_xor(a, 16);
+                a += __shfl_xor(a, 32);
+                a += par_att[H];
+                g[es] = 1.0f / (1.0f + expf(-a));
+            }
+#pragma unroll
+            for (int q8 = 0; q8 < H / 8; ++q8) {
+                const int t = q8 >> 2, q = q8 & 3;
+                const f32x4 y = get4<H>(m, t, q);
+                const float gg = g[L::es(q)];
+                put_pair<H>(m, t, 4 * q, y[0] * gg, y[1] * gg);
+                put_pair<H>(m, t, 4 * q + 2, y[2] * gg, y[3] * gg);
+                if ((q8 & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+            }
         };
         // messages = the operand registers of the first coordinate layer, complete once its first tile has run
         auto store_messages = [&](const Act<H, PREC>& m) {
@@ -1333,8 +1394,21 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
             }
         }
         if (!done) {
+            // layer l from `in` to `out`; ATT: the first coordinate layer starts behind the gate, with nothing outstanding
+            auto step_layer = [&](Act<H, PREC>& in, Act<H, PREC>& out, int l) {
+                if constexpr (ATT) {
+                    if (l == p.n_message) {
+                        gate_messages(in, l);
+                        layer(std::true_type{}, in, out, l);
+                    } else {
+                        layer(std::false_type{}, in, out, l);
+                    }
+                } else {
+                    layer(std::false_type{}, in, out, l);
+                }
+            };
             for (int l = l_first;;) {
-                layer(std::false_type{}, xb, xa, l);
+                step_layer(xb, xa, l);
                 if (!ROWS && l == p.n_message) {
                     if constexpr (MODE == 2) {
                         MDX_STAMP_ALWAYS(30);
@@ -1350,7 +1424,7 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                     else finish_rows(xa, xb);
                     break;
                 }
-                layer(std::false_type{}, xa, xb, l);
+                step_layer(xa, xb, l);
                 if (!ROWS && l == p.n_message) {
                     if constexpr (MODE == 2) {
                         MDX_STAMP_ALWAYS(30);
@@ -1495,12 +1569,21 @@ __global__ __launch_bounds__(256) void egnn_chain_pack_kernel(PackArgs p)
     }
 }
 
+// The two per-edge options of E_GCL's coordinate update (models/egnn.py:128-131, 234-264), applied where the head's scalar meets
+// the coordinate difference:
+//   MDX_EGNN_COORD_TANH       the coordinate MLP ends in nn.Tanh: s_e <- tanh(s_e)
+//   MDX_EGNN_COORD_NORMALIZE  coord_diff <- f(r^2) coord_diff, f(r^2) = tanh(r^2) / sqrt(r^2 + epsilon^2), epsilon = 1e-8, r^2 the
+//                             squared length of coord_diff summed in component order (normalize_radial_norm)
+// trans = (f coord_diff) s, in the reference's order of operations.
+__device__ __forceinline__ float coord_head_value(float s, int flags) { return (flags & MDX_EGNN_COORD_TANH) ? tanhf(s) : s; }
+__device__ __forceinline__ float normalize_factor(float r2) { return tanhf(r2) / sqrtf(r2 + 1.0e-16f); }
+
 // coord_out[i,:] = coord[i,:] + scale_i sum_{e in segment i} (coord[i,:] - coord[dst_e,:]) * s_e
 __global__ __launch_bounds__(256) void egnn_coord_aggregate_kernel(const float* __restrict__ s, const float* __restrict__ coord,
                                                                    const int64_t* __restrict__ edges,
                                                                    const int64_t* __restrict__ offsets,
                                                                    const int64_t* __restrict__ degree, int64_t n_nodes, int D,
-                                                                   int mean, float* __restrict__ out)
+                                                                   int mean, int flags, float* __restrict__ out)
 {
     const int64_t total = n_nodes * D;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -1509,7 +1592,19 @@ __global__ __launch_bounds__(256) void egnn_coord_aggregate_kernel(const float* 
         const int64_t e0 = offsets[node], deg = degree[node];
         const float ci = coord[idx];
         float acc = 0.0f;
-        for (int64_t e = e0; e < e0 + deg; ++e) acc += (ci - coord[edges[2 * e + 1] * D + k]) * s[e];
+        for (int64_t e = e0; e < e0 + deg; ++e) {
+            const int64_t dst = edges[2 * e + 1];
+            float diff = ci - coord[dst * D + k];
+            if (flags & MDX_EGNN_COORD_NORMALIZE) {
+                float r2 = 0.0f;
+                for (int j = 0; j < D; ++j) {
+                    const float dj = coord[node * D + j] - coord[dst * D + j];
+                    r2 += dj * dj;
+                }
+                diff = normalize_factor(r2) * diff;
+            }
+            acc += diff * coord_head_value(s[e], flags);
+        }
         if (mean && deg > 0) acc *= 1.0f / (float)deg;
         out[idx] = ci + acc;
     }
@@ -1558,7 +1653,7 @@ __global__ __launch_bounds__(256) void egnn_node_gather_kernel(const float* __re
                                                                const float* __restrict__ left, int64_t boundary_rows,
                                                                const float* __restrict__ s, const float* __restrict__ coord,
                                                                const int64_t* __restrict__ edges, int D, int mean_coords,
-                                                               float* __restrict__ coord_out)
+                                                               int flags, float* __restrict__ coord_out)
 {
     const int lane = threadIdx.x % kWave;
     const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / kWave;
@@ -1572,10 +1667,23 @@ __global__ __launch_bounds__(256) void egnn_node_gather_kernel(const float* __re
         for (int k = 0; k < 8; ++k) ci[k] = k < D ? coord[node * D + k] : 0.0f;
         for (int64_t e = e0 + lane; e < e1; e += kWave) {
             const int64_t dst = edges[2 * e + 1];
-            const float se = s[e];
+            const float se = coord_head_value(s[e], flags);
+            if (flags & MDX_EGNN_COORD_NORMALIZE) {          // (uniform per launch)
+                float diff[8], r2 = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k < D) part[k] += (ci[k] - coord[dst * D + k]) * se;
+                for (int k = 0; k < 8; ++k) {
+                    diff[k] = k < D ? ci[k] - coord[dst * D + k] : 0.0f;
+                    if (k < D) r2 += diff[k] * diff[k];
+                }
+                const float f = normalize_factor(r2);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < D) part[k] += (f * diff[k]) * se;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < D) part[k] += (ci[k] - coord[dst * D + k]) * se;
+            }
         }
         // messages
         const float scale = (mean_messages && deg > 0) ? 1.0f / (float)deg : 1.0f;
@@ -1619,19 +1727,20 @@ __global__ __launch_bounds__(256) void egnn_node_gather_kernel(const float* __re
     }
 }
 
-template <int H, int PREC, int MODE>
+template <int H, int PREC, int MODE, bool ATT = false>
 int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
 {
     using C = Chain<H, PREC>;
     // ring | biases + first-layer vectors | per-wavefront source ids of the in-kernel aggregation
     // ring | biases + first-layer vectors + scale table | per-wavefront source ids of the in-kernel aggregation | maxima table
-    const size_t lds = (size_t)kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H + 4 * kScaleSlots) +
-                       sizeof(int) * kWaves * 32 + sizeof(uint32_t) * kMaxPositions;
+    size_t lds = (size_t)kRing * C::CHUNK + sizeof(float) * ((size_t)layers * H + 2 * H + 4 * kScaleSlots) +
+                 sizeof(int) * kWaves * 32 + sizeof(uint32_t) * kMaxPositions;
+    if (ATT) lds = ((lds + 15) & ~(size_t)15) + sizeof(float) * (H + 4);       // the gate's weight row and bias (par_att)
     static bool granted[64] = {};       // (one flag per instantiation: function-local static of a template)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MDX_ERR_HIP;
     if (lds > 64 * 1024 && !granted[dev]) {
-        if (hipFuncSetAttribute((const void*)egnn_edge_chain_kernel<H, PREC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)egnn_edge_chain_kernel<H, PREC, MODE, ATT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return MDX_ERR_HIP;
         granted[dev] = true;
@@ -1641,12 +1750,13 @@ int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);       // persistent: one workgroup per CU
-    hipLaunchKernelGGL((egnn_edge_chain_kernel<H, PREC, MODE>), dim3(grid), dim3(kWaves * kWave), lds, st, a);
+    hipLaunchKernelGGL((egnn_edge_chain_kernel<H, PREC, MODE, ATT>), dim3(grid), dim3(kWaves * kWave), lds, st, a);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 
 }  // namespace
 
+#ifndef MDX_CHAIN_NO_ENTRY_POINTS      // (a probe unit includes this file for single instantiations: tools/)
 extern "C" {
 
 int64_t mdx_egnn_chain_image_bytes(int hidden, int n_layers)
@@ -1707,6 +1817,8 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
     a.n_edges = n_edges; a.n_message = c->n_message_layers; a.n_coord = c->n_coord_layers; a.D = coord_dimension;
     a.messages = messages_out; a.edge_scalar = edge_scalar_out; a.status = status;
     a.piece_sums = c->message_mode == MDX_EGNN_MESSAGES_PIECE_SUMS;
+    if ((c->attention_weight == nullptr) != (c->attention_bias == nullptr)) return MDX_ERR_INVALID_ARG;
+    a.att_w = c->attention_weight; a.att_b = c->attention_bias;
 #ifdef MDX_CHAIN_STAMPS
     // (diagnostic builds: `status` is the caller's stamp list, uint64 [4096]; its entry count restarts with every launch)
     if (status && hipMemsetAsync((char*)status + 4095 * 8, 0, 8, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return MDX_ERR_HIP;
@@ -1715,10 +1827,11 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
 #endif
     const int layers = a.n_message + a.n_coord;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define MDX_CHAIN_MODE(HH, MM, AA) (c->precision == 0 ? launch_chain<HH, 0, MM, AA>(a, layers, st) : (c->precision == 1 ? launch_chain<HH, 1, MM, AA>(a, layers, st) : launch_chain<HH, 2, MM, AA>(a, layers, st)))
 #define MDX_CHAIN_CASE(HH)                                                                                            \
     case HH:                                                                                                          \
-        if (a.piece_sums) return c->precision == 0 ? launch_chain<HH, 0, 2>(a, layers, st) : (c->precision == 1 ? launch_chain<HH, 1, 2>(a, layers, st) : launch_chain<HH, 2, 2>(a, layers, st)); \
-        return c->precision == 0 ? launch_chain<HH, 0, 0>(a, layers, st) : (c->precision == 1 ? launch_chain<HH, 1, 0>(a, layers, st) : launch_chain<HH, 2, 0>(a, layers, st));
+        if (a.att_w) return a.piece_sums ? MDX_CHAIN_MODE(HH, 2, true) : MDX_CHAIN_MODE(HH, 0, true);                 \
+        return a.piece_sums ? MDX_CHAIN_MODE(HH, 2, false) : MDX_CHAIN_MODE(HH, 0, false);
     switch (c->hidden) {
         MDX_CHAIN_CASE(32)
         MDX_CHAIN_CASE(64)
@@ -1726,6 +1839,7 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
         MDX_CHAIN_CASE(256)
     }
 #undef MDX_CHAIN_CASE
+#undef MDX_CHAIN_MODE
     return MDX_ERR_UNSUPPORTED;
 }
 
@@ -1759,9 +1873,11 @@ int mdx_segment_combine(const float* pieces, int64_t n_edges, const int64_t* off
 
 int mdx_egnn_node_gather(const float* pieces, int64_t n_edges, const int64_t* offsets, const int64_t* degree, int64_t n_nodes,
                          int H, int mean_messages, const float* left, float* out, const float* edge_scalar, const float* coord,
-                         int coord_dimension, const int64_t* edges, int mean_coords, float* coord_out, mdx_stream_t stream)
+                         int coord_dimension, const int64_t* edges, int mean_coords, int coord_flags, float* coord_out,
+                         mdx_stream_t stream)
 {
     if (n_nodes < 0 || H < 4 || n_edges < 0 || coord_dimension < 1) return MDX_ERR_INVALID_ARG;
+    if (coord_flags & ~(MDX_EGNN_COORD_NORMALIZE | MDX_EGNN_COORD_TANH)) return MDX_ERR_INVALID_ARG;
     if ((H & 3) || coord_dimension > 8) return MDX_ERR_UNSUPPORTED;
     if (n_nodes == 0) return MDX_OK;
     if (!pieces || !offsets || !degree || !out || !edge_scalar || !coord || !edges || !coord_out) return MDX_ERR_INVALID_ARG;
@@ -1769,7 +1885,7 @@ int mdx_egnn_node_gather(const float* pieces, int64_t n_edges, const int64_t* of
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(egnn_node_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        pieces, offsets, degree, n_nodes, H, mean_messages, out, left, (n_edges + 15) >> 4, edge_scalar, coord, edges,
-                       coord_dimension, mean_coords, coord_out);
+                       coord_dimension, mean_coords, coord_flags, coord_out);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 
@@ -1854,17 +1970,19 @@ static int node_mlp_rows(const mdx_egnn_chain_t* c, const float* node_in, int64_
 }
 
 int mdx_egnn_coord_aggregate(const float* edge_scalar, const float* coord, int coord_dimension, const int64_t* edges,
-                             const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int mean, float* coord_out,
-                             mdx_stream_t stream)
+                             const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int mean, int coord_flags,
+                             float* coord_out, mdx_stream_t stream)
 {
     if (n_nodes < 0 || coord_dimension < 1) return MDX_ERR_INVALID_ARG;
+    if (coord_flags & ~(MDX_EGNN_COORD_NORMALIZE | MDX_EGNN_COORD_TANH)) return MDX_ERR_INVALID_ARG;
     if (n_nodes == 0) return MDX_OK;
     if (!edge_scalar || !coord || !edges || !offsets || !degree || !coord_out) return MDX_ERR_INVALID_ARG;
     int64_t blocks = (n_nodes * coord_dimension + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(egnn_coord_aggregate_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       edge_scalar, coord, edges, offsets, degree, n_nodes, coord_dimension, mean, coord_out);
+                       edge_scalar, coord, edges, offsets, degree, n_nodes, coord_dimension, mean, coord_flags, coord_out);
     return hipGetLastError() == hipSuccess ? MDX_OK : MDX_ERR_HIP;
 }
 
 }  // extern "C"
+#endif

@@ -705,11 +705,9 @@ class IterationLoop:
             gen._clear_stale_range_report()      # (the warm-up ran the split-f16 network from an arbitrary state)
             self.graph = torch.cuda.CUDAGraph()
             # Objects whose finaliser calls HIP must not be collected while the stream is capturing: an older loop's
-            # torch.cuda.CUDAGraph (hipGraphExecDestroy) and kernels.BlasContext (hipblasLtDestroy).  The first kind is
-            # released deterministically: the previous loop of this generator is dropped here, loops of other generators
-            # die with their generator (no reference cycle: see __init__), and the collector runs right before the capture
-            # and not during it; the second lives for the whole process in BlasContext._by_device and refuses to destroy
-            # its handle during a capture.
+            # torch.cuda.CUDAGraph (hipGraphExecDestroy).  It is released deterministically: the previous loop of this
+            # generator is dropped here, loops of other generators die with their generator (no reference cycle: see
+            # __init__), and the collector runs right before the capture and not during it.
             previous = gen._buffers.pop("graph_loop", None)
             if previous is not None:
                 previous.graph = None

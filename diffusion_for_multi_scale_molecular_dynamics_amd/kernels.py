@@ -571,66 +571,8 @@ def mlp_pc_sample(sched: DeviceSchedule, pack: MlpPack, flags: PcFlags, number_o
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# EGNN helpers: library GEMM with fused bias(+SiLU) epilogue, fused first message layer
+# EGNN helpers around the MFMA kernels: fused first message layer, sorted-segment reductions
 # ----------------------------------------------------------------------------------------------------------------
-class BlasContext:
-    """A hipBLASLt context (mdx_blas_t) + its workspace, one per device; owned here, destroyed with the object."""
-
-    WORKSPACE_BYTES = 64 << 20
-    _by_device = {}
-
-    def __init__(self, device):
-        handle = C.c_void_p()
-        check(lib().mdx_blas_create(C.byref(handle)), "mdx_blas_create")
-        self.handle = handle
-        self.workspace = torch.empty(self.WORKSPACE_BYTES, dtype=torch.uint8, device=device)
-        self.silu_epilogue_ok = True      # cleared the first time the library reports no SWISH_BIAS kernel
-
-    def close(self):
-        """Release the hipBLASLt handle now (deterministically; mdx_blas_destroy calls into HIP, which is not allowed
-        while a stream of this thread is capturing)."""
-        if self.handle is not None:
-            handle, self.handle = self.handle, None
-            lib().mdx_blas_destroy(handle)
-
-    def __del__(self):
-        # This is the one object of the package whose finaliser calls HIP.  Instances live in _by_device for the life of the
-        # process, so the collector never sees one during a capture; should that ever change, leak the handle rather than
-        # abort the capture.
-        try:
-            if not torch.cuda.is_current_stream_capturing():
-                self.close()
-        except Exception:
-            pass
-
-    @classmethod
-    def close_all(cls):
-        for ctx in cls._by_device.values():
-            ctx.close()
-        cls._by_device.clear()
-
-    @classmethod
-    def get(cls, device):
-        device = torch.device(device)
-        if device not in cls._by_device:
-            with torch.cuda.device(device):
-                cls._by_device[device] = cls(device)
-        return cls._by_device[device]
-
-
-def linear_act(x: torch.Tensor, weight: torch.Tensor, bias, silu: bool) -> torch.Tensor:
-    """act(x @ weight.T + bias) as one hipBLASLt matmul with the BIAS / SWISH_BIAS epilogue (mdx_linear_act)."""
-    ctx = BlasContext.get(x.device)
-    M, K = x.shape
-    N = weight.shape[0]
-    out = torch.empty(M, N, dtype=F32, device=x.device)
-    rc = lib().mdx_linear_act(ctx.handle, ptr(x, F32, "x"), ptr(weight, F32, "weight"), ptr(bias, F32, "bias"),
-                              ptr(out, F32, "out"), M, K, N, int(bool(silu)), C.c_void_p(ctx.workspace.data_ptr()),
-                              ctx.workspace.numel(), stream_handle())
-    check(rc, "mdx_linear_act")
-    return out
-
-
 def egnn_message_input(node_proj, edges, radial, bias, w_radial, silu: bool = True) -> torch.Tensor:
     """First message layer on an edge list: SiLU(P[src,:H] + P[dst,H:] + b + r w_r)  (mdx_egnn_message_input)."""
     E = edges.shape[0]
@@ -738,7 +680,8 @@ class EdgeChainPack:
     scales (ActivationScales, optional): shared with the layer's packs of the other precisions."""
 
     def __init__(self, first_message_layer, message_layers, coord_layers, coord_out_layer, input_size: int, precision: str,
-                 scales=None):
+                 scales=None, attention_layer=None):
+        """attention_layer: E_GCL.att_mlp's nn.Linear(H, 1) (its Sigmoid is the kernel's), or None."""
         H = first_message_layer.out_features
         dev = first_message_layer.weight.device
         layers = list(message_layers) + list(coord_layers)
@@ -757,12 +700,22 @@ class EdgeChainPack:
         self.scales = scales
         act = scales.pointers(precision) if scales is not None else (None, None)
         assert scales is None or scales.count == len(layers) + 2
+        self.att_w = self.att_b = None
+        if attention_layer is not None:
+            if attention_layer.in_features != H or attention_layer.out_features != 1 or attention_layer.bias is None:
+                raise _hip.MdxError("the attention gate of the fused edge chain is nn.Linear(H, 1) with a bias")
+            self.att_w = attention_layer.weight.detach().to(F32).reshape(-1).contiguous()
+            self.att_b = attention_layer.bias.detach().to(F32).reshape(-1).contiguous()
         self.c_struct = _hip.EgnnChain(H, len(list(message_layers)), len(list(coord_layers)),
                                        EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
                                        self.biases.data_ptr(), self.bias_in.data_ptr(), self.w_radial.data_ptr(),
-                                       self.exponents.data_ptr(), *act)
+                                       self.exponents.data_ptr(), *act,
+                                       None if self.att_w is None else self.att_w.data_ptr(),
+                                       None if self.att_b is None else self.att_b.data_ptr())
         # the kernel's LDS: weight ring + small vectors + per-layer scale table + the source ids of the in-kernel aggregation
-        lds = 4 * 32 * H * 4 + 4 * (len(layers) * H + 2 * H) + 16 * (_hip.EGNN_CHAIN_MAX_LAYERS + 4) + 4 * 4 * 32 + 4 * (_hip.EGNN_CHAIN_MAX_LAYERS + 2)
+        # (+ the attention gate's weight row)
+        lds = 4 * 32 * H * 4 + 4 * (len(layers) * H + 2 * H) + 16 * (_hip.EGNN_CHAIN_MAX_LAYERS + 4) + 4 * 4 * 32 + 4 * (_hip.EGNN_CHAIN_MAX_LAYERS + 2) + \
+            (16 + 4 * (H + 4) if self.att_w is not None else 0)
         self.piece_sums_ok = lds <= 160 * 1024
         self.device = dev
 
@@ -796,7 +749,7 @@ class RowChainPack:
         act = scales.pointers(precision) if scales is not None else (None, None)
         assert scales is None or scales.count == len(layers) + 2
         self.c_struct = _hip.EgnnChain(H, len(layers), 0, EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
-                                       self.biases.data_ptr(), None, None, self.exponents.data_ptr(), *act)
+                                       self.biases.data_ptr(), None, None, self.exponents.data_ptr(), *act, None, None)
 
     @staticmethod
     def supported(layers) -> bool:
@@ -925,8 +878,13 @@ def segment_combine(pieces, n_edges: int, offsets, degree, mean: bool, left=None
     return out
 
 
+def coord_flags(normalize: bool, tanh: bool) -> int:
+    """MDX_EGNN_COORD_* bits of an E_GCL layer's coordinate update (models/egnn.py: `normalize`, `tanh`)."""
+    return (_hip.EGNN_COORD_NORMALIZE if normalize else 0) | (_hip.EGNN_COORD_TANH if tanh else 0)
+
+
 def egnn_node_gather(pieces, n_edges: int, offsets, degree, mean_messages: bool, left, edge_scalar, coord, edges,
-                     mean_coords: bool):
+                     mean_coords: bool, flags: int = 0):
     """segment_combine(..., left=left) and egnn_coord_aggregate(...) in one launch (mdx_egnn_node_gather):
     ([left | message sums] [n_nodes, 2H] (or the sums [n_nodes, H] when left is None), coord_out [n_nodes, D])."""
     n_nodes, H = degree.shape[0], pieces.shape[1]
@@ -937,8 +895,8 @@ def egnn_node_gather(pieces, n_edges: int, offsets, degree, mean_messages: bool,
     rc = lib().mdx_egnn_node_gather(ptr(pieces, F32, "pieces"), n_edges, ptr(offsets, I64, "offsets"), ptr(degree, I64, "degree"),
                                     n_nodes, H, int(bool(mean_messages)), ptr(left, F32, "left"), ptr(out, F32, "out"),
                                     ptr(edge_scalar, F32, "edge_scalar"), ptr(coord, F32, "coord"), coord.shape[1],
-                                    ptr(edges, I64, "edges"), int(bool(mean_coords)), ptr(coord_out, F32, "coord_out"),
-                                    stream_handle())
+                                    ptr(edges, I64, "edges"), int(bool(mean_coords)), int(flags),
+                                    ptr(coord_out, F32, "coord_out"), stream_handle())
     check(rc, "mdx_egnn_node_gather")
     return out, coord_out
 
@@ -992,12 +950,13 @@ def egnn_outputs(z, x_hat, k_vectors, h, class_weight, class_bias, mask_class: i
     return scores, logits, zeros
 
 
-def egnn_coord_aggregate(edge_scalar, coord, edges, offsets, degree, mean: bool) -> torch.Tensor:
-    """coord + segment sum/mean of (coord_i - coord_dst) * edge_scalar over each node's sorted edges."""
+def egnn_coord_aggregate(edge_scalar, coord, edges, offsets, degree, mean: bool, flags: int = 0) -> torch.Tensor:
+    """coord + segment sum/mean of (coord_i - coord_dst) * edge_scalar over each node's sorted edges (flags: coord_flags())."""
     out = torch.empty_like(coord)
     rc = lib().mdx_egnn_coord_aggregate(ptr(edge_scalar, F32, "edge_scalar"), ptr(coord, F32, "coord"), coord.shape[1],
                                         ptr(edges, I64, "edges"), ptr(offsets, I64, "offsets"), ptr(degree, I64, "degree"),
-                                        coord.shape[0], int(bool(mean)), ptr(out, F32, "coord_out"), stream_handle())
+                                        coord.shape[0], int(bool(mean)), int(flags), ptr(out, F32, "coord_out"),
+                                        stream_handle())
     check(rc, "mdx_egnn_coord_aggregate")
     return out
 

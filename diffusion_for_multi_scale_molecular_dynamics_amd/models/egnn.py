@@ -11,10 +11,11 @@ get_edges_batch produce):
     (kernels.segment_rows for the messages; kernels.egnn_coord_head = last coordinate layer H -> 1, product with
     coord_diff and segment mean in one pass over the [E, H] activations);
   * on device tensors, without autograd, the whole per-edge part of a layer -- first message layer, the message MLP,
-    the coordinate MLP and its H -> 1 head -- is ONE hand-written MFMA kernel (kernels.egnn_edge_chain,
-    csrc/mdx_egnn_chain.hip) that keeps the [E, H] activations in registers between layers; `edge_chain_precision`
-    selects exact binary32 MFMA ("f32") or the split-f16 three-product form ("f16x3"); None keeps the per-layer
-    library-GEMM path (also taken for shapes the kernel does not cover: attention, tanh, normalize, unequal widths).
+    the attention gate, the coordinate MLP and its H -> 1 head -- is ONE hand-written MFMA kernel (kernels.egnn_edge_chain,
+    csrc/mdx_egnn_chain.hip) that keeps the [E, H] activations in registers between layers; `tanh` and `normalize` act in
+    the per-node kernel that adds the coordinate updates up; `edge_chain_precision` selects exact binary32 MFMA ("f32") or
+    the split-f16 three-product form ("f16x3"); None keeps the per-layer PyTorch path (also taken for shapes the kernel does
+    not cover: widths outside {32, 64, 128, 256}, message and coordinate MLPs of different width, other activations).
 
 The HIP calls are invisible to autograd, so they are used only when no gradient can be requested (torch.no_grad(), or
 nothing requires grad); with autograd on, the module runs as plain PyTorch.  Callers that pass their own edge list
@@ -29,26 +30,12 @@ from torch import nn
 from ..namespace import AXL
 
 
-def run_mlp(layers, x: torch.Tensor, fused: bool) -> torch.Tensor:
-    """Apply a Sequential of Linear / SiLU / ... modules.  With `fused` (device tensors) every Linear, together with a
-    SiLU that follows it, is ONE library matmul with a bias(+SiLU) epilogue (kernels.linear_act) instead of a matmul
-    plus a read+write pass over the activations."""
-    layers = list(layers)
-    if not fused:
-        for layer in layers:
-            x = layer(x)
-        return x
-    from .. import kernels
-    k = 0
-    while k < len(layers):
-        layer = layers[k]
-        if isinstance(layer, nn.Linear) and layer.out_features > 1:
-            with_silu = k + 1 < len(layers) and isinstance(layers[k + 1], nn.SiLU)
-            x = kernels.linear_act(x.contiguous(), layer.weight, layer.bias, with_silu)
-            k += 2 if with_silu else 1
-        else:
-            x = layer(x)
-            k += 1
+def run_mlp(layers, x: torch.Tensor, fused: bool = False) -> torch.Tensor:
+    """Apply a Sequential of Linear / SiLU / ... modules as plain PyTorch ops (layer shapes the MFMA chains do not cover).
+    (`fused` is accepted for the callers' sake and ignored: rounds 1-4 ran every Linear + SiLU pair of this path as one
+    hipBLASLt matmul with a SWISH_BIAS epilogue; the library no longer links a vendor GEMM.)"""
+    for layer in layers:
+        x = layer(x)
     return x
 
 
@@ -173,10 +160,16 @@ class E_GCL(nn.Module):
 
     def _chain_modules(self):
         """(first message layer, message H->H layers, coordinate H->H layers, coordinate head) if the per-edge MLPs have
-        the Linear / SiLU alternation the fused kernel implements, else None."""
-        if self.attention or self.normalize or self.tanh:
-            return None
+        the Linear / SiLU alternation the fused kernel implements, else None.  The layer's options ride along: `tanh` is the
+        nn.Tanh behind the head (applied where the head's scalar is consumed), `normalize` a per-edge factor there too,
+        `attention` the gate inside the kernel (_attention_layer)."""
         message, coordinate = list(self.message_mlp), list(self.coord_mlp)
+        if self.tanh:
+            if not coordinate or not isinstance(coordinate[-1], nn.Tanh):
+                return None
+            coordinate = coordinate[:-1]
+        if self.attention and self._attention_layer() is None:
+            return None
         if len(message) % 2 or len(coordinate) % 2 == 0:
             return None
         pairs = list(zip(message[0::2], message[1::2])) + list(zip(coordinate[0:-1:2], coordinate[1:-1:2]))
@@ -185,6 +178,18 @@ class E_GCL(nn.Module):
         if not isinstance(coordinate[-1], nn.Linear):
             return None
         return message[0], message[2::2], coordinate[0:-1:2], coordinate[-1]
+
+    def _attention_layer(self):
+        """att_mlp's nn.Linear(H, 1) when the gate has the reference's form Linear + Sigmoid, else None."""
+        att = list(getattr(self, "att_mlp", []))
+        if len(att) == 2 and isinstance(att[0], nn.Linear) and isinstance(att[1], nn.Sigmoid) and att[0].out_features == 1 \
+                and att[0].bias is not None:
+            return att[0]
+        return None
+
+    def _coord_flags(self) -> int:
+        from .. import kernels
+        return kernels.coord_flags(self.normalize, self.tanh)
 
     def _edge_chain_pack(self):
         """The layer's kernels.EdgeChainPack, rebuilt when a parameter, the device or the precision changed; None when
@@ -197,7 +202,10 @@ class E_GCL(nn.Module):
         from .. import kernels
         if not kernels.EdgeChainPack.supported(*modules):
             return None
-        linears = [modules[0], *modules[1], *modules[2], modules[3]]
+        attention = self._attention_layer() if self.attention else None
+        if attention is not None and attention.in_features != modules[0].out_features:
+            return None
+        linears = [modules[0], *modules[1], *modules[2], modules[3]] + ([attention] if attention is not None else [])
         stamp = (self.edge_chain_precision,) + tuple((t.data_ptr(), t._version) for lin in linears
                                                       for t in (lin.weight, lin.bias) if t is not None)
         if self._chain[0] != stamp:
@@ -207,7 +215,7 @@ class E_GCL(nn.Module):
                 n_layers = len(list(modules[1])) + len(list(modules[2]))
                 kept[self.edge_chain_precision] = (stamp, kernels.EdgeChainPack(
                     *modules, input_size=self.input_size, precision=self.edge_chain_precision,
-                    scales=self._scales("edge", n_layers, modules[0].weight.device)))
+                    scales=self._scales("edge", n_layers, modules[0].weight.device), attention_layer=attention))
             self._chain = kept[self.edge_chain_precision]
         return self._chain[1]
 
@@ -346,23 +354,26 @@ class E_GCL(nn.Module):
                 # per-node projections: one launch on the matrix cores
                 h = h.contiguous()
                 agg, coord_out = kernels.egnn_node_gather(messages, edge_index.shape[0], offsets, degree, self.message_mean,
-                                                          None, edge_scalar, coord, edge_index, self.coords_mean)
+                                                          None, edge_scalar, coord, edge_index, self.coords_mean,
+                                                          flags=self._coord_flags())
                 out = kernels.node_mlp_rows(whole, h, self.residual, status=self.status_word, agg=agg)
                 if whole.projects:
                     out, self._next_proj = out
                 return out, coord_out
             node_in, coord_out = kernels.egnn_node_gather(messages, edge_index.shape[0], offsets, degree, self.message_mean,
-                                                          h.contiguous(), edge_scalar, coord, edge_index, self.coords_mean)
+                                                          h.contiguous(), edge_scalar, coord, edge_index, self.coords_mean,
+                                                          flags=self._coord_flags())
         else:
-            coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean)
+            coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean,
+                                                     flags=self._coord_flags())
             agg = (kernels.segment_combine(messages, edge_index.shape[0], offsets, degree, self.message_mean) if in_kernel
                    else kernels.segment_rows(messages, offsets, degree, self.message_mean))
             node_in = torch.cat([h, agg], dim=1)
         node_pack = self._node_chain_pack()
         if node_pack is not None and (not self.residual or h.shape[1] == node_pack.hidden):
-            # first node layer (2H -> H, + SiLU): library GEMM per node; the other layers and the residual: one MFMA launch
+            # first node layer (2H -> H, + SiLU): a PyTorch matmul per node; the other layers and the residual: one MFMA launch
             first = self.node_mlp[0]
-            hidden = kernels.linear_act(node_in, first.weight, first.bias, True)
+            hidden = torch.nn.functional.silu(torch.nn.functional.linear(node_in, first.weight, first.bias))
             out = kernels.mlp_chain_rows(node_pack, hidden, residual=h.contiguous() if self.residual else None,
                                          status=self.status_word)
             return out, coord_out

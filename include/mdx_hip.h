@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 12
+#define MDX_ABI_VERSION 13
 
 /* status codes */
 #define MDX_OK 0
@@ -358,16 +358,8 @@ MDX_API int mdx_mlp_pc_sample(const mdx_schedule_t* sched_host, const mdx_mlp_t*
 
 /* ------------------------------------------------------------------------------------------------------------------
  * EGNN score network helpers (the forward stays a PyTorch module; these remove passes PyTorch cannot fuse).
- * mdx_blas_t is an opaque handle around a hipBLASLt context, owned by the caller (create once per device/thread). */
-typedef struct mdx_blas_handle* mdx_blas_t;
-MDX_API int mdx_blas_create(mdx_blas_t* handle_out);
-MDX_API int mdx_blas_destroy(mdx_blas_t handle);
-
-/* out[M,N] = act(x[M,K] . w[N,K]^T + bias[N]) -- nn.Linear (+ nn.SiLU) of the EGNN MLPs (models/egnn.py:85-131) as one
- * hipBLASLt fp32 matmul with the BIAS / SWISH_BIAS epilogue.  w in nn.Linear layout; bias nullable; act 0 none, 1 SiLU.
- * workspace: caller-owned device scratch for the library.  MDX_ERR_UNSUPPORTED when the library has no such kernel. */
-MDX_API int mdx_linear_act(mdx_blas_t handle, const float* x, const float* w, const float* bias, float* out, int64_t M,
-                           int K, int N, int act, void* workspace, uint64_t workspace_bytes, mdx_stream_t stream);
+ * (No vendor GEMM library behind this ABI: every matrix product of the library is a hand-written MFMA kernel; shapes the
+ * edge chain does not cover stay plain PyTorch modules on the caller's side.) */
 
 /* First layer of E_GCL.message_model (models/egnn.py:136-160) on an edge list [E,2] of node indices:
  * out[e,:] = act(node_proj[src_e, :H] + node_proj[dst_e, H:] + bias + radial[e] * w_radial), node_proj [n_nodes, 2H] being
@@ -399,8 +391,13 @@ MDX_API int mdx_segment_rows(const float* data, const int64_t* offsets, const in
  *   y   = SiLU(y W_l^T + b_l), l = n_message_layers .. +n_coord_layers-1    (coordinate MLP, all its H -> H layers)
  *   edge_scalar_out[e] = y . w_out                                          (its last layer, Linear(H, 1, bias=False))
  * The [E,H] activations stay in registers between layers (accumulator tile == next layer's MFMA operand).
- * hidden in {32, 64, 128, 256}; message and coordinate MLPs of equal width; SiLU activations; no attention / tanh /
- * normalize (callers keep the per-layer library path for those).
+ * hidden in {32, 64, 128, 256}; message and coordinate MLPs of equal width; SiLU activations.  E_GCL's options
+ * (models/egnn.py:128-135, 148-160, 234-264):
+ *   attention  attention_weight [H] / attention_bias [1] (device, both or neither): the messages are gated,
+ *              m_e <- m_e sigmoid(m_e . attention_weight + attention_bias), between the message and the coordinate layers --
+ *              messages_out (rows or piece sums) and the coordinate MLP see the gated messages;
+ *   tanh, normalize  act where edge_scalar_out meets the coordinate difference: the coord_flags of mdx_egnn_node_gather /
+ *              mdx_egnn_coord_aggregate (edge_scalar_out itself is the head's raw value).
  * precision 0: v_mfma_f32_32x32x2_f32, exact binary32 (== fmaf chains in a fixed order).
  * precision 1: split-f16, three v_mfma_f32_32x32x16_f16 per product (hi.hi + hi.lo + lo.hi), binary32 accumulation:
  *              ~2^-22 relative per product.  Both operands are held scaled by exact powers of two so that the f16 halves
@@ -438,7 +435,12 @@ typedef struct mdx_egnn_chain {
     /* Precision 0, nullable: device, uint32 [n_layers + 2], the float bits of the largest |carried value| seen at each
      * position so far (atomic maxima; the caller zero-fills it) -- the input of mdx_egnn_chain_adapt_activation_exponents. */
     uint32_t* activation_maxima;
+    /* E_GCL.att_mlp = Linear(H, 1) + Sigmoid, nullable (both or neither; mdx_egnn_edge_chain only): device, [H] and [1]. */
+    const float* attention_weight;
+    const float* attention_bias;
 } mdx_egnn_chain_t;
+#define MDX_EGNN_COORD_NORMALIZE 1   /* coord_diff <- tanh(r^2) / sqrt(r^2 + 1e-16) coord_diff   (E_GCL normalize=True)   */
+#define MDX_EGNN_COORD_TANH 2        /* edge_scalar <- tanh(edge_scalar)                          (E_GCL tanh=True)        */
 /* exponents_inout[q] = min(exponents_inout[q], e) with 2^e maxima[q] in [2^12, 2^13) (e clamped to [-14,
  * MDX_EGNN_F16_ACTIVATION_EXPONENT]) for every position with a recorded maximum; the maxima are zeroed.  Device-side, no host
  * synchronisation: what a caller runs after an exact-f32 pass that followed an MDX_STATUS_EGNN_F16_RANGE report, so that the
@@ -475,11 +477,12 @@ MDX_API int mdx_segment_combine(const float* pieces, int64_t n_edges, const int6
  * between the per-edge chain and the node MLP (models/egnn.py:162-230: both unsorted_segment_sum / _mean calls, the product
  * with coord_diff, the coordinate residual, torch.cat([h, agg])): out = [left | message sums] (or the sums alone),
  * coord_out[i,:] = coord[i,:] + (1/degree_i if mean_coords) sum_e (coord[i,:] - coord[dst_e,:]) edge_scalar[e].  The node's
- * edges are dealt to the lanes of one wavefront and reduced by a butterfly: fixed order, no atomics.  coord_dimension <= 8. */
+ * edges are dealt to the lanes of one wavefront and reduced by a butterfly: fixed order, no atomics.  coord_dimension <= 8.
+ * coord_flags: MDX_EGNN_COORD_* bits (0 for the plain layer). */
 MDX_API int mdx_egnn_node_gather(const float* pieces, int64_t n_edges, const int64_t* offsets, const int64_t* degree,
                                  int64_t n_nodes, int H, int mean_messages, const float* left, float* out,
                                  const float* edge_scalar, const float* coord, int coord_dimension, const int64_t* edges,
-                                 int mean_coords, float* coord_out, mdx_stream_t stream);
+                                 int mean_coords, int coord_flags, float* coord_out, mdx_stream_t stream);
 
 /* EGNNScoreNetwork's per-node inputs and outputs around the EGNN (models/score_networks/egnn_score_network.py:253-290), one
  * launch each instead of a dozen elementwise passes (spatial dimension 3):
@@ -536,7 +539,7 @@ MDX_API int mdx_node_mlp_rows_split(const mdx_egnn_chain_t* chain_host, const fl
  * (models/egnn.py:162-200), on the sorted segments; no atomics, fixed summation order. */
 MDX_API int mdx_egnn_coord_aggregate(const float* edge_scalar, const float* coord, int coord_dimension, const int64_t* edges,
                                      const int64_t* offsets, const int64_t* degree, int64_t n_nodes, int mean,
-                                     float* coord_out, mdx_stream_t stream);
+                                     int coord_flags, float* coord_out, mdx_stream_t stream);
 
 /* Device-RNG draws as stand-alone fills (trajectory initialisation, tests of the RNG specification).
  * kind 0 = uniform (0,1), 1 = standard normal, 2 = Gumbel(0,1).  out [n_items, width]. */

@@ -1171,6 +1171,78 @@ def golden_egnn_variants():
     save("net_egnn_variants.npz", **out)
 
 
+def golden_egnn_options_wide():
+    """E_GCL's options at the widths the hand-written kernels are instantiated for beyond 32 (formula weights, so no state_dict is
+    stored; tests/formula_weights.py):
+      template_1d     the reference's shipped configuration with an option switched on -- configuration_templates/
+                      diffusion_config_files/config_diffusion_egnn_2_atoms_in_1D.yaml:52-67: spatial_dimension 1, two atoms,
+                      4 graph layers x 128 wide x 4 hidden layers, normalize=True, fully connected -- on 16 structures
+      attention_256   attention + tanh at the production width: 2 graph layers x 256 wide x 2 hidden layers, radial cutoff 7.5,
+                      two atom types, N = 64, 3 structures (formula scale 2: the gate's logit then varies between edges)
+      normalize_128   normalize + attention, 2 x 128 x 3, sum aggregations, N = 64, 3 structures
+    Each with the module's binary64 output on the same inputs."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from formula_weights import fill_with_formula
+    g = torch.Generator().manual_seed(4242)
+    out = {}
+
+    def record(name, p, scale, A, X, L, sigma):
+        net = fill_with_formula(EGNNScoreNetwork(p).eval(), scale=scale)
+        net64 = fill_with_formula(EGNNScoreNetwork(p).eval(), scale=scale).double()
+        B = X.shape[0]
+        batch = {NOISY_AXL_COMPOSITION: AXL(A=A, X=X, L=L), TIME: torch.rand(B, 1, generator=g), NOISE: sigma,
+                 CARTESIAN_FORCES: torch.zeros_like(X)}
+        with torch.no_grad():
+            o = net(batch, conditional=False)
+            if p.edges == "radial_cutoff":
+                o64 = _fp64_forward_batch(net64, batch)
+            else:
+                o64 = net64({NOISY_AXL_COMPOSITION: AXL(A=A, X=X.double(), L=L.double()), TIME: batch[TIME].double(),
+                             NOISE: sigma.double(), CARTESIAN_FORCES: torch.zeros_like(X).double()}, conditional=False)
+        for key, val in (("A", A), ("X", X), ("L", L), ("time", batch[TIME]), ("noise", sigma), ("out_A", o.A), ("out_X", o.X),
+                         ("out_X_fp64", o64.X), ("out_A_fp64", o64.A)):
+            out[f"{name}/{key}"] = _np(val)
+        out[f"{name}/formula_scale"] = np.array(scale)
+
+    B = 16
+    p = EGNNScoreNetworkParameters(spatial_dimension=1, num_atom_types=1, n_layers=4, coordinate_hidden_dimensions_size=128,
+                                   coordinate_n_hidden_dimensions=4, coords_agg="mean", message_hidden_dimensions_size=128,
+                                   message_n_hidden_dimensions=4, node_hidden_dimensions_size=128, node_n_hidden_dimensions=4,
+                                   attention=False, normalize=True, residual=True, tanh=False, edges="fully_connected")
+    record("template_1d", p, 2.0, torch.randint(0, 2, (B, 2), generator=g), torch.rand(B, 2, 1, generator=g),
+           torch.ones(B, 1), torch.rand(B, 1, generator=g) * 0.2)
+    B, N, cell = 3, 64, 11.084
+    L = torch.tensor([cell, cell, cell, 0, 0, 0.0]).repeat(B, 1)
+    p = EGNNScoreNetworkParameters(num_atom_types=2, n_layers=2, coordinate_hidden_dimensions_size=256,
+                                   coordinate_n_hidden_dimensions=2, message_hidden_dimensions_size=256,
+                                   message_n_hidden_dimensions=2, node_hidden_dimensions_size=256, node_n_hidden_dimensions=2,
+                                   attention=True, tanh=True, edges="radial_cutoff", radial_cutoff=7.5)
+    record("attention_256", p, 2.0, torch.randint(0, 3, (B, N), generator=g), torch.rand(B, N, 3, generator=g), L,
+           torch.rand(B, 1, generator=g) * 0.2)
+    p = EGNNScoreNetworkParameters(num_atom_types=2, n_layers=2, coordinate_hidden_dimensions_size=128,
+                                   coordinate_n_hidden_dimensions=3, message_hidden_dimensions_size=128,
+                                   message_n_hidden_dimensions=3, node_hidden_dimensions_size=128, node_n_hidden_dimensions=3,
+                                   attention=True, normalize=True, coords_agg="sum", message_agg="sum",
+                                   edges="radial_cutoff", radial_cutoff=7.5)
+    record("normalize_128", p, 1.5, torch.randint(0, 3, (B, N), generator=g), torch.rand(B, N, 3, generator=g), L,
+           torch.rand(B, 1, generator=g) * 0.2)
+    out["names"] = np.array(["template_1d", "attention_256", "normalize_128"])
+    save("net_egnn_options_wide.npz", **out)
+
+
+def _fp64_forward_batch(net64, batch):
+    from diffusion_for_multi_scale_molecular_dynamics.models.score_networks import egnn_score_network as _mod
+    b = batch[NOISY_AXL_COMPOSITION]
+    batch64 = {NOISY_AXL_COMPOSITION: AXL(A=b.A, X=b.X.double(), L=b.L.double()), TIME: batch[TIME].double(),
+               NOISE: batch[NOISE].double(), CARTESIAN_FORCES: batch[CARTESIAN_FORCES].double()}
+    search = _mod.get_edges_with_radial_cutoff
+    _mod.get_edges_with_radial_cutoff = lambda x, cell, *a, **k: search(x.float(), cell.float(), *a, **k)
+    try:
+        return net64(batch64, conditional=False)
+    finally:
+        _mod.get_edges_with_radial_cutoff = search
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -1204,3 +1276,5 @@ if __name__ == "__main__":
         golden_c5_shape()
     if which in ("all", "variants"):
         golden_egnn_variants()
+    if which in ("all", "options_wide"):
+        golden_egnn_options_wide()

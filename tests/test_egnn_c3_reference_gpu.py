@@ -332,25 +332,53 @@ def test_c3_arithmetic_modes_agree_over_many_iterations(cuda):
         assert err < 1e-5, f"{precision} vs f32 after 24 iterations: {err:.2e}"
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3_32x32"])
 @pytest.mark.parametrize("name", ["attention", "normalize_tanh", "sum_noresidual", "all_duplicates_kept"])
-def test_egnn_option_variants_on_the_gpu_against_reference(cuda, name):
-    """The same options on the GPU: HIP radius graph (one sorted list for either drop_duplicate_edges setting), the fused edge
-    chain where the layer shape allows it (sum aggregations, no residual) and the per-layer library path where it does not
-    (attention, normalize, tanh), against the reference's forward: scores within 1e-5 rel-L2."""
-    from test_host_cpu import variant_case, variant_net
+def test_egnn_option_variants_on_the_gpu_against_reference(cuda, name, precision):
+    """Every option of the reference's E_GCL (models/egnn.py:128-135, 148-160, 234-264) on the hand-written path: HIP radius
+    graph (one sorted list for either drop_duplicate_edges setting), the fused MFMA edge chain with the attention gate inside
+    it, normalize / tanh in the per-node kernel that adds the coordinate updates up -- against the reference's forward: scores
+    within 1e-5 rel-L2 (or the reference's own distance from the exact answer where that is larger), all three arithmetic
+    modes, and the chain really ran in every graph layer."""
+    from test_host_cpu import variant_case, variant_net, variant_tolerance
     g = load_golden("net_egnn_variants.npz")
     net, batch = variant_case(g, name, variant_net(name), device=cuda)
+    net.edge_chain_precision = precision
     with torch.no_grad():
         out = net(batch, conditional=False)
     net.check_status()
     ref = g[f"{name}/out_X"].astype(np.float64)
     err = np.linalg.norm(out.X.cpu().numpy() - ref) / np.linalg.norm(ref)
-    from test_host_cpu import variant_tolerance
     tol = variant_tolerance(g, name)          # 1e-5, or the reference's own distance from the exact answer where that is larger
-    assert err < tol, f"{name}: {err:.2e} (tolerance {tol:.2e})"
+    assert err < tol, f"{name} / {precision}: {err:.2e} (tolerance {tol:.2e})"
     np.testing.assert_allclose(out.A.cpu().numpy()[..., :-1], g[f"{name}/out_A"][..., :-1], rtol=1e-4, atol=1e-5)
-    fused = net.egnn.graph_layers[0]._chain[1] is not None
-    assert fused == (name == "sum_noresidual")
+    for layer in net.egnn.graph_layers:
+        assert layer._chain[1] is not None and layer._chain[1].precision == precision, "the fused edge chain did not run"
+        assert (layer._chain[1].att_w is not None) == layer.attention
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3_32x32"])
+@pytest.mark.parametrize("name", ["template_1d", "attention_256", "normalize_128"])
+def test_egnn_options_at_kernel_widths_on_the_gpu_against_reference(cuda, name, precision):
+    """The options at the widths 128 and 256 (tests/golden/make_golden.py::golden_egnn_options_wide): the reference's shipped
+    1-D template (normalize=True, hidden 128, spatial dimension 1: coordinates of dimension D = 2 in the chain), attention + tanh
+    at 256 (the ATT instantiation of the production-width kernel), attention + normalize with sum aggregations at 128 --
+    scores <= 1e-5 against the reference's output, logits close, the fused chain in every graph layer."""
+    from test_host_cpu import wide_option_case
+    g = load_golden("net_egnn_options_wide.npz")
+    net, batch = wide_option_case(g, name, device=cuda)
+    net.edge_chain_precision = precision
+    with torch.no_grad():
+        out = net(batch, conditional=False)
+    net.check_status()
+    ref = g[f"{name}/out_X"].astype(np.float64)
+    err = np.linalg.norm(out.X.cpu().numpy() - ref) / np.linalg.norm(ref)
+    floor = np.linalg.norm(ref - g[f"{name}/out_X_fp64"]) / np.linalg.norm(ref)
+    print(f"{name} / {precision}: {err:.2e} (the reference's own distance from binary64: {floor:.2e})")
+    assert err < 1e-5, f"{name} / {precision}: {err:.2e}"
+    np.testing.assert_allclose(out.A.cpu().numpy()[..., :-1], g[f"{name}/out_A"][..., :-1], rtol=1e-4, atol=1e-5)
+    for layer in net.egnn.graph_layers:
+        assert layer._chain[1] is not None and layer._chain[1].precision == precision, "the fused edge chain did not run"
 
 
 def test_cli_with_the_experiment_configuration_and_a_checkpoint(cuda, tmp_path):

@@ -957,25 +957,6 @@ def test_fused_sampler_padded_family_equals_generic_folded(cuda, shape, variant)
     assert (results["padded"].A != nat).all() and np.isfinite(results["padded"].X).all()
 
 
-# -------------------------------------------------------------------------------------------------------------
-# EGNN helpers: library GEMM with fused bias+SiLU epilogue, fused first message layer
-# -------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,K,N", [(1, 8, 4), (37, 256, 256), (4099, 64, 32), (200000, 256, 256), (513, 7, 12)])
-@pytest.mark.parametrize("silu", [False, True])
-def test_linear_act_against_torch(cuda, M, K, N, silu):
-    from diffusion_for_multi_scale_molecular_dynamics_amd import kernels
-    torch.manual_seed(M + K)
-    x = torch.randn(M, K, device=cuda)
-    lin = torch.nn.Linear(K, N).to(cuda)
-    with torch.no_grad():
-        want = lin(x)
-        if silu:
-            want = torch.nn.functional.silu(want)
-        got = kernels.linear_act(x, lin.weight, lin.bias, silu)
-    # float32 GEMM in a different tiling + the library's SiLU: 1e-5 of the output scale
-    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-6
-
-
 def test_egnn_fused_ops_equal_plain_torch(cuda):
     """The EGNN forward with the fused helpers (hipBLASLt bias+SiLU epilogue, fused first message layer) against the
     same module with plain PyTorch ops, radius-graph edges, experiment-like widths."""

@@ -1,5 +1,5 @@
 """Time the fused MFMA edge-chain kernel at a workload's shape (default C3: E ~ 819 k edges, H = 256, 4 message + 5
-coordinate layers) in both arithmetic modes, next to the same chain as per-layer hipBLASLt calls (mdx_linear_act)."""
+coordinate layers) in both arithmetic modes, next to the same chain as per-layer PyTorch linear + SiLU calls."""
 import argparse
 import json
 import os
@@ -67,9 +67,9 @@ with torch.no_grad():
             def launch():
                 x = kernels.egnn_message_input(proj, edges, radial, lin0.bias, lin0.weight[:, 2 * n_in].contiguous())
                 for layer in msg:
-                    x = kernels.linear_act(x, layer.weight, layer.bias, True)
+                    x = torch.nn.functional.silu(torch.nn.functional.linear(x, layer.weight, layer.bias))
                 for layer in crd:
-                    x = kernels.linear_act(x, layer.weight, layer.bias, True)
+                    x = torch.nn.functional.silu(torch.nn.functional.linear(x, layer.weight, layer.bias))
                 return x
         else:
             pack = kernels.EdgeChainPack(lin0, msg, crd, out, input_size=n_in, precision=mode)
