@@ -33,7 +33,8 @@ import types
 import numpy as np
 import torch
 
-OUT = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("MDX_GOLDEN_OUT", HERE)      # (tests/test_golden_reproducible.py regenerates into a scratch directory)
 
 # --------------------------------------------------------------------------------------------------------------
 # container-only stubs for absent third-party modules
@@ -777,7 +778,7 @@ def _egnn_c3(num_atom_types=1, scale=1.0):
     """The reference's production EGNN (experiments/.../Si_2x2x2/config_diffusion_egnn.yaml:44-60): 4 graph layers, 256 wide,
     4 hidden layers per MLP, radial cutoff 7.5 -- with every trainable parameter filled from tests/formula_weights.py
     (the fixture then needs no 19 MB state_dict: the tests evaluate the same formula)."""
-    sys.path.insert(0, os.path.dirname(OUT))
+    sys.path.insert(0, os.path.dirname(HERE))
     from formula_weights import fill_with_formula
     p = EGNNScoreNetworkParameters(num_atom_types=num_atom_types, n_layers=4,
                                    coordinate_hidden_dimensions_size=256, coordinate_n_hidden_dimensions=4,
@@ -1181,7 +1182,7 @@ def golden_egnn_options_wide():
                       two atom types, N = 64, 3 structures (formula scale 2: the gate's logit then varies between edges)
       normalize_128   normalize + attention, 2 x 128 x 3, sum aggregations, N = 64, 3 structures
     Each with the module's binary64 output on the same inputs."""
-    sys.path.insert(0, os.path.dirname(OUT))
+    sys.path.insert(0, os.path.dirname(HERE))
     from formula_weights import fill_with_formula
     g = torch.Generator().manual_seed(4242)
     out = {}
