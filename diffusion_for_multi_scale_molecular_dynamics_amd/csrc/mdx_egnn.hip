@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void egnn_coord_head_kernel(const float* __
             finish(e, p0); finish(e + 1, p1); finish(e + 2, p2); finish(e + 3, p3);
         }
         for (; e < e0 + deg; ++e) finish(e, row_dot(e));
-        if (lane < d) trans[node * d + lane] = (mean && deg > 0) ? acc * (1.0f / (float)deg) : acc;
+        if (lane < d) trans[node * d + lane] = (mean && deg > 0) ? acc / (float)deg : acc;      // (true division: egnn_utils.py:66-68)
     }
 }
 
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void segment_rows_kernel(const float* __res
     const int quads = H >> 2;
     for (int64_t node = wave; node < n_nodes; node += n_waves) {
         const int64_t e0 = offsets[node], deg = degree[node];
-        const float scale = (mean && deg > 0) ? 1.0f / (float)deg : 1.0f;
+        const float count = (mean && deg > 0) ? (float)deg : 1.0f;
         for (int q = lane; q < quads; q += kWave) {
             float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 4
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void segment_rows_kernel(const float* __res
                 const float4 v = reinterpret_cast<const float4*>(data + e * H)[q];
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
-            if (mean) { acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale; }
+            if (mean) { acc.x /= count; acc.y /= count; acc.z /= count; acc.w /= count; }
             reinterpret_cast<float4*>(out + node * H)[q] = acc;
         }
     }

@@ -1605,7 +1605,7 @@ __global__ __launch_bounds__(256) void egnn_coord_aggregate_kernel(const float* 
             }
             acc += diff * coord_head_value(s[e], flags);
         }
-        if (mean && deg > 0) acc *= 1.0f / (float)deg;
+        if (mean && deg > 0) acc = acc / (float)deg;          // (a true division, as unsorted_segment_mean's: egnn_utils.py:66-68)
         out[idx] = ci + acc;
     }
 }
@@ -1626,14 +1626,14 @@ __global__ __launch_bounds__(256) void segment_combine_kernel(const float* __res
     const int quads = H >> 2;
     for (int64_t node = wave; node < n_nodes; node += n_waves) {
         const int64_t e0 = offsets[node], deg = degree[node], e1 = e0 + deg;
-        const float scale = (mean && deg > 0) ? 1.0f / (float)deg : 1.0f;
+        const float count = (mean && deg > 0) ? (float)deg : 1.0f;      // the mean DIVIDES by the count (egnn_utils.py:66-68)
         // the node's last piece: a boundary row if its last edge is 15 mod 16, else the node's own row
         const int64_t last_row = ((e1 - 1) & 15) == 15 ? ((e1 - 1) >> 4) : boundary_rows + node;
         for (int q = lane; q < quads; q += kWave) {
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
             for (int64_t e = e0 | 15; e < e1 - 1; e += 16) acc += reinterpret_cast<const f32x4*>(pieces + (e >> 4) * H)[q];
             if (deg > 0) acc += reinterpret_cast<const f32x4*>(pieces + last_row * H)[q];
-            if (mean) acc *= scale;
+            if (mean) acc = acc / count;
             if (left) {
                 reinterpret_cast<f32x4*>(out + node * 2 * H)[q] = reinterpret_cast<const f32x4*>(left + node * H)[q];
                 reinterpret_cast<f32x4*>(out + node * 2 * H + H)[q] = acc;
@@ -1686,13 +1686,13 @@ __global__ __launch_bounds__(256) void egnn_node_gather_kernel(const float* __re
             }
         }
         // messages
-        const float scale = (mean_messages && deg > 0) ? 1.0f / (float)deg : 1.0f;
+        const float count = (mean_messages && deg > 0) ? (float)deg : 1.0f;      // (a true division: egnn_utils.py:66-68)
         const int64_t last_row = ((e1 - 1) & 15) == 15 ? ((e1 - 1) >> 4) : boundary_rows + node;
         for (int q = lane; q < quads; q += kWave) {
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
             for (int64_t e = e0 | 15; e < e1 - 1; e += 16) acc += reinterpret_cast<const f32x4*>(pieces + (e >> 4) * H)[q];
             if (deg > 0) acc += reinterpret_cast<const f32x4*>(pieces + last_row * H)[q];
-            if (mean_messages) acc *= scale;
+            if (mean_messages) acc = acc / count;
             if (left) {
                 reinterpret_cast<f32x4*>(out + node * 2 * H)[q] = reinterpret_cast<const f32x4*>(left + node * H)[q];
                 reinterpret_cast<f32x4*>(out + node * 2 * H + H)[q] = acc;
@@ -1721,7 +1721,7 @@ __global__ __launch_bounds__(256) void egnn_node_gather_kernel(const float* __re
             for (int k = 0; k < 8; ++k) {
                 if (k == lane) { total = part[k]; mine = ci[k]; }
             }
-            if (mean_coords && deg > 0) total *= 1.0f / (float)deg;
+            if (mean_coords && deg > 0) total = total / (float)deg;
             coord_out[node * D + lane] = mine + total;
         }
     }

@@ -303,7 +303,7 @@ class E_GCL(nn.Module):
             if pack is not None:
                 return self._forward_edge_chain(pack, h, edge_index, coord, degree, offsets, n_edges, node_proj, next_layer)
         assert n_edges is None, "a capacity-sized edge list needs the fused edge chain in every layer"
-        inv_deg = (1.0 / degree.clamp(min=1).to(h.dtype)).unsqueeze(1)
+        count = degree.clamp(min=1).to(h.dtype).unsqueeze(1)      # (the reference DIVIDES by the count: egnn_utils.py:66-68)
 
         coord_diff = coord.index_select(0, row) - coord.index_select(0, col)
         radial = (coord_diff ** 2).sum(dim=1, keepdim=True)
@@ -320,7 +320,7 @@ class E_GCL(nn.Module):
                                                     coord_diff.contiguous(), offsets, degree, self.coords_mean)
         else:
             trans = segment_sum_sorted(coord_diff * run_mlp(self.coord_mlp, messages, fused), degree)
-            coord = coord + (trans * inv_deg if self.coords_mean else trans)
+            coord = coord + (trans / count if self.coords_mean else trans)
 
         if segments:
             from .. import kernels
@@ -328,7 +328,7 @@ class E_GCL(nn.Module):
         else:
             agg = segment_sum_sorted(messages, degree)
             if self.message_mean:
-                agg = agg * inv_deg
+                agg = agg / count
         out = run_mlp(self.node_mlp, torch.cat([h, agg], dim=1), fused)
         if self.residual:
             out = h + out
