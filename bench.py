@@ -297,7 +297,7 @@ def time_edge_gemm(n_edges, device, hidden=256, launches=10):
                        "per network forward)", avg_launch_us=round(ms * 1e3, 2))
 
 
-TRAFFIC_FILE = "traffic_r04.json"      # the latest committed PMC record of the edge chain's HBM traffic
+TRAFFIC_FILE = "traffic_r05.json"      # the latest committed PMC record of the edge chain's HBM traffic
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 
 
