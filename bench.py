@@ -576,6 +576,7 @@ def launch_ranks(args):
         for name in sorted(os.listdir(errors)):
             with open(os.path.join(errors, name)) as f:
                 reports.append(json.loads(f.read())["bench_error"])
+        reports.sort(key=lambda r: r.get("at", 0.0))       # the rank that failed FIRST first: the others usually die of its death
         print(json.dumps({"bench_launcher": {"exit_code": code, "elapsed_s": round(time.perf_counter() - t0, 1),
                                              "rank_errors": reports or ["no rank left a report (killed by a signal?)"]}}),
               file=sys.stderr, flush=True)
@@ -587,7 +588,7 @@ def launch_ranks(args):
 def report_rank_error(rank, exc):
     """A rank's own account of why it is about to die: one line on stderr, and a file the launcher reads."""
     import traceback
-    text = json.dumps({"bench_error": {"rank": rank, "error": repr(exc),
+    text = json.dumps({"bench_error": {"rank": rank, "at": time.time(), "error": repr(exc),
                                        "where": traceback.format_exception(type(exc), exc, exc.__traceback__)[-2].strip()}})
     print(text, file=sys.stderr, flush=True)
     folder = os.environ.get("BENCH_ERROR_DIR")

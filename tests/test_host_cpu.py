@@ -341,6 +341,7 @@ def test_bench_fails_fast_when_a_rank_dies(how):
     assert len(report) == 1 and report[0]["bench_launcher"]["exit_code"] == out.returncode
     errors = report[0]["bench_launcher"]["rank_errors"]
     if how == "raise":
+        # (rank 0 may report too -- its collective fails when its peer is gone -- but the rank that failed first is listed first)
         assert errors[0]["rank"] == 1 and "rank 1 was asked to fail" in errors[0]["error"]
     else:
         assert errors == ["no rank left a report (killed by a signal?)"]
