@@ -97,7 +97,7 @@ def build(force=False):
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mdx_hip.h"))
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-s", "-j3", "-C", CSRC, "-B"])
+        subprocess.check_call(["make", "-s", "-j4", "-C", CSRC, "-B"])
     return LIB_PATH
 
 

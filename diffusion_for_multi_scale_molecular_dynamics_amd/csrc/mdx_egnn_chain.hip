@@ -1147,37 +1147,38 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
         // like the chain's first layer (nothing outstanding).  H / 2 fused multiply-adds and as many products per lane: noise
         // beside the layer's 2 H^2 MACs per edge.
         auto gate_messages = [&](Act<H, PREC>& m, int l) {
-            if constexpr (!ATT) return;
-            epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, m, sc_prev, false, amax);
-            flush_max(l);
-            float part[NS];
+            if constexpr (ATT) {
+                epilogue_elements<H, PREC>(NT - 1, 0, 16, pend, m, sc_prev, false, amax);
+                flush_max(l);
+                float part[NS];
 #pragma unroll
-            for (int es = 0; es < NS; ++es) part[es] = 0.0f;
+                for (int es = 0; es < NS; ++es) part[es] = 0.0f;
 #pragma unroll
-            for (int q8 = 0; q8 < H / 8; ++q8) {
-                const int t = q8 >> 2, q = q8 & 3;
-                const f32x4 y = get4<H>(m, t, q);
-                const f32x4 w4 = *(const __attribute__((address_space(3))) f32x4*)(par_att + 32 * t + L::fb(q, h));
+                for (int q8 = 0; q8 < H / 8; ++q8) {
+                    const int t = q8 >> 2, q = q8 & 3;
+                    const f32x4 y = get4<H>(m, t, q);
+                    const f32x4 w4 = *(const __attribute__((address_space(3))) f32x4*)(par_att + 32 * t + L::fb(q, h));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) part[L::es(q)] = __builtin_fmaf(y[i], w4[i], part[L::es(q)]);
-            }
-            float g[NS];
+                    for (int i = 0; i < 4; ++i) part[L::es(q)] = __builtin_fmaf(y[i], w4[i], part[L::es(q)]);
+                }
+                float g[NS];
 #pragma unroll
-            for (int es = 0; es < NS; ++es) {
-                float a = part[es];
-                if constexpr (W16) a += __shfl_xor(a, 16);
-                a += __shfl_xor(a, 32);
-                a += par_att[H];
-                g[es] = 1.0f / (1.0f + expf(-a));
-            }
+                for (int es = 0; es < NS; ++es) {
+                    float a = part[es];
+                    if constexpr (W16) a += __shfl_xor(a, 16);
+                    a += __shfl_xor(a, 32);
+                    a += par_att[H];
+                    g[es] = 1.0f / (1.0f + expf(-a));
+                }
 #pragma unroll
-            for (int q8 = 0; q8 < H / 8; ++q8) {
-                const int t = q8 >> 2, q = q8 & 3;
-                const f32x4 y = get4<H>(m, t, q);
-                const float gg = g[L::es(q)];
-                put_pair<H>(m, t, 4 * q, y[0] * gg, y[1] * gg);
-                put_pair<H>(m, t, 4 * q + 2, y[2] * gg, y[3] * gg);
-                if ((q8 & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+                for (int q8 = 0; q8 < H / 8; ++q8) {
+                    const int t = q8 >> 2, q = q8 & 3;
+                    const f32x4 y = get4<H>(m, t, q);
+                    const float gg = g[L::es(q)];
+                    put_pair<H>(m, t, 4 * q, y[0] * gg, y[1] * gg);
+                    put_pair<H>(m, t, 4 * q + 2, y[2] * gg, y[3] * gg);
+                    if ((q8 & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+                }
             }
         };
         // messages = the operand registers of the first coordinate layer, complete once its first tile has run
@@ -1756,7 +1757,29 @@ int launch_chain(const ChainArgs& a, int layers, hipStream_t st)
 
 }  // namespace
 
-#ifndef MDX_CHAIN_NO_ENTRY_POINTS      // (a probe unit includes this file for single instantiations: tools/)
+// The ATT = true instantiations of the edge chain, compiled in mdx_egnn_chain_att.hip (which includes this file with
+// MDX_CHAIN_ATTENTION_UNIT defined): `args` is a ChainArgs.  Not part of the ABI (hidden visibility).
+extern "C" int mdx_chain_launch_attention(const void* args, int hidden, int precision, int layers, mdx_stream_t stream);
+
+#ifdef MDX_CHAIN_ATTENTION_UNIT
+extern "C" int mdx_chain_launch_attention(const void* args, int hidden, int precision, int layers, mdx_stream_t stream)
+{
+    const ChainArgs& a = *static_cast<const ChainArgs*>(args);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define MDX_ATT_CASE(HH) \
+    case HH: return precision == 0 ? launch_chain<HH, 0, 2, true>(a, layers, st) : (precision == 1 ? launch_chain<HH, 1, 2, true>(a, layers, st) : launch_chain<HH, 2, 2, true>(a, layers, st));
+    switch (hidden) {
+        MDX_ATT_CASE(32)
+        MDX_ATT_CASE(64)
+        MDX_ATT_CASE(128)
+        MDX_ATT_CASE(256)
+    }
+#undef MDX_ATT_CASE
+    return MDX_ERR_UNSUPPORTED;
+}
+#endif
+
+#ifndef MDX_CHAIN_NO_ENTRY_POINTS      // (the attention unit and the probe units of tools/ include this file without them)
 extern "C" {
 
 int64_t mdx_egnn_chain_image_bytes(int hidden, int n_layers)
@@ -1827,10 +1850,12 @@ int mdx_egnn_edge_chain(const mdx_egnn_chain_t* c, const float* node_proj, const
 #endif
     const int layers = a.n_message + a.n_coord;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // The attention instantiations live in a translation unit of their own (mdx_egnn_chain_att.hip: the same source, compiled
+    // beside this one): piece-sums mode only -- what E_GCL's forward runs.
+    if (a.att_w) return a.piece_sums ? mdx_chain_launch_attention(&a, c->hidden, c->precision, layers, stream) : MDX_ERR_UNSUPPORTED;
 #define MDX_CHAIN_MODE(HH, MM, AA) (c->precision == 0 ? launch_chain<HH, 0, MM, AA>(a, layers, st) : (c->precision == 1 ? launch_chain<HH, 1, MM, AA>(a, layers, st) : launch_chain<HH, 2, MM, AA>(a, layers, st)))
 #define MDX_CHAIN_CASE(HH)                                                                                            \
     case HH:                                                                                                          \
-        if (a.att_w) return a.piece_sums ? MDX_CHAIN_MODE(HH, 2, true) : MDX_CHAIN_MODE(HH, 0, true);                 \
         return a.piece_sums ? MDX_CHAIN_MODE(HH, 2, false) : MDX_CHAIN_MODE(HH, 0, false);
     switch (c->hidden) {
         MDX_CHAIN_CASE(32)

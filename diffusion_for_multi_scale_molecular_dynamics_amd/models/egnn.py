@@ -217,6 +217,8 @@ class E_GCL(nn.Module):
                     *modules, input_size=self.input_size, precision=self.edge_chain_precision,
                     scales=self._scales("edge", n_layers, modules[0].weight.device), attention_layer=attention))
             self._chain = kept[self.edge_chain_precision]
+        if attention is not None and not self._chain[1].piece_sums_ok:
+            return None          # (the gate is instantiated for the in-kernel message sums only: mdx_egnn_edge_chain)
         return self._chain[1]
 
     def _node_chain_pack(self):

@@ -395,7 +395,8 @@ MDX_API int mdx_segment_rows(const float* data, const int64_t* offsets, const in
  * (models/egnn.py:128-135, 148-160, 234-264):
  *   attention  attention_weight [H] / attention_bias [1] (device, both or neither): the messages are gated,
  *              m_e <- m_e sigmoid(m_e . attention_weight + attention_bias), between the message and the coordinate layers --
- *              messages_out (rows or piece sums) and the coordinate MLP see the gated messages;
+ *              messages_out and the coordinate MLP see the gated messages; instantiated for message_mode =
+ *              MDX_EGNN_MESSAGES_PIECE_SUMS (MDX_ERR_UNSUPPORTED with MDX_EGNN_MESSAGES_ROWS);
  *   tanh, normalize  act where edge_scalar_out meets the coordinate difference: the coord_flags of mdx_egnn_node_gather /
  *              mdx_egnn_coord_aggregate (edge_scalar_out itself is the head's raw value).
  * precision 0: v_mfma_f32_32x32x2_f32, exact binary32 (== fmaf chains in a fixed order).
