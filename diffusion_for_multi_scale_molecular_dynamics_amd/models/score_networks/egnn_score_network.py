@@ -114,6 +114,12 @@ class EGNNScoreNetwork(ScoreNetwork):
         self._logged_two_call_switch = False
         self.egnn = self._make_egnn(hp)
 
+    def __getstate__(self):
+        """Copies and pickles of the module carry no cached device tensors (the fully connected edge lists)."""
+        state = dict(self.__dict__)
+        state.pop("_fully_connected_edges", None)
+        return state
+
     @property
     def edge_chain_precision(self):
         """"f32" (exact binary32 MFMA), "f16x3" (split-f16, three products) or None (per-layer library GEMMs): the
@@ -204,9 +210,16 @@ class EGNNScoreNetwork(ScoreNetwork):
     def _build_edges(self, relative_coordinates: torch.Tensor, lattice_parameters: torch.Tensor):
         bsz, n, d = relative_coordinates.shape
         if self.edges == "fully_connected":
-            edges = neighbors.get_edges_batch(n, bsz, device=relative_coordinates.device)
-            degree = torch.full((bsz * n,), n - 1, dtype=torch.int64, device=relative_coordinates.device)
-            return edges, degree
+            # (the list depends on the batch's shape alone: built once per shape and device, reused by every forward -- and by
+            # the forwards of a captured sampler iteration)
+            key = (n, bsz, str(relative_coordinates.device))
+            cache = self.__dict__.setdefault("_fully_connected_edges", {})
+            if key not in cache:
+                if len(cache) >= 8:
+                    cache.clear()
+                cache[key] = (neighbors.get_edges_batch(n, bsz, device=relative_coordinates.device),
+                              torch.full((bsz * n,), n - 1, dtype=torch.int64, device=relative_coordinates.device))
+            return cache[key]
         if self.edge_builder is not None:
             lengths = lattice_parameters[:, :d].clip(min=2.2 * self.radial_cutoff)   # "avoid box collapse" (:236-239)
             return self.edge_builder(relative_coordinates, torch.diag_embed(lengths), self.radial_cutoff)

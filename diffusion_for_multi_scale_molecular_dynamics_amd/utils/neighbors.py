@@ -124,11 +124,13 @@ def get_edges_static_clipped(relative_coordinates: torch.Tensor, lattice_paramet
 
 
 def get_edges_batch(n_nodes: int, batch_size: int, device=None) -> torch.Tensor:
-    """Fully connected edges without self loops, [B n (n-1), 2], sorted by source (models/egnn_utils.py:73-104)."""
-    idx = torch.arange(n_nodes, device=device)
-    src = idx.repeat_interleave(n_nodes)
-    dst = idx.repeat(n_nodes)
-    keep = src != dst
-    pair = torch.stack([src[keep], dst[keep]], dim=1)
+    """Fully connected edges without self loops, [B n (n-1), 2], sorted by source (models/egnn_utils.py:73-104).  Index
+    arithmetic only -- no boolean mask, whose output size is a host read: the list can be built while a stream is capturing."""
+    if n_nodes < 2:
+        return torch.zeros(0, 2, dtype=torch.int64, device=device)
+    src = torch.arange(n_nodes, device=device).repeat_interleave(n_nodes - 1)
+    k = torch.arange(n_nodes - 1, device=device).repeat(n_nodes)
+    dst = k + (k >= src).to(k.dtype)                                    # the k-th node other than src, in increasing order
+    pair = torch.stack([src, dst], dim=1)
     offsets = (torch.arange(batch_size, device=device) * n_nodes).view(-1, 1, 1)
     return (pair.unsqueeze(0) + offsets).reshape(-1, 2)

@@ -1484,3 +1484,60 @@ def test_sharded_driver_per_shard_parity_on_the_hip_path(cuda, tmp_path):
             assert torch.equal(g["A"], want_A), (name, r)
             assert torch.equal(g["X"].view(torch.int32), want_X.view(torch.int32)), (name, r)
             assert g["X"].shape[0] == total and torch.equal(g["C"], g["X"] * g["L"][:, None, :3])
+
+
+# -------------------------------------------------------------------------------------------------------------
+# round 5: the sampler around EGNNs with E_GCL's options (attention gate inside the MFMA chain, normalize / tanh in the
+# per-node kernel) and around the reference's 1-D template shape
+# -------------------------------------------------------------------------------------------------------------
+def _option_net(kind, edge_builder=None):
+    from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import (
+        EGNNScoreNetwork, EGNNScoreNetworkParameters)
+    common = dict(n_layers=2, coordinate_hidden_dimensions_size=32, coordinate_n_hidden_dimensions=2,
+                  message_hidden_dimensions_size=32, message_n_hidden_dimensions=2, node_hidden_dimensions_size=32,
+                  node_n_hidden_dimensions=2)
+    if kind == "template_1d":        # config_diffusion_egnn_2_atoms_in_1D.yaml:52-67 at a quarter of its width
+        p = EGNNScoreNetworkParameters(spatial_dimension=1, num_atom_types=1, normalize=True, edges="fully_connected", **common)
+    else:
+        p = EGNNScoreNetworkParameters(num_atom_types=2, attention=True, normalize=True, tanh=True, edges="radial_cutoff",
+                                       radial_cutoff=7.5, **common)
+    return EGNNScoreNetwork(p, edge_builder=edge_builder).eval()
+
+
+@pytest.mark.parametrize("kind", ["all_options", "template_1d"])
+def test_sampler_around_egnn_options_graph_eager_and_oracle(cuda, kind):
+    """LangevinGenerator around an EGNN with attention + normalize + tanh (two atom types, radius graph, N = 64) and around the
+    reference's 1-D template shape (spatial dimension 1, two atoms, normalize, fully connected): device Philox, five time
+    indices, M = 1 -- the iteration replayed from a hipGraph equals the eager launches bit for bit, and both equal the CPU
+    oracle's run of the same Philox specification around the same module on the CPU (atom types exact, coordinates <= 1e-5);
+    the fused chain ran in every graph layer."""
+    P = _pkg()
+    import warnings
+    if kind == "template_1d":
+        skw = cases.sampling_ns(2, 1, M=1, one=False, greedy=False, cell=[1.0], d=1)
+        batch = 16
+    else:
+        skw = cases.sampling_ns(64, 2, M=1, cell=[11.084] * 3)
+        batch = 4
+    nkw = cases.noise_ns(5, **cases.LIN)
+    torch.manual_seed(4321)
+    net_cpu = _option_net(kind, edge_builder=nets.oracle_edge_builder)
+    outs = {}
+    for use_graph in (False, True):
+        net = _option_net(kind)
+        net.load_state_dict(net_cpu.state_dict())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            npar, spar = P["Noise"](**nkw), P["Sampling"](**skw, rng_mode="device", seed=99, use_hip_graph=use_graph)
+        gen = P["Langevin"](npar, spar, net.to(cuda))
+        with torch.no_grad():
+            outs[use_graph] = _np(gen.sample(batch, cuda))
+        assert gen.f16_range_fallbacks == 0
+        assert all(layer._chain[1] is not None for layer in net.egnn.graph_layers), "the fused edge chain did not run"
+        if kind == "all_options":
+            assert all(layer._chain[1].att_w is not None for layer in net.egnn.graph_layers)
+    assert np.array_equal(outs[False].A, outs[True].A)
+    assert np.array_equal(outs[False].X.view(np.int32), outs[True].X.view(np.int32))
+    ora = RS.OracleLangevinGenerator(npar, spar, net_cpu, noise=RS.PhiloxNoise(99, 0)).sample(batch)
+    assert np.array_equal(outs[True].A, ora.A) and (ora.A != spar.num_atom_types).all()
+    assert torus_rel_l2(outs[True].X, ora.X) < 1e-5
