@@ -550,7 +550,8 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
     def _run_loop(self, starting_noisy_composition: AXL, starting_step_index: int, ending_step_index: int) -> AXL:
         if self.fused_score_network:
             return self._sample_fused(starting_noisy_composition, starting_step_index, ending_step_index)
-        if self.use_hip_graph and getattr(self.noise_source, "device_rng", False) and not self.record:
+        if self.use_hip_graph and getattr(self.noise_source, "device_rng", False) and not self.record and \
+                self._network_is_capture_safe(starting_noisy_composition):
             return self._sample_with_graph(starting_noisy_composition, starting_step_index, ending_step_index)
         composition = starting_noisy_composition
         forces = torch.zeros_like(composition.X)
@@ -558,6 +559,22 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
         for i in range(starting_step_index - 1, max(ending_step_index, 0) - 1, -1):
             composition = self._guarded_iteration(composition, i, forces)
         return composition
+
+    def _network_is_capture_safe(self, composition: AXL) -> bool:
+        """A score network may say that its forward on this batch shape needs a host synchronisation (`capture_safe(batch,
+        atoms, device)`: EGNNScoreNetwork with a radius graph whose layers do not all run the fused edge chain, or whose
+        capacity-sized edge list does not fit) -- the iteration is then launched eagerly, with one warning, instead of failing
+        inside the capture.  Networks without the method are taken at the caller's word (use_hip_graph=True)."""
+        ask = getattr(self.axl_network, "capture_safe", None)
+        if ask is None:
+            return True
+        safe = bool(ask(composition.X.shape[0], composition.X.shape[1], composition.X.device))
+        if not safe and not getattr(self, "_warned_not_capturable", False):
+            import warnings
+            warnings.warn("use_hip_graph=True, but the score network's forward on this batch shape needs a host "
+                          "synchronisation: the sampler iteration is launched eagerly")
+            self._warned_not_capturable = True
+        return safe
 
     def _visits_at(self, index_i: int) -> int:
         """Passes through time index i: 1 + resampling steps, none at the last index (RePaint algorithm 1, t > 1)."""

@@ -231,36 +231,52 @@ class EGNNScoreNetwork(ScoreNetwork):
         if self.graph_status is None or self.graph_status.device != relative_coordinates.device:
             self.graph_status = torch.zeros(1, dtype=torch.int32, device=relative_coordinates.device)
         capacity = bsz * n * (n - 1)
-        width = max((layer.message_mlp[0].out_features for layer in self.egnn.graph_layers), default=0)
-        if relative_coordinates.is_cuda and not torch.is_grad_enabled() and capacity > 0 and \
-                all(layer.use_fused_ops and layer._edge_chain_pack() is not None for layer in self.egnn.graph_layers):
-            needed = capacity * 20 + (capacity // 16 + bsz * n) * width * 4
-            # (hipMemGetInfo is not allowed while a stream is capturing: the answer of the eager warm-up iterations that
-            # precede every capture of this shape is kept)
-            key = (str(relative_coordinates.device), capacity, width, self.static_edge_list_max_fraction)
-            decisions = self.__dict__.setdefault("_static_decisions", {})
-            if key not in decisions and not torch.cuda.is_current_stream_capturing():
-                # free = what the driver reports + what torch's caching allocator holds but has not handed out
-                free = torch.cuda.mem_get_info(relative_coordinates.device)[0] + torch.cuda.memory_reserved(
-                    relative_coordinates.device) - torch.cuda.memory_allocated(relative_coordinates.device)
-                decisions[key] = (needed <= self.static_edge_list_max_fraction * free, free)
-            fits, free = decisions.get(key, (True, 0))
-            if fits:
-                # clip, diagonal cell, cartesian positions, count, scan and fill behind one call (three launches)
-                edges, degree, offsets, n_edges = neighbors.get_edges_static_clipped(
-                    relative_coordinates, lattice_parameters.to(torch.float32), 2.2 * self.radial_cutoff, self.radial_cutoff,
-                    capacity, status=self.graph_status)
-                return edges, (degree, offsets, n_edges)
-            if not self._logged_two_call_switch:
-                import logging
-                logging.getLogger(__name__).warning(
-                    "EGNN radius graph: a capacity-sized edge list would take %.1f GB of the %.1f GB free on the device; using "
-                    "the two-call protocol (one host read per forward, the sampler iteration is not captured in a hipGraph)",
-                    needed / 2 ** 30, free / 2 ** 30)
-                self._logged_two_call_switch = True
+        if relative_coordinates.is_cuda and not torch.is_grad_enabled() and self._static_edge_list_fits(bsz, n, relative_coordinates.device):
+            # clip, diagonal cell, cartesian positions, count, scan and fill behind one call (three launches)
+            edges, degree, offsets, n_edges = neighbors.get_edges_static_clipped(
+                relative_coordinates, lattice_parameters.to(torch.float32), 2.2 * self.radial_cutoff, self.radial_cutoff,
+                capacity, status=self.graph_status)
+            return edges, (degree, offsets, n_edges)
         lengths = lattice_parameters[:, :d].clip(min=2.2 * self.radial_cutoff)       # "avoid box collapse" (:236-239)
         return neighbors.get_edges_with_radial_cutoff(relative_coordinates, torch.diag_embed(lengths), self.radial_cutoff,
                                                       status=self.graph_status, return_degree=True)
+
+    def _static_edge_list_fits(self, bsz: int, n: int, device) -> bool:
+        """May the radius graph of a [bsz, n] batch go into a capacity-sized list (no host read per forward)?  Every graph
+        layer must run the fused edge chain (nothing else then needs the edge count on the host) and the list must cost less
+        than `static_edge_list_max_fraction` of the device's free memory; the answer is kept per shape (hipMemGetInfo is not
+        allowed while a stream is capturing: the eager warm-up iterations that precede every capture ask first)."""
+        capacity = bsz * n * (n - 1)
+        if capacity <= 0 or not all(layer.use_fused_ops and layer._edge_chain_pack() is not None
+                                    for layer in self.egnn.graph_layers):
+            return False
+        width = max((layer.message_mlp[0].out_features for layer in self.egnn.graph_layers), default=0)
+        needed = capacity * 20 + (capacity // 16 + bsz * n) * width * 4
+        key = (str(device), capacity, width, self.static_edge_list_max_fraction)
+        decisions = self.__dict__.setdefault("_static_decisions", {})
+        if key not in decisions and not torch.cuda.is_current_stream_capturing():
+            # free = what the driver reports + what torch's caching allocator holds but has not handed out
+            free = torch.cuda.mem_get_info(device)[0] + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+            decisions[key] = (needed <= self.static_edge_list_max_fraction * free, free)
+        fits, free = decisions.get(key, (True, 0))
+        if not fits and not self._logged_two_call_switch:
+            import logging
+            logging.getLogger(__name__).warning(
+                "EGNN radius graph: a capacity-sized edge list would take %.1f GB of the %.1f GB free on the device; using "
+                "the two-call protocol (one host read per forward, the sampler iteration is not captured in a hipGraph)",
+                needed / 2 ** 30, free / 2 ** 30)
+            self._logged_two_call_switch = True
+        return fits
+
+    def capture_safe(self, batch_size: int, number_of_atoms: int, device) -> bool:
+        """Can a forward on a [batch_size, number_of_atoms] batch be captured into a hipGraph (no host synchronisation)?
+        What a generator asks before it captures its iteration (LangevinGenerator._run_loop): fully connected graphs always;
+        radius graphs when the capacity-sized edge list applies; a caller's own edge builder never (it is host code)."""
+        if self.edges == "fully_connected":
+            return True
+        if self.edge_builder is not None:
+            return False
+        return self._static_edge_list_fits(batch_size, number_of_atoms, torch.device(device))
 
     def _forward_unchecked(self, batch: Dict[AnyStr, torch.Tensor], conditional: bool = False) -> AXL:
         comp = batch[NOISY_AXL_COMPOSITION]

@@ -47,6 +47,11 @@ class ForceFieldAugmentedScoreNetwork(torch.nn.Module):
         if hasattr(self._score_network, "edge_chain_precision"):
             self._score_network.edge_chain_precision = value
 
+    def capture_safe(self, batch_size: int, number_of_atoms: int, device) -> bool:
+        """The pseudo-force needs the FULL periodic adjacency (with shifts), whose size is read on the host per forward: an
+        iteration around this wrapper is never captured into a hipGraph (LangevinGenerator then launches it eagerly)."""
+        return False
+
     def adapt_f16_range(self):
         adapt = getattr(self._score_network, "adapt_f16_range", None)
         if adapt is not None:

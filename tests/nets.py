@@ -89,6 +89,10 @@ class ScaledScore(torch.nn.Module):
     def graph_status(self):
         return getattr(self.net, "graph_status", None)
 
+    def capture_safe(self, batch_size, number_of_atoms, device):
+        ask = getattr(self.net, "capture_safe", None)
+        return True if ask is None else ask(batch_size, number_of_atoms, device)
+
     @property
     def edge_chain_precision(self):
         return getattr(self.net, "edge_chain_precision", None)

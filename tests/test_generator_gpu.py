@@ -1541,3 +1541,40 @@ def test_sampler_around_egnn_options_graph_eager_and_oracle(cuda, kind):
     ora = RS.OracleLangevinGenerator(npar, spar, net_cpu, noise=RS.PhiloxNoise(99, 0)).sample(batch)
     assert np.array_equal(outs[True].A, ora.A) and (ora.A != spar.num_atom_types).all()
     assert torus_rel_l2(outs[True].X, ora.X) < 1e-5
+
+
+def test_use_hip_graph_with_a_network_that_cannot_be_captured_runs_eagerly(cuda):
+    """`use_hip_graph: true` around a score network whose forward needs a host read -- an EGNN with a radius graph whose layer
+    width (48) is outside the fused edge chain's, so the edge list is sized after reading the edge count -- used to die inside
+    the capture (hipErrorStreamCaptureUnsupported).  The network now says so (`capture_safe`), the generator warns once and
+    launches the iteration eagerly: the same bits as a generator built with use_hip_graph=False."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import (
+        EGNNScoreNetwork, EGNNScoreNetworkParameters)
+    P = _pkg()
+    import warnings
+    outs = {}
+    for use_graph in (True, False):
+        torch.manual_seed(77)
+        net = EGNNScoreNetwork(EGNNScoreNetworkParameters(
+            num_atom_types=1, n_layers=2, coordinate_hidden_dimensions_size=48, coordinate_n_hidden_dimensions=1,
+            message_hidden_dimensions_size=48, message_n_hidden_dimensions=1, node_hidden_dimensions_size=48,
+            node_n_hidden_dimensions=1, edges="radial_cutoff", radial_cutoff=7.5)).eval().to(cuda)
+        assert not net.capture_safe(3, 64, cuda)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            npar = P["Noise"](**cases.noise_ns(4, **cases.LIN))
+            spar = P["Sampling"](**cases.sampling_ns(64, 1, M=1, one=False, greedy=False, cell=[10.86] * 3), rng_mode="device",
+                                 seed=5, use_hip_graph=use_graph)
+        gen = P["Langevin"](npar, spar, net)
+        with torch.no_grad():
+            if use_graph:
+                with pytest.warns(UserWarning, match="launched eagerly"):
+                    outs[use_graph] = _np(gen.sample(3, cuda))
+                with warnings.catch_warnings():
+                    warnings.simplefilter("error")               # (one warning per generator)
+                    gen.sample(3, cuda)
+            else:
+                outs[use_graph] = _np(gen.sample(3, cuda))
+        assert "graph_loop" not in gen._buffers
+    assert np.array_equal(outs[True].A, outs[False].A)
+    assert np.array_equal(outs[True].X.view(np.int32), outs[False].X.view(np.int32))
