@@ -1238,3 +1238,90 @@ def test_activation_scale_state_can_be_reset(cuda):
         s.exponents.fill_(2)
     net.reset_f16_range()
     assert all(int(s.exponents.min()) == 6 and int(s.exponents.max()) == 6 for s in scales)
+
+
+@pytest.mark.parametrize("precision", CHAIN_MODES)
+@pytest.mark.parametrize("H,n_msg,n_crd,n_nodes,deg", [(32, 1, 1, 40, 7), (64, 2, 3, 300, 11), (128, 3, 2, 500, 25),
+                                                        (256, 4, 5, 1200, 25), (256, 2, 2, 3, 2)])
+def test_edge_chain_attention_gate_against_fp64(cuda, precision, H, n_msg, n_crd, n_nodes, deg):
+    """The attention instantiations (ATT) of the chain kernel alone, against fp64: m_e <- m_e sigmoid(m_e . w_att + b_att)
+    between the message and the coordinate layers (models/egnn.py:148-160), the gate's weight scaled so that its logits have a
+    standard deviation of 1.5: the gate really varies between edges.  Ragged sorted edge list (degrees 0 .. 2 deg, not a multiple of the 128-edge tile), the
+    in-kernel message sums combined per node against the fp64 segment sums of the GATED messages, the head's scalar against the
+    fp64 coordinate MLP of the gated messages; a device-side edge count below the capacity leaves later rows untouched; the
+    rows mode is refused for an attention chain (MDX_ERR_UNSUPPORTED: the gate is instantiated for the piece sums)."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
+    g = torch.Generator().manual_seed(2000 * H + n_nodes)
+    n_in, D = 24, 6
+    torch.manual_seed(H + n_msg + 100)
+    lin0 = torch.nn.Linear(2 * n_in + 1, H)
+    msg = [torch.nn.Linear(H, H) for _ in range(n_msg)]
+    crd = [torch.nn.Linear(H, H) for _ in range(n_crd)]
+    out = torch.nn.Linear(H, 1, bias=False)
+    att = torch.nn.Linear(H, 1)
+    with torch.no_grad():
+        for layer in msg + crd:
+            layer.weight.mul_(1.7)
+    degree = torch.randint(0, 2 * deg, (n_nodes,), generator=g)
+    degree[0] = 0
+    degree[-1] = max(int(degree[-1]), 6)
+    src = torch.repeat_interleave(torch.arange(n_nodes), degree)
+    E = int(src.numel())
+    dst = torch.randint(0, n_nodes, (E,), generator=g)
+    edges = torch.stack([src, dst], 1)
+    h = torch.randn(n_nodes, n_in, generator=g)
+    coord = torch.rand(n_nodes, D, generator=g) * 2 - 1
+    # fp64 reference: messages, gate, gated messages -> coordinate MLP -> head; segment sums of the gated messages
+    f64, silu = torch.float64, torch.nn.functional.silu
+    diff = coord.to(f64)[src] - coord.to(f64)[dst]
+    x = torch.cat([h.to(f64)[src], h.to(f64)[dst], (diff ** 2).sum(1, keepdim=True)], dim=1)
+    x = silu(x @ lin0.weight.to(f64).t() + lin0.bias.to(f64))
+    for layer in msg:
+        x = silu(x @ layer.weight.to(f64).t() + layer.bias.to(f64))
+    with torch.no_grad():                       # spread the gate's logits to a standard deviation of 1.5: the gate must vary
+        x = x.detach()
+        att.weight.mul_(1.5 / float((x @ att.weight.to(f64).t()).std().clamp(min=1e-12)))
+        logit = x @ att.weight.to(f64).t() + att.bias.to(f64)
+    assert 1.0 < float(logit.std()) < 2.0
+    x = x * torch.sigmoid(logit)
+    y = x
+    for layer in crd:
+        y = silu(y @ layer.weight.to(f64).t() + layer.bias.to(f64))
+    want_s = (y @ out.weight.to(f64).t()).reshape(-1)
+    # (the head's scalar is a 256-term sum that cancels to a tenth or less of its terms in these random networks -- torch's own
+    # binary32 evaluation of the largest case is 8e-6 from fp64 in relative terms -- so its error is measured against the sum of
+    # the terms' magnitudes, the scale its rounding errors live on; the plain relative error gets a 20 x looser bar)
+    want_s_scale = (y.abs() @ out.weight.to(f64).abs().t()).reshape(-1)
+    want_sums = torch.zeros(n_nodes, H, dtype=f64).index_add_(0, src, x)
+
+    mods = [m.to(cuda) for m in [lin0] + msg + crd + [out, att]]
+    lin0_d, msg_d, crd_d, out_d, att_d = mods[0], mods[1:1 + n_msg], mods[1 + n_msg:-2], mods[-2], mods[-1]
+    pack = kernels.EdgeChainPack(lin0_d, msg_d, crd_d, out_d, input_size=n_in, precision=precision, attention_layer=att_d)
+    assert pack.att_w is not None and pack.piece_sums_ok
+    w = lin0_d.weight.detach()
+    proj = torch.nn.functional.linear(h.to(cuda), torch.cat([w[:, :n_in], w[:, n_in:2 * n_in]], 0)).contiguous()
+    status = torch.zeros(1, dtype=torch.int32, device=cuda)
+    coord_d, edges_d = coord.to(cuda).contiguous(), edges.to(cuda)
+    pieces, got_s = kernels.egnn_edge_chain(pack, proj, coord_d, edges_d, status=status, piece_sums=True)
+    degree_d = degree.to(cuda)
+    offsets_d = (torch.cumsum(degree_d, 0) - degree_d).contiguous()
+    got_sums = kernels.segment_combine(pieces, E, offsets_d, degree_d, False)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and torch.isfinite(got_s).all() and torch.isfinite(got_sums).all()
+    tol = TOLERANCE[precision]
+    err_s, err_m = _rel_l2(got_s, want_s), _rel_l2(got_sums, want_sums)
+    err_s_scaled = float((got_s.double().cpu() - want_s).norm() / want_s_scale.norm())
+    assert err_s_scaled < tol and err_s < 20 * tol and err_m < tol, (precision, H, err_s_scaled, err_s, err_m)
+    # ungated, the same chain gives something else (the gate is not a no-op in this test)
+    plain = kernels.EdgeChainPack(lin0_d, msg_d, crd_d, out_d, input_size=n_in, precision=precision)
+    _, plain_s = kernels.egnn_edge_chain(plain, proj, coord_d, edges_d, piece_sums=True)
+    assert _rel_l2(plain_s, want_s) > 1e-2
+    # a device-resident edge count below the capacity: the head's scalars beyond it are not written
+    if E > 5:
+        n_dev = torch.tensor([E - 5], dtype=torch.int64, device=cuda)
+        _, s2 = kernels.egnn_edge_chain(pack, proj, coord_d, edges_d, n_edges_dev=n_dev, piece_sums=True)
+        torch.cuda.synchronize()
+        assert torch.equal(s2[:E - 5], got_s[:E - 5])
+    # rows mode + attention: refused, not silently ungated
+    with pytest.raises(_hip.MdxError):
+        kernels.egnn_edge_chain(pack, proj, coord_d, edges_d, piece_sums=False)
