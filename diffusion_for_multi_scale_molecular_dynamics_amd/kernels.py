@@ -673,40 +673,73 @@ class ActivationScales:
         return (None, self.maxima.data_ptr()) if precision == "f32" else (self.exponents.data_ptr(), None)
 
 
+CHAIN_WIDTHS = (32, 64, 128, 256)       # the widths egnn_edge_chain_kernel is instantiated for
+
+
+def chain_width(*widths) -> int:
+    """The instantiated chain width that holds layers of these widths (0: none does)."""
+    need = max(widths)
+    return next((w for w in CHAIN_WIDTHS if w >= need), 0)
+
+
+def _pad2(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    w = w.detach().to(F32)
+    if tuple(w.shape) == (rows, cols):
+        return w.contiguous()
+    out = torch.zeros(rows, cols, dtype=F32, device=w.device)
+    out[:w.shape[0], :w.shape[1]] = w
+    return out
+
+
+def _pad1(v: torch.Tensor, n: int) -> torch.Tensor:
+    return _pad2(v.reshape(1, -1), 1, n).reshape(-1)
+
+
 class EdgeChainPack:
     """Device image of one E_GCL layer's per-edge MLP chain for mdx_egnn_edge_chain: the H -> H weight matrices of the
     message MLP (after its first layer) and of the coordinate MLP, re-laid out by mdx_egnn_chain_pack for `precision`,
     plus the small vectors.  Built from the modules' parameters at construction; `stamp` tells when to rebuild.
-    scales (ActivationScales, optional): shared with the layer's packs of the other precisions."""
+    scales (ActivationScales, optional): shared with the layer's packs of the other precisions.
+
+    Widths.  The kernel runs square layers of one width H in {32, 64, 128, 256}.  A message MLP of width m and a coordinate
+    MLP of width c (the reference's DEFAULT hyper-parameters are m = 16, c = 32: models/score_networks/egnn_score_network.py:
+    23-45) run at H = chain_width(m, c) with every matrix, bias and vector ZERO-PADDED: a padded neuron has zero weights and a
+    zero bias, so its pre-activation is 0, SiLU(0) = 0, and it feeds zeros on -- the same function, bit for bit in exact
+    arithmetic, at the price of multiplying zeros.  `hidden` = H, `message_width` = m: the message sums come out [.., H] with
+    columns m .. H-1 zero."""
 
     def __init__(self, first_message_layer, message_layers, coord_layers, coord_out_layer, input_size: int, precision: str,
                  scales=None, attention_layer=None):
-        """attention_layer: E_GCL.att_mlp's nn.Linear(H, 1) (its Sigmoid is the kernel's), or None."""
-        H = first_message_layer.out_features
+        """attention_layer: E_GCL.att_mlp's nn.Linear(m, 1) (its Sigmoid is the kernel's), or None."""
         dev = first_message_layer.weight.device
-        layers = list(message_layers) + list(coord_layers)
+        message_layers, coord_layers = list(message_layers), list(coord_layers)
+        layers = message_layers + coord_layers
         if precision not in EDGE_CHAIN_PRECISIONS:
             raise _hip.MdxError(f"edge-chain precision must be one of {sorted(EDGE_CHAIN_PRECISIONS)}; got {precision!r}")
         if not self.supported(first_message_layer, message_layers, coord_layers, coord_out_layer):
             raise _hip.MdxError("this E_GCL shape is not covered by the fused edge chain (see mdx_egnn_edge_chain)")
-        self.precision, self.hidden = precision, H
-        self.image, self.exponents = _pack_chain_image([layer.weight for layer in layers], coord_out_layer.weight, H, precision)
-        self.biases = torch.stack([layer.bias.detach().to(F32) for layer in layers]).contiguous()
-        self.bias_in = first_message_layer.bias.detach().to(F32).contiguous()
-        self.w_radial = first_message_layer.weight.detach()[:, 2 * input_size].to(F32).contiguous()
+        m = first_message_layer.out_features
+        H = chain_width(m, coord_out_layer.in_features)
+        self.precision, self.hidden, self.message_width = precision, H, m
+        self.image, self.exponents = _pack_chain_image([_pad2(layer.weight, H, H) for layer in layers],
+                                                       _pad1(coord_out_layer.weight, H), H, precision)
+        self.biases = torch.stack([_pad1(layer.bias, H) for layer in layers]).contiguous()
+        self.bias_in = _pad1(first_message_layer.bias, H)
+        self.w_radial = _pad1(first_message_layer.weight.detach()[:, 2 * input_size], H)
         # [2H, n_in]: the per-node projections of the first message layer (source half | destination half) as ONE matrix
         w0 = first_message_layer.weight.detach().to(F32)
-        self.proj_weight = torch.cat([w0[:, :input_size], w0[:, input_size:2 * input_size]], dim=0).contiguous()
+        self.proj_weight = torch.cat([_pad2(w0[:, :input_size], H, input_size),
+                                      _pad2(w0[:, input_size:2 * input_size], H, input_size)], dim=0).contiguous()
         self.scales = scales
         act = scales.pointers(precision) if scales is not None else (None, None)
         assert scales is None or scales.count == len(layers) + 2
         self.att_w = self.att_b = None
         if attention_layer is not None:
-            if attention_layer.in_features != H or attention_layer.out_features != 1 or attention_layer.bias is None:
-                raise _hip.MdxError("the attention gate of the fused edge chain is nn.Linear(H, 1) with a bias")
-            self.att_w = attention_layer.weight.detach().to(F32).reshape(-1).contiguous()
+            if attention_layer.in_features != m or attention_layer.out_features != 1 or attention_layer.bias is None:
+                raise _hip.MdxError("the attention gate of the fused edge chain is nn.Linear(message width, 1) with a bias")
+            self.att_w = _pad1(attention_layer.weight, H)
             self.att_b = attention_layer.bias.detach().to(F32).reshape(-1).contiguous()
-        self.c_struct = _hip.EgnnChain(H, len(list(message_layers)), len(list(coord_layers)),
+        self.c_struct = _hip.EgnnChain(H, len(message_layers), len(coord_layers),
                                        EDGE_CHAIN_PRECISIONS[precision], 0, 0, self.image.data_ptr(),
                                        self.biases.data_ptr(), self.bias_in.data_ptr(), self.w_radial.data_ptr(),
                                        self.exponents.data_ptr(), *act,
@@ -721,12 +754,18 @@ class EdgeChainPack:
 
     @staticmethod
     def supported(first_message_layer, message_layers, coord_layers, coord_out_layer) -> bool:
-        H = first_message_layer.out_features
-        layers = list(message_layers) + list(coord_layers)
-        return (H in (32, 64, 128, 256) and len(list(message_layers)) >= 1 and len(list(coord_layers)) >= 1 and
-                len(layers) <= _hip.EGNN_CHAIN_MAX_LAYERS and
-                all(l.in_features == H and l.out_features == H and l.bias is not None for l in layers) and
-                first_message_layer.bias is not None and coord_out_layer.in_features == H and
+        """nn.Linear stacks m -> m (message, after the first layer), m -> c -> c ... (coordinate), c -> 1 without a bias (head),
+        with chain_width(m, c) an instantiated width."""
+        message_layers, coord_layers = list(message_layers), list(coord_layers)
+        if len(message_layers) < 1 or len(coord_layers) < 1 or \
+                len(message_layers) + len(coord_layers) > _hip.EGNN_CHAIN_MAX_LAYERS:
+            return False
+        m, c = first_message_layer.out_features, coord_out_layer.in_features
+        widths_in = [m] * len(message_layers) + [m] + [c] * (len(coord_layers) - 1)
+        widths_out = [m] * len(message_layers) + [c] * len(coord_layers)
+        return (chain_width(m, c) != 0 and first_message_layer.bias is not None and
+                all(l.in_features == i and l.out_features == o and l.bias is not None
+                    for l, i, o in zip(message_layers + coord_layers, widths_in, widths_out)) and
                 coord_out_layer.out_features == 1 and coord_out_layer.bias is None)
 
 

@@ -15,7 +15,8 @@ get_edges_batch produce):
     csrc/mdx_egnn_chain.hip) that keeps the [E, H] activations in registers between layers; `tanh` and `normalize` act in
     the per-node kernel that adds the coordinate updates up; `edge_chain_precision` selects exact binary32 MFMA ("f32") or
     the split-f16 three-product form ("f16x3"); None keeps the per-layer PyTorch path (also taken for shapes the kernel does
-    not cover: widths outside {32, 64, 128, 256}, message and coordinate MLPs of different width, other activations).
+    not cover: widths above 256, other activations).  Narrow and unequal message / coordinate widths (the reference's defaults
+    are 16 / 32) run on the chain zero-padded to its next width.
 
 The HIP calls are invisible to autograd, so they are used only when no gradient can be requested (torch.no_grad(), or
 nothing requires grad); with autograd on, the module runs as plain PyTorch.  Callers that pass their own edge list
@@ -264,7 +265,7 @@ class E_GCL(nn.Module):
         next_pack = next_layer._edge_chain_pack() if next_layer is not None and next_layer.use_fused_ops else None
         projection = None
         if next_pack is not None and tuple(next_pack.proj_weight.shape) == (2 * linears[0].out_features, linears[0].out_features) \
-                and next_pack.hidden == linears[0].out_features:
+                and next_pack.hidden == linears[0].out_features and next_pack.message_width == next_pack.hidden:
             projection = next_pack.proj_weight
         first_next = next_layer.message_mlp[0].weight if projection is not None else None
         stamp = (self.edge_chain_precision,) + tuple((t.data_ptr(), t._version) for lin in linears for t in (lin.weight, lin.bias)) + \
@@ -347,7 +348,15 @@ class E_GCL(nn.Module):
         in_kernel = pack.piece_sums_ok and h.shape[0] < (1 << 31)
         messages, edge_scalar = kernels.egnn_edge_chain(pack, proj.contiguous(), coord, edge_index, status=self.status_word,
                                                         n_edges_dev=n_edges, piece_sums=in_kernel)
-        if in_kernel and h.shape[1] == messages.shape[1] and coord.shape[1] <= 8:
+        padded = pack.message_width != pack.hidden      # a narrow / unequal-width layer run zero-padded (kernels.EdgeChainPack)
+        if padded:
+            # the message sums come out [n_nodes, H] with columns message_width .. H-1 zero: the node MLP takes the real ones
+            coord_out = kernels.egnn_coord_aggregate(edge_scalar, coord, edge_index, offsets, degree, self.coords_mean,
+                                                     flags=self._coord_flags())
+            agg = (kernels.segment_combine(messages, edge_index.shape[0], offsets, degree, self.message_mean) if in_kernel
+                   else kernels.segment_rows(messages, offsets, degree, self.message_mean))
+            node_in = torch.cat([h, agg[:, :pack.message_width]], dim=1)
+        elif in_kernel and h.shape[1] == messages.shape[1] and coord.shape[1] <= 8:
             whole = self._node_mlp_pack(next_layer)
             if whole is not None and whole.hidden == h.shape[1]:
                 # everything per node between the edge chain and the node MLP in one pass (the message sums and the updated

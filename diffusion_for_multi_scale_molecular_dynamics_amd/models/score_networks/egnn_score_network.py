@@ -250,7 +250,7 @@ class EGNNScoreNetwork(ScoreNetwork):
         if capacity <= 0 or not all(layer.use_fused_ops and layer._edge_chain_pack() is not None
                                     for layer in self.egnn.graph_layers):
             return False
-        width = max((layer.message_mlp[0].out_features for layer in self.egnn.graph_layers), default=0)
+        width = max((layer._edge_chain_pack().hidden for layer in self.egnn.graph_layers), default=0)
         needed = capacity * 20 + (capacity // 16 + bsz * n) * width * 4
         key = (str(device), capacity, width, self.static_edge_list_max_fraction)
         decisions = self.__dict__.setdefault("_static_decisions", {})

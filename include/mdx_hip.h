@@ -391,7 +391,9 @@ MDX_API int mdx_segment_rows(const float* data, const int64_t* offsets, const in
  *   y   = SiLU(y W_l^T + b_l), l = n_message_layers .. +n_coord_layers-1    (coordinate MLP, all its H -> H layers)
  *   edge_scalar_out[e] = y . w_out                                          (its last layer, Linear(H, 1, bias=False))
  * The [E,H] activations stay in registers between layers (accumulator tile == next layer's MFMA operand).
- * hidden in {32, 64, 128, 256}; message and coordinate MLPs of equal width; SiLU activations.  E_GCL's options
+ * hidden in {32, 64, 128, 256}; message and coordinate MLPs of equal width (a caller with narrower or unequal widths passes
+ * zero-padded matrices, biases and vectors: a padded neuron computes SiLU(0) = 0 and feeds zeros on -- what the Python host
+ * side does for the reference's default widths 16 / 32); SiLU activations.  E_GCL's options
  * (models/egnn.py:128-135, 148-160, 234-264):
  *   attention  attention_weight [H] / attention_bias [1] (device, both or neither): the messages are gated,
  *              m_e <- m_e sigmoid(m_e . attention_weight + attention_bias), between the message and the coordinate layers --

@@ -1181,6 +1181,7 @@ def golden_egnn_options_wide():
       attention_256   attention + tanh at the production width: 2 graph layers x 256 wide x 2 hidden layers, radial cutoff 7.5,
                       two atom types, N = 64, 3 structures (formula scale 2: the gate's logit then varies between edges)
       normalize_128   normalize + attention, 2 x 128 x 3, sum aggregations, N = 64, 3 structures
+      default_widths, unequal_48_96   narrow / unequal message and coordinate widths (see below)
     Each with the module's binary64 output on the same inputs."""
     sys.path.insert(0, os.path.dirname(HERE))
     from formula_weights import fill_with_formula
@@ -1227,7 +1228,19 @@ def golden_egnn_options_wide():
                                    edges="radial_cutoff", radial_cutoff=7.5)
     record("normalize_128", p, 1.5, torch.randint(0, 3, (B, N), generator=g), torch.rand(B, N, 3, generator=g), L,
            torch.rand(B, 1, generator=g) * 0.2)
-    out["names"] = np.array(["template_1d", "attention_256", "normalize_128"])
+    # narrow and unequal widths (run zero-padded on the chain: kernels.EdgeChainPack): the reference's DEFAULT hyper-parameters
+    # (egnn_score_network.py:23-45: message 16 x 1, node 32 x 1, coordinate 32 x 1, 4 graph layers), and message 48 / coordinate
+    # 96 / node 64 with attention + tanh
+    p = EGNNScoreNetworkParameters(num_atom_types=2, edges="radial_cutoff", radial_cutoff=7.5)
+    record("default_widths", p, 2.0, torch.randint(0, 3, (B, N), generator=g), torch.rand(B, N, 3, generator=g), L,
+           torch.rand(B, 1, generator=g) * 0.2)
+    p = EGNNScoreNetworkParameters(num_atom_types=2, n_layers=2, coordinate_hidden_dimensions_size=96,
+                                   coordinate_n_hidden_dimensions=2, message_hidden_dimensions_size=48,
+                                   message_n_hidden_dimensions=2, node_hidden_dimensions_size=64, node_n_hidden_dimensions=2,
+                                   attention=True, tanh=True, edges="radial_cutoff", radial_cutoff=7.5)
+    record("unequal_48_96", p, 2.0, torch.randint(0, 3, (B, N), generator=g), torch.rand(B, N, 3, generator=g), L,
+           torch.rand(B, 1, generator=g) * 0.2)
+    out["names"] = np.array(["template_1d", "attention_256", "normalize_128", "default_widths", "unequal_48_96"])
     save("net_egnn_options_wide.npz", **out)
 
 

@@ -358,12 +358,14 @@ def test_egnn_option_variants_on_the_gpu_against_reference(cuda, name, precision
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3_32x32"])
-@pytest.mark.parametrize("name", ["template_1d", "attention_256", "normalize_128"])
+@pytest.mark.parametrize("name", ["template_1d", "attention_256", "normalize_128", "default_widths", "unequal_48_96"])
 def test_egnn_options_at_kernel_widths_on_the_gpu_against_reference(cuda, name, precision):
     """The options at the widths 128 and 256 (tests/golden/make_golden.py::golden_egnn_options_wide): the reference's shipped
     1-D template (normalize=True, hidden 128, spatial dimension 1: coordinates of dimension D = 2 in the chain), attention + tanh
-    at 256 (the ATT instantiation of the production-width kernel), attention + normalize with sum aggregations at 128 --
-    scores <= 1e-5 against the reference's output, logits close, the fused chain in every graph layer."""
+    at 256 (the ATT instantiation of the production-width kernel), attention + normalize with sum aggregations at 128; and
+    NARROW / UNEQUAL widths, which the chain runs zero-padded to its next width (kernels.EdgeChainPack): the reference's default
+    hyper-parameters (message 16, node 32, coordinate 32 -> chain width 32) and message 48 / coordinate 96 / node 64 with
+    attention + tanh (-> 128) -- scores <= 1e-5 against the reference's output, logits close, the fused chain in every layer."""
     from test_host_cpu import wide_option_case
     g = load_golden("net_egnn_options_wide.npz")
     net, batch = wide_option_case(g, name, device=cuda)

@@ -1545,7 +1545,7 @@ def test_sampler_around_egnn_options_graph_eager_and_oracle(cuda, kind):
 
 def test_use_hip_graph_with_a_network_that_cannot_be_captured_runs_eagerly(cuda):
     """`use_hip_graph: true` around a score network whose forward needs a host read -- an EGNN with a radius graph whose layer
-    width (48) is outside the fused edge chain's, so the edge list is sized after reading the edge count -- used to die inside
+    width (288) is beyond the fused edge chain's widths, so the edge list is sized after reading the edge count -- used to die inside
     the capture (hipErrorStreamCaptureUnsupported).  The network now says so (`capture_safe`), the generator warns once and
     launches the iteration eagerly: the same bits as a generator built with use_hip_graph=False."""
     from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import (
@@ -1556,8 +1556,8 @@ def test_use_hip_graph_with_a_network_that_cannot_be_captured_runs_eagerly(cuda)
     for use_graph in (True, False):
         torch.manual_seed(77)
         net = EGNNScoreNetwork(EGNNScoreNetworkParameters(
-            num_atom_types=1, n_layers=2, coordinate_hidden_dimensions_size=48, coordinate_n_hidden_dimensions=1,
-            message_hidden_dimensions_size=48, message_n_hidden_dimensions=1, node_hidden_dimensions_size=48,
+            num_atom_types=1, n_layers=2, coordinate_hidden_dimensions_size=288, coordinate_n_hidden_dimensions=1,
+            message_hidden_dimensions_size=288, message_n_hidden_dimensions=1, node_hidden_dimensions_size=32,
             node_n_hidden_dimensions=1, edges="radial_cutoff", radial_cutoff=7.5)).eval().to(cuda)
         assert not net.capture_safe(3, 64, cuda)
         with warnings.catch_warnings():

@@ -489,6 +489,11 @@ WIDE_OPTIONS = {
                            message_hidden_dimensions_size=128, message_n_hidden_dimensions=3, node_hidden_dimensions_size=128,
                            node_n_hidden_dimensions=3, attention=True, normalize=True, coords_agg="sum", message_agg="sum",
                            edges="radial_cutoff", radial_cutoff=7.5), 1.5),
+    # narrow / unequal widths: the reference's default hyper-parameters (message 16, node 32, coordinate 32); 48 / 64 / 96
+    "default_widths": (dict(num_atom_types=2, edges="radial_cutoff", radial_cutoff=7.5), 2.0),
+    "unequal_48_96": (dict(num_atom_types=2, n_layers=2, coordinate_hidden_dimensions_size=96, coordinate_n_hidden_dimensions=2,
+                           message_hidden_dimensions_size=48, message_n_hidden_dimensions=2, node_hidden_dimensions_size=64,
+                           node_n_hidden_dimensions=2, attention=True, tanh=True, edges="radial_cutoff", radial_cutoff=7.5), 2.0),
 }
 
 
