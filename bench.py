@@ -445,16 +445,14 @@ class CardSensor:
     Values are None where the sensor files are absent or unreadable (nothing is guessed)."""
 
     def __init__(self, device_index):
-        import ctypes
         import glob
         self.power, self.cap, self.sclk, self.bdf = None, None, None, None
         self.samples, self.clocks, self._stop, self._thread = [], [], False, None
         try:
-            hip = ctypes.CDLL("libamdhip64.so")
-            buf = ctypes.create_string_buffer(64)
-            if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0:
-                self.bdf = buf.value.decode().lower()
-        except OSError:
+            # the card's PCI address from torch's own device properties (no second handle on the HIP runtime)
+            p = torch.cuda.get_device_properties(int(device_index))
+            self.bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        except (AttributeError, RuntimeError, AssertionError):
             pass
         if self.bdf is None:
             return
