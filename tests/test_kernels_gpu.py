@@ -556,3 +556,44 @@ def test_updates_with_device_scalars_equal_host_scalars(cuda):
                            kernels.relative_coordinates_update(x, s, z, w32, n32, s32))
         assert torch.equal(kernels.lattice_parameters_update(x, s, z, weights=weights),
                            kernels.lattice_parameters_update(x, s, z, w32, n32, s32))
+
+
+def test_plain_c_consumer_of_the_abi(K, cuda, tmp_path):
+    """The boundary is a C ABI: tests/c_abi/abi_consumer.c -- plain C, no Python, no torch -- is compiled against
+    include/mdx_hip.h and libmdx_hip.so, builds configs[2]'s schedule tables (S1) and wraps six coordinates (F1) through the
+    entry points exactly as another host language would, and the file it writes equals the reference-made fixture bit for bit
+    (the linear schedule: time, sigma, sigma^2, g^2, beta, alpha_bar, the three matrix tables; g / epsilon within the stated
+    ulp) and the Python binding's output of the same call in every bit."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("no C compiler / ROCm headers on this machine")
+    exe, out = str(tmp_path / "abi_consumer"), str(tmp_path / "tables.bin")
+    libdir = os.path.dirname(_hip.LIB_PATH)
+    # plain gcc, C11: the HIP runtime's host API (hipMalloc, hipMemcpy) from its C header, the library from its own
+    build = subprocess.run([gcc, "-std=c11", "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "c_abi", "abi_consumer.c"),
+                            "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", "-L", libdir, "-lmdx_hip",
+                            "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
+                           capture_output=True, text=True, timeout=300)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe, out], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    data = np.fromfile(out, dtype=np.float32)
+    T, C = 1000, 2
+    assert data.size == 9 * T + 3 * T * C * C + 6
+    names = ["time", "sigma", "sigma_squared", "g", "g_squared", "epsilon", "sqrt_2_epsilon", "beta", "alpha_bar"]
+    got = {n: data[k * T:(k + 1) * T] for k, n in enumerate(names)}
+    for k, n in enumerate(["q_matrix", "q_bar_matrix", "q_bar_tm1_matrix"]):
+        got[n] = data[9 * T + k * T * C * C: 9 * T + (k + 1) * T * C * C].reshape(T, C, C)
+    g = load_golden("schedules.npz")
+    for key in ("time", "sigma", "sigma_squared", "g_squared", "beta", "alpha_bar", "q_matrix", "q_bar_matrix", "q_bar_tm1_matrix"):
+        assert np.array_equal(got[key], g[f"c3_T1000_lin/{key}"]), key                     # bit-exact against the reference
+    assert ulp_diff(got["g"], g["c3_T1000_lin/g"]).max() <= 1 and ulp_diff(got["epsilon"], g["c3_T1000_lin/epsilon"]).max() <= 1
+    s = K.noise_schedule_build(T, "linear", 1e-5, 1e-4, 0.2, 2.5e-8, C, cuda)                # the Python binding: the same bits
+    for key in names + ["q_matrix", "q_bar_matrix", "q_bar_tm1_matrix"]:
+        assert np.array_equal(got[key].view(np.int32), getattr(s, key).cpu().numpy().view(np.int32)), key
+    assert np.array_equal(data[-6:], np.array([0.0, 0.0, 0.0, 0.75, 0.75, 0.5], dtype=np.float32))
