@@ -1400,6 +1400,9 @@ __global__ __launch_bounds__(kWaves* kWave, 1) void egnn_edge_chain_kernel(Chain
                 if constexpr (ATT) {
                     if (l == p.n_message) {
                         gate_messages(in, l);
+                        // (like the aggregation phase: the next tile's prefetched fragments and initial accumulator are read
+                        // again from LDS behind the gate instead of being kept live across it -- 48 registers the gate needs)
+                        reload_prefetch(par + l * H);
                         layer(std::true_type{}, in, out, l);
                     } else {
                         layer(std::false_type{}, in, out, l);
