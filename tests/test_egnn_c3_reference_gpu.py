@@ -191,7 +191,7 @@ def _shape_of(name):
     return cases.shape_of(name)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3_32x32"])
 @pytest.mark.parametrize("name", C3_C4_TRAJECTORIES)
 def test_c3_teacher_forced_steps(cuda, name, precision, record_property):
     """Every recorded step of the reference at production width, from the reference's composition with the reference's draws:
