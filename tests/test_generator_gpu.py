@@ -958,7 +958,7 @@ def test_fused_sampler_padded_family_equals_generic_folded(cuda, shape, variant)
 
 
 def test_egnn_fused_ops_equal_plain_torch(cuda):
-    """The EGNN forward with the fused helpers (hipBLASLt bias+SiLU epilogue, fused first message layer) against the
+    """The EGNN forward with the fused helpers (fused first message layer, sorted-segment reductions, the MFMA chains) against the
     same module with plain PyTorch ops, radius-graph edges, experiment-like widths."""
     from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE,
                                                                               NOISY_AXL_COMPOSITION, TIME)
