@@ -247,6 +247,8 @@ class EGNNScoreNetwork(ScoreNetwork):
         than `static_edge_list_max_fraction` of the device's free memory; the answer is kept per shape (hipMemGetInfo is not
         allowed while a stream is capturing: the eager warm-up iterations that precede every capture ask first)."""
         capacity = bsz * n * (n - 1)
+        if self.spatial_dimension != 3:      # (1-D / 2-D radius graphs go through the padded two-call search: utils/neighbors.py)
+            return False
         if capacity <= 0 or not all(layer.use_fused_ops and layer._edge_chain_pack() is not None
                                     for layer in self.egnn.graph_layers):
             return False

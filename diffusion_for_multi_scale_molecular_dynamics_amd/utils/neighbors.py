@@ -38,6 +38,25 @@ def _raise_if_cutoff_too_large(status: torch.Tensor):
         raise MdxError("radius graph: the edge list outgrew its capacity and the retry did not run (internal error)")
 
 
+def embed_in_three_dimensions(cartesian_positions: torch.Tensor, basis_vectors: torch.Tensor, radial_cutoff: float):
+    """(positions [B, N, 3], cell [B, 3, 3]) of a 1- or 2-dimensional periodic problem for the three-dimensional radius-graph
+    kernel: the missing coordinates are zero and the missing cell vectors are orthogonal ones of length 4 x cutoff, so every
+    periodic image along them is beyond the cutoff and the shortest cell-crossing distance (the "cutoff too large" check:
+    neighbors.py:107-113, 248-351) is decided by the real vectors -- the same edges, shifts (their first d components) and
+    check as the reference's d-dimensional search (neighbors.py:36-224 takes spatial_dimension in {1, 2, 3}).  Three-dimensional
+    inputs pass through."""
+    batch_size, natom, d = cartesian_positions.shape
+    if d == 3:
+        return cartesian_positions.contiguous(), basis_vectors.contiguous()
+    positions = torch.zeros(batch_size, natom, 3, dtype=cartesian_positions.dtype, device=cartesian_positions.device)
+    positions[..., :d] = cartesian_positions
+    cell = torch.zeros(batch_size, 3, 3, dtype=basis_vectors.dtype, device=basis_vectors.device)
+    cell[:, :d, :d] = basis_vectors
+    for k in range(d, 3):
+        cell[:, k, k] = 4.0 * float(radial_cutoff)
+    return positions, cell
+
+
 def get_periodic_adjacency_information(cartesian_positions: torch.Tensor, basis_vectors: torch.Tensor,
                                        radial_cutoff: float, spatial_dimension: int = 3,
                                        check_cutoff: bool = True) -> AdjacencyInfo:
@@ -45,12 +64,14 @@ def get_periodic_adjacency_information(cartesian_positions: torch.Tensor, basis_
     assert cartesian_positions.dim() == 3, "Wrong number of dimensions for relative_coordinates"
     assert basis_vectors.dim() == 3, "Wrong number of dimensions for basis_vectors"
     batch_size, natom, d = cartesian_positions.shape
-    assert d == spatial_dimension == 3, "the HIP radius-graph kernel is three-dimensional"
-    assert basis_vectors.shape == (batch_size, 3, 3), "Wrong shape for basis vectors"
+    assert d == spatial_dimension and d in (1, 2, 3), "The spatial dimension must be 1, 2 or 3."
+    assert basis_vectors.shape == (batch_size, d, d), "Wrong shape for basis vectors"
     assert radial_cutoff > 0.0, "The radial cutoff should be greater than zero"
     status = _new_status(cartesian_positions.device) if check_cutoff else None
-    out = kernels.radius_graph(cartesian_positions.contiguous(), basis_vectors.contiguous(), radial_cutoff,
-                               unique=False, status=status)
+    positions3, cell3 = embed_in_three_dimensions(cartesian_positions, basis_vectors, radial_cutoff)
+    out = kernels.radius_graph(positions3, cell3, radial_cutoff, unique=False, status=status)
+    if d < 3:
+        out = dict(out, shifts=out["shifts"][:, :d].contiguous())
     if check_cutoff:
         _raise_if_cutoff_too_large(status)
     number_of_edges = out["counts"].sum(dim=1)
@@ -94,7 +115,8 @@ def get_edges_with_radial_cutoff(relative_coordinates: torch.Tensor, unit_cell: 
     if drop_duplicate_edges:
         own = status is None
         st = _new_status(cart.device) if own else status
-        out = kernels.radius_graph(cart, unit_cell.contiguous(), radial_cutoff, unique=True, status=st)
+        cart3, cell3 = embed_in_three_dimensions(cart, unit_cell, radial_cutoff)        # (1-D / 2-D: see there)
+        out = kernels.radius_graph(cart3, cell3, radial_cutoff, unique=True, status=st)
         if own:
             _raise_if_cutoff_too_large(st)
         if return_degree:

@@ -226,7 +226,11 @@ MDX_API int mdx_forward_diffusion_step(const mdx_schedule_t* sched_host, int ind
  * unique = 1: one edge per (src,dst) pair whatever the image (torch.unique(dim=1) of the reference), edges
  *             [E,2] int64 with batch-global node indices (b*N + i); image_out unused.
  * unique = 0: one edge per (src,dst,image); edges [E,2] with per-structure indices, image_out[E] in 0..26
- *             (itertools.product(-1,0,1) order, utils/lattice_utils.py:10-29), shifts_out [E,3] (nullable). */
+ *             (itertools.product(-1,0,1) order, utils/lattice_utils.py:10-29), shifts_out [E,3] (nullable).
+ * Positions [B,N,3] and cells [B,3,3].  The reference takes spatial_dimension 1, 2 or 3: a caller with fewer dimensions
+ * embeds its problem -- zero coordinates and orthogonal cell vectors of 4 x cutoff in the missing dimensions: no periodic
+ * image along them is within the cutoff, the cutoff-too-large status is decided by the real vectors -- and keeps the first
+ * d components of the shifts (what the Python host side does: utils/neighbors.py::embed_in_three_dimensions). */
 MDX_API int mdx_radius_graph_count(const float* cartesian_positions, const float* basis_vectors, float radial_cutoff,
                            int64_t batch, int number_of_atoms, int unique, int64_t* counts, uint32_t* status,
                            mdx_stream_t stream);

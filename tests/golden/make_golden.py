@@ -1172,6 +1172,55 @@ def golden_egnn_variants():
     save("net_egnn_variants.npz", **out)
 
 
+def golden_low_dimensions():
+    """The reference's neighbour search and EGNN in ONE and TWO dimensions (utils/neighbors.py:36-224 takes spatial_dimension in
+    {1, 2, 3}; the reference's own tests run both there: tests/utils/test_neighbors.py:239-260,
+    tests/models/score_network/test_score_network_general_tests.py:335-371):
+      low_dimensions.npz   d1 / d2: get_periodic_adjacency_information on random positions in a 1-D cell and in slightly sheared
+                           2-D cells (adjacency, shifts, edge counts, canonically sorted), get_edges_with_radial_cutoff's unique
+                           edge list, and the smallest cell-crossing distance (for the cutoff-too-large check);
+                           egnn_d1 / egnn_d2: EGNNScoreNetwork (hidden 32, 2 layers, radial cutoff 3.0, formula weights at scale
+                           1.5) forward on 4 structures of 6 / 12 atoms in cells of 7 - 10."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from formula_weights import fill_with_formula
+    from diffusion_for_multi_scale_molecular_dynamics.utils.neighbors import _get_shortest_distance_that_crosses_unit_cell
+    g = torch.Generator().manual_seed(1212)
+    out = {}
+    B = 4
+    for d, N, rc in ((1, 6, 2.5), (2, 12, 3.0)):
+        name = f"d{d}"
+        X = torch.rand(B, N, d, generator=g)
+        cell = torch.diag_embed(7.0 + 3.0 * torch.rand(B, d, generator=g)) + (0.3 * (torch.rand(B, d, d, generator=g) - 0.5) if d > 1 else 0.0)
+        cart = torch.matmul(X, cell)
+        info = get_periodic_adjacency_information(cart, cell, rc, spatial_dimension=d)
+        adj, eb, shifts = _np(info.adjacency_matrix), _np(info.edge_batch_indices), _np(info.shifts)
+        key = np.lexsort(tuple(shifts[:, k] for k in reversed(range(d))) + (adj[1], adj[0], eb))
+        out[f"{name}/X"], out[f"{name}/cell"], out[f"{name}/cart"], out[f"{name}/rc"] = _np(X), _np(cell), _np(cart), np.array(rc)
+        out[f"{name}/adj_sorted"] = adj[:, key].astype(np.int32)
+        out[f"{name}/edge_batch_sorted"] = eb[key].astype(np.int32)
+        out[f"{name}/shifts_sorted"] = shifts[key]
+        out[f"{name}/number_of_edges"] = _np(info.number_of_edges)
+        out[f"{name}/unique_edges"] = _np(get_edges_with_radial_cutoff(X, cell, rc, drop_duplicate_edges=True,
+                                                                       spatial_dimension=d)).astype(np.int32)
+        out[f"{name}/shortest_crossing"] = _np(_get_shortest_distance_that_crosses_unit_cell(cell, spatial_dimension=d))
+        # the network on the same kind of structures (orthogonal cell: lattice parameters = the lengths, angles zero)
+        p = EGNNScoreNetworkParameters(spatial_dimension=d, num_atom_types=1, n_layers=2, coordinate_hidden_dimensions_size=32,
+                                       coordinate_n_hidden_dimensions=2, message_hidden_dimensions_size=32,
+                                       message_n_hidden_dimensions=2, node_hidden_dimensions_size=32, node_n_hidden_dimensions=2,
+                                       edges="radial_cutoff", radial_cutoff=3.0)
+        net = fill_with_formula(EGNNScoreNetwork(p).eval(), scale=1.5)
+        lengths = 7.0 + 3.0 * torch.rand(B, d, generator=g)
+        L = torch.cat([lengths, torch.zeros(B, d * (d + 1) // 2 - d)], dim=1)
+        Xn, A = torch.rand(B, N, d, generator=g), torch.randint(0, 2, (B, N), generator=g)
+        batch = {NOISY_AXL_COMPOSITION: AXL(A=A, X=Xn, L=L), TIME: torch.rand(B, 1, generator=g),
+                 NOISE: torch.rand(B, 1, generator=g) * 0.2, CARTESIAN_FORCES: torch.zeros_like(Xn)}
+        with torch.no_grad():
+            o = net(batch, conditional=False)
+        for key_, val in (("A", A), ("X", Xn), ("L", L), ("time", batch[TIME]), ("noise", batch[NOISE]), ("out_A", o.A), ("out_X", o.X)):
+            out[f"egnn_{name}/{key_}"] = _np(val)
+    save("low_dimensions.npz", **out)
+
+
 def golden_egnn_options_wide():
     """E_GCL's options at the widths the hand-written kernels are instantiated for beyond 32 (formula weights, so no state_dict is
     stored; tests/formula_weights.py):
@@ -1292,3 +1341,5 @@ if __name__ == "__main__":
         golden_egnn_variants()
     if which in ("all", "options_wide"):
         golden_egnn_options_wide()
+    if which in ("all", "low_dimensions"):
+        golden_low_dimensions()

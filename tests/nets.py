@@ -68,7 +68,16 @@ def oracle_edge_builder(relative_coordinates, unit_cell, radial_cutoff):
     """CPU edge list from the oracle's radius graph, so the product's EGNN module can run on CPU tensors in tests."""
     from oracle import mdx_oracle as O
     cart = torch.matmul(relative_coordinates, unit_cell).cpu().numpy()
-    r = O.radius_graph(cart, unit_cell.cpu().numpy(), radial_cutoff, unique=True)
+    cell = unit_cell.cpu().numpy()
+    d = cart.shape[-1]
+    if d < 3:       # the oracle's search is three-dimensional: embed (zero coordinates, orthogonal cell vectors of 4 x cutoff)
+        cart = np.concatenate([cart, np.zeros(cart.shape[:-1] + (3 - d,), cart.dtype)], axis=-1)
+        full = np.zeros(cell.shape[:-2] + (3, 3), cell.dtype)
+        full[..., :d, :d] = cell
+        for k in range(d, 3):
+            full[..., k, k] = 4.0 * radial_cutoff
+        cell = full
+    r = O.radius_graph(cart, cell, radial_cutoff, unique=True)
     dev = relative_coordinates.device
     return (torch.from_numpy(np.stack([r["src"], r["dst"]], 1)).to(dev),
             torch.from_numpy(r["counts"].reshape(-1)).to(dev))

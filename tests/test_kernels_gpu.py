@@ -383,6 +383,53 @@ def test_radius_graph_orthorhombic_fast_path(K, oracle, cuda, B, N, box, rc):
     _check_graph(K, oracle, cuda, cart, cell, rc)
 
 
+@pytest.mark.parametrize("name", ["d1", "d2"])
+def test_periodic_adjacency_in_one_and_two_dimensions_against_reference(cuda, name):
+    """get_periodic_adjacency_information / get_edges_with_radial_cutoff with spatial_dimension 1 and 2, as the reference takes
+    them (utils/neighbors.py:36-224, models/egnn_utils.py:107-144): the HIP kernel on the problem embedded in three dimensions
+    (utils/neighbors.embed_in_three_dimensions) gives the reference's edge multiset, shifts (bitwise), counts, and the unique
+    edge list in the reference's order; a cutoff 0.1 above the shortest cell-crossing distance raises the reference's
+    AssertionError and 0.1 below does not (tests/utils/test_neighbors.py:239-260)."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd.utils import neighbors
+    g = load_golden("low_dimensions.npz")
+    cart, cell = (torch.from_numpy(g[f"{name}/{k}"]).to(cuda) for k in ("cart", "cell"))
+    rc = float(g[f"{name}/rc"])
+    d = cart.shape[-1]
+    info = neighbors.get_periodic_adjacency_information(cart, cell, rc, spatial_dimension=d)
+    adj, eb, shifts = info.adjacency_matrix.cpu().numpy(), info.edge_batch_indices.cpu().numpy(), info.shifts.cpu().numpy()
+    assert shifts.shape[1] == d
+    key = np.lexsort(tuple(shifts[:, k] for k in reversed(range(d))) + (adj[1], adj[0], eb))
+    assert np.array_equal(adj[:, key], g[f"{name}/adj_sorted"]) and np.array_equal(eb[key], g[f"{name}/edge_batch_sorted"])
+    assert np.array_equal(shifts[key].view(np.int32), g[f"{name}/shifts_sorted"].view(np.int32))
+    assert np.array_equal(info.number_of_edges.cpu().numpy(), g[f"{name}/number_of_edges"])
+    X = torch.from_numpy(g[f"{name}/X"]).to(cuda)
+    unique = neighbors.get_edges_with_radial_cutoff(X, cell, rc, spatial_dimension=d)
+    assert np.array_equal(unique.cpu().numpy(), g[f"{name}/unique_edges"])
+    shortest, b = float(g[f"{name}/shortest_crossing"].min()), int(g[f"{name}/shortest_crossing"].argmin())
+    neighbors.get_periodic_adjacency_information(cart[b:b + 1], cell[b:b + 1], shortest - 0.1, spatial_dimension=d)
+    with pytest.raises(AssertionError, match="radial cutoff is so large"):
+        neighbors.get_periodic_adjacency_information(cart[b:b + 1], cell[b:b + 1], shortest + 0.1, spatial_dimension=d)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("name", ["egnn_d1", "egnn_d2"])
+def test_egnn_with_a_radius_graph_in_one_and_two_dimensions_on_the_gpu(cuda, name, precision):
+    """EGNNScoreNetwork with `edges: radial_cutoff` in one and two dimensions on the HIP path -- the embedded radius graph, the
+    MFMA edge chain with coordinate dimension 2 / 4 -- against the reference's forward: scores <= 1e-5, logits close."""
+    from test_oracle_golden import low_dimension_case
+    g = load_golden("low_dimensions.npz")
+    net, batch = low_dimension_case(g, name, device=cuda)
+    net.edge_chain_precision = precision
+    assert not net.capture_safe(4, batch[next(iter(batch))].X.shape[1], cuda)     # (the embedded search is the two-call one)
+    with torch.no_grad():
+        out = net(batch, conditional=False)
+    net.check_status()
+    ref = g[f"{name}/out_X"].astype(np.float64)
+    assert np.linalg.norm(out.X.cpu().numpy() - ref) / np.linalg.norm(ref) < 1e-5
+    np.testing.assert_allclose(out.A.cpu().numpy()[..., :-1], g[f"{name}/out_A"][..., :-1], rtol=1e-4, atol=1e-5)
+    assert all(layer._chain[1] is not None and layer._chain[1].precision == precision for layer in net.egnn.graph_layers)
+
+
 def test_radius_graph_cutoff_too_large_sets_status(K, cuda):
     cart = torch.rand(2, 8, 3, device=cuda) * 4.0
     cell = torch.diag(torch.tensor([4.0, 4.0, 4.0])).repeat(2, 1, 1).to(cuda)
