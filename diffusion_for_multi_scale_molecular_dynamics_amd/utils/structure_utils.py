@@ -13,9 +13,10 @@ def compute_distances_in_batch(cartesian_positions: torch.Tensor, unit_cell: tor
                                max_distance: float) -> torch.Tensor:
     """All distances 0 < |p_i - (p_j + image)| <= max_distance over the 27 nearest images, for every structure."""
     batch_size, n_atoms, d = cartesian_positions.shape
-    assert d == 3 and unit_cell.shape == (batch_size, 3, 3)
-    cart = cartesian_positions.contiguous()
-    out = kernels.radius_graph(cart, unit_cell.contiguous(), max_distance, unique=False, status=None)
+    assert d in (1, 2, 3) and unit_cell.shape == (batch_size, d, d)
+    from .neighbors import embed_in_three_dimensions
+    cart, cell = embed_in_three_dimensions(cartesian_positions, unit_cell, max_distance)     # (1-D / 2-D: see there)
+    out = kernels.radius_graph(cart, cell, max_distance, unique=False, status=None)
     edges, shifts = out["edges"], out["shifts"]
     structure = torch.repeat_interleave(torch.arange(batch_size, device=cart.device), out["counts"].sum(dim=1))
     flat = cart.reshape(batch_size * n_atoms, 3)

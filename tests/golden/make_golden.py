@@ -723,16 +723,21 @@ def golden_next():
 
 
 
-def golden_distances():
-    """utils/structure_utils.py:41-121 (pymatgen is only imported by that module for an unrelated helper: stubbed)."""
+def _reference_compute_distances_in_batch():
     pm = types.ModuleType("pymatgen")
     pmc = types.ModuleType("pymatgen.core")
     pmc.Lattice = object
     pmc.Structure = object
     pm.core = pmc
-    sys.modules["pymatgen"] = pm
-    sys.modules["pymatgen.core"] = pmc
+    sys.modules.setdefault("pymatgen", pm)
+    sys.modules.setdefault("pymatgen.core", pmc)
     from diffusion_for_multi_scale_molecular_dynamics.utils.structure_utils import compute_distances_in_batch
+    return compute_distances_in_batch
+
+
+def golden_distances():
+    """utils/structure_utils.py:41-121 (pymatgen is only imported by that module for an unrelated helper: stubbed)."""
+    compute_distances_in_batch = _reference_compute_distances_in_batch()
     g = torch.Generator().manual_seed(707)
     out = {}
     for name, B, N, box, rc in (("d8", 3, 8, 5.43, 4.0), ("d64", 2, 64, 10.86, 5.0)):
@@ -1178,12 +1183,14 @@ def golden_low_dimensions():
     tests/models/score_network/test_score_network_general_tests.py:335-371):
       low_dimensions.npz   d1 / d2: get_periodic_adjacency_information on random positions in a 1-D cell and in slightly sheared
                            2-D cells (adjacency, shifts, edge counts, canonically sorted), get_edges_with_radial_cutoff's unique
-                           edge list, and the smallest cell-crossing distance (for the cutoff-too-large check);
+                           edge list, the smallest cell-crossing distance (for the cutoff-too-large check), and
+                           compute_distances_in_batch's bag of distances (sorted);
                            egnn_d1 / egnn_d2: EGNNScoreNetwork (hidden 32, 2 layers, radial cutoff 3.0, formula weights at scale
                            1.5) forward on 4 structures of 6 / 12 atoms in cells of 7 - 10."""
     sys.path.insert(0, os.path.dirname(HERE))
     from formula_weights import fill_with_formula
     from diffusion_for_multi_scale_molecular_dynamics.utils.neighbors import _get_shortest_distance_that_crosses_unit_cell
+    compute_distances_in_batch = _reference_compute_distances_in_batch()
     g = torch.Generator().manual_seed(1212)
     out = {}
     B = 4
@@ -1203,6 +1210,7 @@ def golden_low_dimensions():
         out[f"{name}/unique_edges"] = _np(get_edges_with_radial_cutoff(X, cell, rc, drop_duplicate_edges=True,
                                                                        spatial_dimension=d)).astype(np.int32)
         out[f"{name}/shortest_crossing"] = _np(_get_shortest_distance_that_crosses_unit_cell(cell, spatial_dimension=d))
+        out[f"{name}/distances_sorted"] = np.sort(_np(compute_distances_in_batch(cart, cell, rc)))      # structure_utils.py:41-121
         # the network on the same kind of structures (orthogonal cell: lattice parameters = the lengths, angles zero)
         p = EGNNScoreNetworkParameters(spatial_dimension=d, num_atom_types=1, n_layers=2, coordinate_hidden_dimensions_size=32,
                                        coordinate_n_hidden_dimensions=2, message_hidden_dimensions_size=32,

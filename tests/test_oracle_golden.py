@@ -157,6 +157,9 @@ def test_radius_graph_in_one_and_two_dimensions(oracle, name):
     assert np.array_equal(full["counts"].sum(1), g[f"{name}/number_of_edges"])
     uq = oracle.radius_graph(cart3, cell3, rc, unique=True)
     assert np.array_equal(np.stack([uq["src"], uq["dst"]], 1), g[f"{name}/unique_edges"])
+    # the reference's compute_distances_in_batch (structure_utils.py:41-121) returns the lengths of exactly these edges
+    lengths = np.linalg.norm(cart[eb, full["dst"]] + shifts - cart[eb, full["src"]], axis=1)
+    np.testing.assert_allclose(np.sort(lengths), g[f"{name}/distances_sorted"], rtol=1e-6, atol=1e-6)
     shortest = float(g[f"{name}/shortest_crossing"].min())
     b = int(g[f"{name}/shortest_crossing"].argmin())
     oracle.radius_graph(*_embed3(cart[b:b + 1], cell[b:b + 1], shortest - 0.1), shortest - 0.1, unique=True)
