@@ -80,7 +80,7 @@ class ForceFieldAugmentedScoreNetwork(torch.nn.Module):
         lengths = comp.L[:, :d].clip(min=1.0)                       # min_box_size = 1.0 (:147-150)
         cell = torch.diag_embed(lengths)
         cart = torch.matmul(x, cell)
-        info = get_periodic_adjacency_information(cart, cell, radial_cutoff=r0, spatial_dimension=d)
+        info = get_periodic_adjacency_information(cart, cell, radial_cutoff=r0)      # d = 3 only, as the reference (:131-135)
         src, dst = info.adjacency_matrix
         node = info.edge_batch_indices * n + src                    # sorted: edges are grouped by source atom
         flat = cart.reshape(bsz * n, d)
