@@ -257,27 +257,25 @@ def time_update_kernel(gen, batch, w, device, launches=200):
 
 
 def time_radius_graph(batch, w, device, launches=50):
-    """Average duration of one radius-graph fill launch (N1) at the workload's size."""
+    """Average duration of one graph build as the sampler runs it (N1 + N2: mdx_egnn_radius_graph on relative coordinates, hit
+    masks + emission = two launches) at the workload's size, and of its count / scan / fill form (three launches) beside it."""
     n = w["n_atoms"]
-    box = max(w["cell"], 2.2 * 7.5)
     x = torch.rand(batch, n, 3, device=device)
-    cell = torch.diag(torch.tensor([box] * 3)).repeat(batch, 1, 1).to(device)
-    cart = (x @ cell).contiguous()
-    out = kernels.radius_graph(cart, cell, 7.5, unique=True)
-    counts = out["counts"].view(-1)
-    offsets = (torch.cumsum(counts, 0) - counts).contiguous()
-    edges = torch.empty_like(out["edges"])
-    from diffusion_for_multi_scale_molecular_dynamics_amd._hip import check, lib, ptr, stream_handle
+    lattice = torch.tensor([w["cell"]] * 3 + [0.0] * 3).repeat(batch, 1).to(device)
+    capacity = batch * n * (n - 1)
+    ms = {}
+    for form, two in (("masks_emit", True), ("count_scan_fill", False)):
+        keep = []
 
-    def launch():
-        check(lib().mdx_radius_graph_fill(ptr(cart, torch.float32, "c"), ptr(cell, torch.float32, "b"), 7.5, batch, n, 1,
-                                          ptr(offsets, torch.int64, "o"), ptr(edges, torch.int64, "e"), None, None,
-                                          stream_handle()), "fill")
-    ms = time_launches(launch, device, launches)
-    n_edges = int(edges.shape[0])
-    bytes_per_launch = batch * n * (12 + 8) + 16 * n_edges    # read X + offsets, write 16 B per edge
-    return dict(kernel="radius_graph_kernel<fill> (N1)", ms=ms, bytes=bytes_per_launch,
-                edges_per_atom=n_edges / (batch * n))
+        def launch():
+            keep.append(kernels.egnn_radius_graph(x, lattice, 2.2 * 7.5, 7.5, capacity, two_launches=two))
+            del keep[:-2]
+        ms[form] = time_launches(launch, device, launches)
+    n_edges = int(keep[-1]["n_edges"].item())
+    bytes_per_launch = batch * n * (12 + 8 + 8) + 16 * n_edges    # read X, write counts + offsets, write 16 B per edge
+    return dict(kernel="mdx_egnn_radius_graph (N1 + N2 as the sampler runs it: egnn_graph_mask_kernel + egnn_graph_emit_kernel)",
+                ms=ms["masks_emit"], bytes=bytes_per_launch, edges_per_atom=n_edges / (batch * n),
+                extra=dict(launches_per_build=2, count_scan_fill_form_us=round(ms["count_scan_fill"] * 1e3, 2)))
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3    # dense fp32-input MFMA peak of MI355X (MI355X_MICROARCH.md; no xf32/TF32 on gfx950)
@@ -825,9 +823,20 @@ def measure_workload(job, name, steps, warmup, whole_job_budget_s, egnn_precisio
                     path = os.path.join(ROOT, "profiles", fname)
                     if os.path.exists(path):
                         table.update(json.load(open(path)))
-                entry = table[f"{name}/{forward}"]
-                if entry["kernel"] == m["kernel"].split()[0].split("<")[0] and batch == w["batch"]:
-                    traffic = entry["bytes_per_launch"]
+                if m["kernel"].startswith("mdx_egnn_radius_graph"):
+                    # the committed counter record of the two graph-build kernels at this workload's shape (same edge density:
+                    # uniform random coordinates), scaled to the edge count of the build timed here
+                    entry = json.load(open(os.path.join(ROOT, "profiles", "traffic_graph_r05.json")))[name]
+                    if batch == entry["batch"] and w["n_atoms"] == entry["number_of_atoms"]:
+                        traffic = int(entry["bytes_per_build"] * m["bytes"] / entry["algorithmic_bytes"])
+                        m.setdefault("extra", {})["traffic_from"] = (
+                            "profiles/traffic_graph_r05.json: rocprofv3 --pmc passes of the two kernels at this shape "
+                            f"({entry['bytes_per_build']} B per build against {entry['algorithmic_bytes']} B algorithmic), scaled to the "
+                            "edge count of the build timed here; not a measurement of this run")
+                else:
+                    entry = table[f"{name}/{forward}"]
+                    if entry["kernel"] == m["kernel"].split()[0].split("<")[0] and batch == w["batch"]:
+                        traffic = entry["bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 pass
             roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -835,6 +844,7 @@ def measure_workload(job, name, steps, warmup, whole_job_budget_s, egnn_precisio
                             avg_launch_us=round(m["ms"] * 1e3, 3), algorithmic_bytes_per_launch=m["bytes"])
             if "compute" in m:
                 roofline["compute"] = m["compute"]
+            roofline.update(m.get("extra", {}))
 
     out = dict(
         name=name, w=w, T=T, mlp=mlp, batch=batch, steps=steps, warmup=warmup, forward=forward, use_graph=use_graph,

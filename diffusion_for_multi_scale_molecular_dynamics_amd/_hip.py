@@ -22,14 +22,14 @@ MAX_CLASSES = 8
 TAG_COORD, TAG_GUMBEL, TAG_LATTICE, TAG_INIT, TAG_REPAINT_X0, TAG_BINARY, TAG_REPAINT_Z, TAG_REPAINT_U, \
     TAG_INIT_LATTICE, TAG_RESAMPLE_Z, TAG_RESAMPLE_U = range(11)
 
-ABI_VERSION = 13         # MDX_ABI_VERSION of include/mdx_hip.h
+ABI_VERSION = 14         # MDX_ABI_VERSION of include/mdx_hip.h
 ABI_SYMBOLS = (
     "mdx_abi_version", "mdx_status_string", "mdx_noise_schedule_build", "mdx_index_set", "mdx_index_add",
     "mdx_fill_time_sigma", "mdx_relative_coordinates_update", "mdx_lattice_parameters_update",
     "mdx_relative_coordinates_update_dev", "mdx_lattice_parameters_update_dev",
     "mdx_atom_types_update", "mdx_pc_step_update", "mdx_noise_relative_coordinates", "mdx_noise_atom_types", "mdx_noise_relative_coordinates_sigmas", "mdx_noise_atom_types_per_atom",
     "mdx_noise_lattice_parameters",
-    "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_radius_graph_fill_capped", "mdx_egnn_radius_graph", "mdx_mlp_forward",
+    "mdx_repaint_constrained_rows", "mdx_forward_diffusion_step", "mdx_radius_graph_count", "mdx_radius_graph_fill", "mdx_radius_graph_fill_capped", "mdx_egnn_radius_graph", "mdx_egnn_radius_graph_workspace_words", "mdx_mlp_forward",
     "mdx_mlp_pc_sample", "mdx_mlp_pc_sample_variant", "mdx_mlp_pc_sample_workspace_floats", "mdx_mlp_image_floats", "mdx_mlp_pack_image", "mdx_egnn_message_input", "mdx_egnn_coord_head", "mdx_segment_rows",
     "mdx_egnn_chain_image_bytes", "mdx_egnn_chain_pack", "mdx_egnn_chain_adapt_activation_exponents", "mdx_egnn_edge_chain", "mdx_egnn_piece_rows", "mdx_segment_combine", "mdx_egnn_node_gather", "mdx_mlp_chain_rows", "mdx_egnn_coord_aggregate",
     "mdx_egnn_node_inputs", "mdx_egnn_scores", "mdx_egnn_outputs", "mdx_node_mlp_rows", "mdx_node_mlp_rows_split",
@@ -168,7 +168,9 @@ def _declare(L):
     L.mdx_radius_graph_fill_capped.restype = i32
     L.mdx_radius_graph_fill_capped.argtypes = [vp, vp, f32, i64, i32, i32, vp, i64, vp, vp, vp, vp, vp]
     L.mdx_egnn_radius_graph.restype = i32
-    L.mdx_egnn_radius_graph.argtypes = [vp, vp, i32, f32, f32, i64, i32, i64, vp, vp, vp, vp, vp, vp]
+    L.mdx_egnn_radius_graph.argtypes = [vp, vp, i32, f32, f32, i64, i32, i64, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.mdx_egnn_radius_graph_workspace_words.restype = i64
+    L.mdx_egnn_radius_graph_workspace_words.argtypes = [i64, i32]
     L.mdx_mlp_forward.restype = i32
     L.mdx_mlp_forward.argtypes = [C.POINTER(Mlp), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
     L.mdx_mlp_pc_sample.restype = i32

@@ -1888,6 +1888,54 @@ __device__ __forceinline__ float crossing_distance(const float* cell)
     return dmin;
 }
 
+// Bit l of the result: image l (itertools.product(-1, 0, 1) order) of atom j lies within the cutoff of atom i, 0 < d^2 <= rc^2
+// (neighbors.py:192-194 excludes coincident atoms as well as the atom itself).  `ortho`: the cell is diagonal with
+// rc <= L_min / 2.2, so only the nearest image can qualify and ONE is evaluated, with the expression of the sweep: same bits.
+__device__ __forceinline__ uint32_t images_within_cutoff(bool ortho, float pix, float piy, float piz, float pjx, float pjy, float pjz,
+                                                         float inv_lx, float inv_ly, float inv_lz, float lx, float ly, float lz,
+                                                         const float* lv, float rc2)
+{
+    uint32_t mask = 0;
+    if (ortho) {
+        const int nx = max(-1, min(1, (int)__builtin_rintf((pix - pjx) * inv_lx)));
+        const int ny = max(-1, min(1, (int)__builtin_rintf((piy - pjy) * inv_ly)));
+        const int nz = max(-1, min(1, (int)__builtin_rintf((piz - pjz) * inv_lz)));
+        // image vector of a diagonal cell: n_k * L_k, exact, identical to the fma chain that fills lv[]
+        const float sx = pjx + (float)nx * lx, sy = pjy + (float)ny * ly, sz = pjz + (float)nz * lz;
+        const float dx = pix - sx, dy = piy - sy, dz = piz - sz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (0.0f < d2 && d2 <= rc2) mask = (1u << ((nx + 1) * 9 + (ny + 1) * 3 + (nz + 1)));
+    } else {
+        // not unrolled: a full unroll hoists the 81 image-vector components into registers (113 VGPRs, half the
+        // occupancy) for the benefit of the rare triclinic path
+#pragma nounroll
+        for (int l = 0; l < 27; ++l) {
+            const float sx = pjx + lv[3 * l], sy = pjy + lv[3 * l + 1], sz = pjz + lv[3 * l + 2];
+            const float dx = pix - sx, dy = piy - sy, dz = piz - sz;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (0.0f < d2 && d2 <= rc2) mask |= (1u << l);
+        }
+    }
+    return mask;
+}
+
+// images_within_cutoff(...) != 0 for a caller that does not need to know WHICH image: the image number stays a float (rint, then
+// clamped to -1 .. 1 by a median) instead of going through an integer -- the same n, the same n * L, pj + n * L, pi - (...) and d^2,
+// ten instructions fewer per pair.  (A NaN difference gives n = 0 there and an unspecified n here; d^2 is NaN either way: no hit.)
+__device__ __forceinline__ bool any_image_within_cutoff(bool ortho, float pix, float piy, float piz, float pjx, float pjy, float pjz,
+                                                        float inv_lx, float inv_ly, float inv_lz, float lx, float ly, float lz,
+                                                        const float* lv, float rc2)
+{
+    if (!ortho) return images_within_cutoff(false, pix, piy, piz, pjx, pjy, pjz, inv_lx, inv_ly, inv_lz, lx, ly, lz, lv, rc2) != 0;
+    const float nx = __builtin_amdgcn_fmed3f(__builtin_rintf((pix - pjx) * inv_lx), -1.0f, 1.0f);
+    const float ny = __builtin_amdgcn_fmed3f(__builtin_rintf((piy - pjy) * inv_ly), -1.0f, 1.0f);
+    const float nz = __builtin_amdgcn_fmed3f(__builtin_rintf((piz - pjz) * inv_lz), -1.0f, 1.0f);
+    const float sx = pjx + nx * lx, sy = pjy + ny * ly, sz = pjz + nz * lz;
+    const float dx = pix - sx, dy = piy - sy, dz = piz - sz;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    return 0.0f < d2 && d2 <= rc2;
+}
+
 // One workgroup = one (structure, chunk of kRowsPerBlock source rows).  The structure's positions and its 27
 // image vectors are staged in LDS once; each wavefront then owns source rows and sweeps the destinations 64 at
 // a time.  Lane ranks from ballot/scan make the writes dense and ordered by (src, dst, image).
@@ -1958,28 +2006,9 @@ __global__ __launch_bounds__(kBlock) void radius_graph_kernel(const float* __res
         for (int j0 = 0; j0 < N; j0 += kWave) {
             const int j = j0 + lane;
             uint32_t mask = 0;
-            if (j < N && ortho) {
-                const float pjx = pos[3 * j], pjy = pos[3 * j + 1], pjz = pos[3 * j + 2];
-                const int nx = max(-1, min(1, (int)__builtin_rintf((pix - pjx) * inv_lx)));
-                const int ny = max(-1, min(1, (int)__builtin_rintf((piy - pjy) * inv_ly)));
-                const int nz = max(-1, min(1, (int)__builtin_rintf((piz - pjz) * inv_lz)));
-                // image vector of a diagonal cell: n_k * L_k, exact, identical to the fma chain that fills lv[]
-                const float sx = pjx + (float)nx * cl[0], sy = pjy + (float)ny * cl[4], sz = pjz + (float)nz * cl[8];
-                const float dx = pix - sx, dy = piy - sy, dz = piz - sz;
-                const float d2 = (dx * dx + dy * dy) + dz * dz;
-                if (0.0f < d2 && d2 <= rc2) mask = (1u << ((nx + 1) * 9 + (ny + 1) * 3 + (nz + 1)));
-            } else if (j < N) {
-                const float pjx = pos[3 * j], pjy = pos[3 * j + 1], pjz = pos[3 * j + 2];
-                // not unrolled: a full unroll hoists the 81 image-vector components into registers (113 VGPRs, half
-                // the occupancy) for the benefit of the rare triclinic path
-#pragma nounroll
-                for (int l = 0; l < 27; ++l) {
-                    const float sx = pjx + lv[3 * l], sy = pjy + lv[3 * l + 1], sz = pjz + lv[3 * l + 2];
-                    const float dx = pix - sx, dy = piy - sy, dz = piz - sz;
-                    const float d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (0.0f < d2 && d2 <= rc2) mask |= (1u << l);
-                }
-            }
+            if (j < N)
+                mask = images_within_cutoff(ortho, pix, piy, piz, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], inv_lx, inv_ly,
+                                            inv_lz, cl[0], cl[4], cl[8], lv, rc2);
             int cnt, rank, total;
             if (unique) {
                 cnt = (mask != 0);
@@ -2109,6 +2138,186 @@ __global__ __launch_bounds__(kScanBlock) void offsets_scan_kernel(const int64_t*
         carry += tile_sums[kScanRows * kScanWaves];
     }
     if (threadIdx.x == 0) *total = carry;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// N1 as the EGNN score network builds it, in TWO launches: hit masks, then emission
+// ---------------------------------------------------------------------------------------------------------------
+// count -> scan -> fill evaluates every pair twice and puts a one-workgroup scan of B*N counts between two chip-wide launches.  Here
+// the adjacency of a structure is kept as what the ballot already is -- one 64-bit word per (source row, 64 destinations) -- in a
+// caller's workspace (N = 64: 512 bytes per structure); the second launch needs no positions and no arithmetic: it sums the totals
+// of the structures before its own (B words), scans its N row counts, and turns the words into ordered 16-byte pairs.
+// One workgroup per structure in both; a wavefront owns a CONTIGUOUS run of source rows, so its edges are one contiguous run of the
+// list and the write position is a running sum.  Same pair test as radius_graph_kernel (images_within_cutoff): same edges, same order.
+constexpr int kGraphMaxAtoms = 1024, kGraphMaxBatch = 2048;
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void egnn_graph_mask_kernel(const float* __restrict__ relative, const float* __restrict__ lattice,
+                                                                   int lattice_stride, float clip_min, float rc, int N,
+                                                                   int64_t* __restrict__ counts, unsigned long long* __restrict__ masks,
+                                                                   int64_t* __restrict__ totals, uint32_t* status)
+{
+    extern __shared__ float lds[];
+    float* pos = lds;                                    // [N][3]
+    float* lv = lds + 3 * N;                             // [27][3]
+    int* wave_total = reinterpret_cast<int*>(lv + 81);   // [THREADS / kWave]
+    const int64_t b = blockIdx.x;
+    const float* P = relative + b * N * 3;
+    float cl[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cl[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = lattice[b * lattice_stride + k];
+        cl[4 * k] = v < clip_min ? clip_min : v;             // torch.clip(min=): a NaN stays a NaN
+    }
+    for (int i = threadIdx.x; i < 3 * N; i += THREADS) {
+        const int c = i % 3;
+        pos[i] = P[i] * (c == 0 ? cl[0] : c == 1 ? cl[4] : cl[8]);
+    }
+    if (threadIdx.x < 81) {
+        const int l = threadIdx.x / 3, c = threadIdx.x % 3;
+        const float rel[3] = {(float)(l / 9 - 1), (float)((l / 3) % 3 - 1), (float)(l % 3 - 1)};
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc = __builtin_fmaf(rel[k], c == 0 ? cl[k * 3] : c == 1 ? cl[k * 3 + 1] : cl[k * 3 + 2], acc);
+        lv[threadIdx.x] = acc;
+    }
+    if (threadIdx.x == 96 && status) {
+        if (!(crossing_distance(cl) > rc)) atomicOr(status, MDX_STATUS_CUTOFF_TOO_LARGE);
+    }
+    const bool ortho = cl[0] > 0.0f && cl[4] > 0.0f && cl[8] > 0.0f && rc * 2.2f <= fminf(cl[0], fminf(cl[4], cl[8]));
+    const float inv_lx = ortho ? 1.0f / cl[0] : 0.0f, inv_ly = ortho ? 1.0f / cl[4] : 0.0f, inv_lz = ortho ? 1.0f / cl[8] : 0.0f;
+    __syncthreads();
+    const float rc2 = rc * rc;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int words = (N + kWave - 1) / kWave;                           // per source row
+    const int rows = (N + THREADS / kWave - 1) / (THREADS / kWave);      // per wavefront, contiguous
+    const int first = wave * rows, last = min(N, first + rows);
+    int total = 0;
+    if (N <= kWave) {
+        // one word per row: the lane's destination atom stays in registers over the wavefront's rows
+        const int j = lane < N ? lane : 0;
+        const float pjx = pos[3 * j], pjy = pos[3 * j + 1], pjz = pos[3 * j + 2];
+        for (int i = first; i < last; ++i) {
+            const bool hit = any_image_within_cutoff(ortho, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], pjx, pjy, pjz, inv_lx, inv_ly,
+                                                     inv_lz, cl[0], cl[4], cl[8], lv, rc2);
+            const unsigned long long hits = __ballot(lane < N && hit);
+            const int count = __popcll(hits);
+            if (lane == 0) {
+                masks[b * N + i] = hits;
+                counts[b * N + i] = count;
+            }
+            total += count;
+        }
+    } else
+    for (int i = first; i < last; ++i) {
+        const float pix = pos[3 * i], piy = pos[3 * i + 1], piz = pos[3 * i + 2];
+        unsigned long long* row_words = masks + (b * N + i) * words;
+        int count = 0;
+        for (int w = 0; w < words; ++w) {
+            const int j = w * kWave + lane;
+            bool hit = false;
+            if (j < N)
+                hit = any_image_within_cutoff(ortho, pix, piy, piz, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], inv_lx, inv_ly,
+                                              inv_lz, cl[0], cl[4], cl[8], lv, rc2);
+            const unsigned long long hits = __ballot(hit);
+            if (lane == 0) row_words[w] = hits;
+            count += __popcll(hits);
+        }
+        if (lane == 0) counts[b * N + i] = count;
+        total += count;
+    }
+    if (lane == 0) wave_total[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t sum = 0;
+        for (int w = 0; w < THREADS / kWave; ++w) sum += wave_total[w];
+        totals[b] = sum;
+    }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void egnn_graph_emit_kernel(int N, int64_t B, const int64_t* __restrict__ counts,
+                                                                   const unsigned long long* __restrict__ masks,
+                                                                   const int64_t* __restrict__ totals, int64_t* __restrict__ offsets,
+                                                                   int64_t* __restrict__ n_edges, int64_t* __restrict__ edges,
+                                                                   int64_t capacity, uint32_t* status)
+{
+    extern __shared__ int row_offset[];                  // [N + 1]: exclusive scan of the structure's row counts, the total behind
+    __shared__ int64_t partial[THREADS / kWave];
+    const int64_t b = blockIdx.x;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int words = (N + kWave - 1) / kWave;
+    const int rows = (N + THREADS / kWave - 1) / (THREADS / kWave);
+    const int first = min(N, wave * rows), last = min(N, first + rows);
+    const int n_words = (last - first) * words;          // this wavefront's hit words: one contiguous run
+    const unsigned long long* my_words = masks + (b * N + first) * words;
+    unsigned long long held = lane < n_words ? my_words[lane] : 0ull;        // requested before anything waits
+    // edges of the structures before this one
+    int64_t before = 0;
+    for (int64_t k = threadIdx.x; k < b; k += THREADS) before += totals[k];
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) before += __shfl_xor(before, o, kWave);
+    if (lane == 0) partial[wave] = before;
+    if (wave == 0) {
+        int carry = 0;
+        for (int c0 = 0; c0 < N; c0 += kWave) {
+            const int i = c0 + lane;
+            const int v = i < N ? (int)counts[b * N + i] : 0;
+            const int incl = wave_inclusive_scan(v);
+            if (i < N) row_offset[i] = carry + incl - v;
+            carry += __shfl(incl, kWave - 1, kWave);
+        }
+        if (lane == 0) row_offset[N] = carry;
+    }
+    __syncthreads();
+    int64_t base = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / kWave; ++w) base += partial[w];
+    for (int i = threadIdx.x; i < N; i += THREADS) offsets[b * N + i] = base + row_offset[i];
+    const int total = row_offset[N];
+    if (threadIdx.x == 0) {
+        if (b == B - 1) *n_edges = base + total;
+        // a caller-sized edge list that is too small: nothing is written beyond it, and the caller is told
+        if (status && base + total > capacity) atomicOr(status, MDX_STATUS_GRAPH_CAPACITY);
+    }
+    if (n_words == 0) return;
+    int64_t e = base + row_offset[first];
+    int64_t src = b * N + first;
+    int w_in_row = 0;
+    for (int c0 = 0; c0 < n_words; c0 += kWave) {
+        if (c0) held = c0 + lane < n_words ? my_words[c0 + lane] : 0ull;
+        const int limit = min(kWave, n_words - c0);
+        for (int k = 0; k < limit; ++k) {
+            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)held, k), hi = __builtin_amdgcn_readlane((uint32_t)(held >> 32), k);
+            const unsigned long long hits = ((unsigned long long)hi << 32) | lo;
+            if ((hits >> lane) & 1ull) {
+                const int64_t at = e + __popcll(hits & ((1ull << lane) - 1ull));
+                longlong2 pair;
+                pair.x = src;
+                pair.y = b * N + w_in_row * kWave + lane;
+                if (at < capacity) reinterpret_cast<longlong2*>(edges)[at] = pair;        // one 16-B store per edge
+            }
+            e += __popcll(hits);
+            if (++w_in_row == words) { w_in_row = 0; ++src; }
+        }
+    }
+}
+
+template <int THREADS>
+static void launch_graph_two_pass(const float* relative_coordinates, const float* lattice_parameters, int lattice_stride, float clip_min,
+                                  float rc, int64_t batch, int N, int64_t capacity, int64_t* counts, int64_t* offsets,
+                                  int64_t* n_edges, int64_t* edges_out, uint32_t* status, uint64_t* workspace, hipStream_t stream)
+{
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(workspace);
+    int64_t* totals = reinterpret_cast<int64_t*>(workspace) + batch * N * (int64_t)cdiv(N, kWave);
+    const size_t lds = sizeof(float) * (3 * (size_t)N + 81) + sizeof(int) * (THREADS / kWave);
+    hipLaunchKernelGGL(egnn_graph_mask_kernel<THREADS>, dim3((unsigned)batch), dim3(THREADS), lds, stream, relative_coordinates,
+                       lattice_parameters, lattice_stride, clip_min, rc, N, counts, masks, totals, status);
+    hipLaunchKernelGGL(egnn_graph_emit_kernel<THREADS>, dim3((unsigned)batch), dim3(THREADS), sizeof(int) * ((size_t)N + 1), stream,
+                       N, batch, (const int64_t*)counts, (const unsigned long long*)masks, (const int64_t*)totals, offsets, n_edges,
+                       edges_out, capacity, status);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2523,15 +2732,35 @@ int mdx_radius_graph_fill_capped(const float* cart, const float* cell, float rc,
     return launch_status();
 }
 
+int64_t mdx_egnn_radius_graph_workspace_words(int64_t batch, int N)
+{
+    if (batch < 1 || N < 1 || N > kGraphMaxAtoms || batch > kGraphMaxBatch) return 0;
+    return batch * N * (int64_t)cdiv(N, kWave) + batch;
+}
+
 int mdx_egnn_radius_graph(const float* relative_coordinates, const float* lattice_parameters, int lattice_stride, float clip_min,
                           float rc, int64_t batch, int N, int64_t capacity, int64_t* counts, int64_t* offsets,
-                          int64_t* n_edges, int64_t* edges_out, uint32_t* status, mdx_stream_t stream)
+                          int64_t* n_edges, int64_t* edges_out, uint32_t* status, uint64_t* workspace, int64_t workspace_words,
+                          mdx_stream_t stream)
 {
     if (batch < 0 || N < 1 || !(rc > 0.0f) || capacity < 0 || lattice_stride < 3 || !(clip_min >= 0.0f)) return MDX_ERR_INVALID_ARG;
     if (N > 5000) return MDX_ERR_UNSUPPORTED;
     if (!n_edges) return MDX_ERR_INVALID_ARG;
     if (batch == 0) return hipMemsetAsync(n_edges, 0, sizeof(int64_t), as_stream(stream)) == hipSuccess ? MDX_OK : MDX_ERR_HIP;
     if (!relative_coordinates || !lattice_parameters || !counts || !offsets || (capacity > 0 && !edges_out)) return MDX_ERR_INVALID_ARG;
+    if (workspace_words < 0 || (workspace_words > 0 && !workspace)) return MDX_ERR_INVALID_ARG;
+    const int64_t needed = mdx_egnn_radius_graph_workspace_words(batch, N);
+    if (workspace && needed > 0) {
+        if (workspace_words < needed) return MDX_ERR_INVALID_ARG;
+        // sixteen wavefronts per structure while the launch still fits the chip at once (8 192 wavefront slots), four beyond
+        if (N <= 16 || (N <= kWave && batch > 768))
+            launch_graph_two_pass<256>(relative_coordinates, lattice_parameters, lattice_stride, clip_min, rc, batch, N, capacity,
+                                       counts, offsets, n_edges, edges_out, status, workspace, as_stream(stream));
+        else
+            launch_graph_two_pass<1024>(relative_coordinates, lattice_parameters, lattice_stride, clip_min, rc, batch, N, capacity,
+                                        counts, offsets, n_edges, edges_out, status, workspace, as_stream(stream));
+        return launch_status();
+    }
     const int chunks = (int)cdiv(N, kRowsPerBlock);
     const size_t lds = sizeof(float) * (3 * (size_t)N + 81);
     const dim3 grid((unsigned)(batch * chunks));

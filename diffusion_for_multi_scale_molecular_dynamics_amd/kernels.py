@@ -291,10 +291,11 @@ def radius_graph_static(cartesian_positions, basis_vectors, radial_cutoff: float
 
 
 def egnn_radius_graph(relative_coordinates, lattice_parameters, clip_min: float, radial_cutoff: float, capacity: int,
-                      status: Optional[torch.Tensor] = None):
+                      status: Optional[torch.Tensor] = None, two_launches: bool = True):
     """radius_graph_static for the graph EGNNScoreNetwork builds (egnn_score_network.py:236-247): relative coordinates
-    [B,N,3] in the cell diag(max(lattice_parameters[:, :3], clip_min)); count, device-side scan and fill behind ONE call
-    (mdx_egnn_radius_graph: three launches, no library kernel, no host read).  Same dict as radius_graph_static."""
+    [B,N,3] in the cell diag(max(lattice_parameters[:, :3], clip_min)) behind ONE call, no library kernel, no host read
+    (mdx_egnn_radius_graph): hit masks + emission (two launches, every pair tested once) where that form applies
+    (N <= 1024, B <= 2048) and `two_launches`, else count, device-side scan and fill.  Same dict as radius_graph_static."""
     B, N, d = relative_coordinates.shape
     assert d == 3 and lattice_parameters.dim() == 2 and lattice_parameters.shape[0] == B and lattice_parameters.shape[1] >= 3
     dev = relative_coordinates.device
@@ -302,11 +303,14 @@ def egnn_radius_graph(relative_coordinates, lattice_parameters, clip_min: float,
     offsets = torch.empty(B * N, dtype=I64, device=dev)
     n_edges = torch.empty(1, dtype=I64, device=dev)
     edges = torch.empty(int(capacity), 2, dtype=I64, device=dev)
+    words = int(lib().mdx_egnn_radius_graph_workspace_words(B, N)) if two_launches else 0
+    workspace = torch.empty(words, dtype=I64, device=dev) if words else None
     check(lib().mdx_egnn_radius_graph(ptr(relative_coordinates, F32, "relative_coordinates"),
                                       ptr(lattice_parameters, F32, "lattice_parameters"), lattice_parameters.shape[1],
                                       float(clip_min), float(radial_cutoff), B, N, int(capacity), ptr(counts, I64, "counts"),
                                       ptr(offsets, I64, "offsets"), ptr(n_edges, I64, "n_edges"), ptr(edges, I64, "edges"),
-                                      ptr(status, I32, "status"), stream_handle()), "mdx_egnn_radius_graph")
+                                      ptr(status, I32, "status"), ptr(workspace, I64, "workspace"), words, stream_handle()),
+          "mdx_egnn_radius_graph")
     return dict(counts=counts, offsets=offsets, edges=edges, n_edges=n_edges)
 
 

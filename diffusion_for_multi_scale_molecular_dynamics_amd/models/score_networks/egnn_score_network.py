@@ -232,7 +232,7 @@ class EGNNScoreNetwork(ScoreNetwork):
             self.graph_status = torch.zeros(1, dtype=torch.int32, device=relative_coordinates.device)
         capacity = bsz * n * (n - 1)
         if relative_coordinates.is_cuda and not torch.is_grad_enabled() and self._static_edge_list_fits(bsz, n, relative_coordinates.device):
-            # clip, diagonal cell, cartesian positions, count, scan and fill behind one call (three launches)
+            # clip, diagonal cell, cartesian positions, hit masks and emission behind one call (two launches)
             edges, degree, offsets, n_edges = neighbors.get_edges_static_clipped(
                 relative_coordinates, lattice_parameters.to(torch.float32), 2.2 * self.radial_cutoff, self.radial_cutoff,
                 capacity, status=self.graph_status)

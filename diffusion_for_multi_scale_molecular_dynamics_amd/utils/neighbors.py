@@ -139,7 +139,7 @@ def get_edges_static(relative_coordinates: torch.Tensor, unit_cell: torch.Tensor
 def get_edges_static_clipped(relative_coordinates: torch.Tensor, lattice_parameters: torch.Tensor, clip_min: float,
                              radial_cutoff: float, capacity: int, status: Optional[torch.Tensor] = None):
     """get_edges_static for the cell EGNNScoreNetwork searches in -- orthogonal, lengths lattice_parameters[:, :3] clipped from
-    below (egnn_score_network.py:236-240) -- straight from the relative coordinates: one call, three launches."""
+    below (egnn_score_network.py:236-240) -- straight from the relative coordinates: one call, two launches (kernels.egnn_radius_graph)."""
     out = kernels.egnn_radius_graph(relative_coordinates.contiguous(), lattice_parameters.contiguous(), clip_min, radial_cutoff,
                                     capacity, status=status)
     return out["edges"], out["counts"], out["offsets"], out["n_edges"]

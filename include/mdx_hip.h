@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDX_ABI_VERSION 13
+#define MDX_ABI_VERSION 14
 
 /* status codes */
 #define MDX_OK 0
@@ -249,14 +249,20 @@ MDX_API int mdx_radius_graph_fill_capped(const float* cartesian_positions, const
 
 /* The graph EGNNScoreNetwork builds per forward (models/score_networks/egnn_score_network.py:236-247): the unique-pair radius
  * graph of RELATIVE coordinates [batch, N, 3] in the orthogonal cell diag(max(lattice_parameters[b, 0..2], clip_min)) (the
- * reference clips the cell lengths to 2.2 x cutoff and zeroes the angles), as count -> device-side exclusive scan -> fill: three
- * launches, no host read, nothing but the caller's buffers (counts, offsets [batch*N]; n_edges [1]; edges_out [capacity, 2]).
- * Cartesian positions are formed in the kernels as relative x length, the bits of the reference's matmul with the diagonal cell.
- * lattice_stride = row length of lattice_parameters (>= 3).  Status bits as mdx_radius_graph_count / _fill_capped. */
+ * reference clips the cell lengths to 2.2 x cutoff and zeroes the angles); no host read, nothing but the caller's buffers
+ * (counts, offsets [batch*N]; n_edges [1]; edges_out [capacity, 2]).  Cartesian positions are formed in the kernels as
+ * relative x length, the bits of the reference's matmul with the diagonal cell.  lattice_stride = row length of
+ * lattice_parameters (>= 3).  Status bits as mdx_radius_graph_count / _fill_capped.
+ * With a `workspace` of mdx_egnn_radius_graph_workspace_words(batch, N) 64-bit words (caller-owned, need not be initialised, not
+ * read after the call) the build is TWO launches and every pair is tested once: the first keeps each source row's hits as 64-bit
+ * words in the workspace, the second sums the totals of the structures in front, scans the row counts and writes the pairs.
+ * The helper returns 0 where that form does not apply (N > 1024 or batch > 2048); then, or with workspace = NULL, the build is
+ * count -> device-side exclusive scan -> fill (three launches).  Same outputs, bit for bit, either way. */
+MDX_API int64_t mdx_egnn_radius_graph_workspace_words(int64_t batch, int number_of_atoms);
 MDX_API int mdx_egnn_radius_graph(const float* relative_coordinates, const float* lattice_parameters, int lattice_stride,
                                   float clip_min, float radial_cutoff, int64_t batch, int number_of_atoms, int64_t capacity,
                                   int64_t* counts, int64_t* offsets, int64_t* n_edges, int64_t* edges_out, uint32_t* status,
-                                  mdx_stream_t stream);
+                                  uint64_t* workspace, int64_t workspace_words, mdx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused score network: the reference's MLPScoreNetwork (models/score_networks/mlp_score_network.py:54-370,

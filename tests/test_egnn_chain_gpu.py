@@ -433,13 +433,17 @@ def test_radius_graph_static_equals_two_call(cuda):
     assert torch.equal(guard[:small], ref["edges"][:small]) and (guard[small:] == -5).all()
 
 
-@pytest.mark.parametrize("B,N", [(3, 5), (7, 64), (70, 64), (2, 200), (257, 65), (520, 64), (2, 513), (1, 1000)])
-def test_egnn_radius_graph_from_relative_coordinates(cuda, B, N):
-    """mdx_egnn_radius_graph (relative coordinates + lattice parameters in, clip / diagonal cell / positions / scan inside: three
-    launches) gives bit for bit what the score network built before from torch.clip, diag_embed, matmul, the two radius-graph
-    launches and torch.cumsum -- lengths below the clip, count lists of more than one scan tile of 16 384 entries (257 x 65 with a
-    ragged last thread, 520 x 64 with three tiles) and short ragged ones included; a capacity that is too small is reported and
-    respected."""
+@pytest.mark.parametrize("two_launches", [True, False], ids=["masks_emit", "count_scan_fill"])
+@pytest.mark.parametrize("B,N", [(3, 5), (7, 64), (70, 64), (2, 200), (257, 65), (520, 64), (2, 513), (1, 1000), (1, 1), (5, 63),
+                                 (3, 128), (256, 216), (2, 1024), (2, 1025), (2049, 8)])
+def test_egnn_radius_graph_from_relative_coordinates(cuda, B, N, two_launches):
+    """mdx_egnn_radius_graph (relative coordinates + lattice parameters in, clip / diagonal cell / positions / scan inside) gives
+    bit for bit what the score network built before from torch.clip, diag_embed, matmul, the two radius-graph launches and
+    torch.cumsum, in both of its forms -- hit masks + emission (two launches with a workspace; a source row of 1 - 16 words, one or
+    sixteen wavefronts per structure, the shapes C3 and C5 sample) and count / scan / fill (three; also what the first form falls
+    back to beyond N 1024 or B 2048) -- lengths below the clip, count lists of more than one scan tile of 16 384 entries (257 x 65
+    with a ragged last thread, 520 x 64 with three tiles) and short ragged ones included; a capacity that is too small is reported
+    and respected."""
     from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
     g = torch.Generator().manual_seed(100 * B + N)
     rc = 3.2
@@ -451,14 +455,17 @@ def test_egnn_radius_graph_from_relative_coordinates(cuda, B, N):
     status = torch.zeros(1, dtype=torch.int32, device=cuda)
     capacity = B * N * (N - 1)
     want = kernels.radius_graph_static(cart, cell.contiguous(), rc, capacity, status=status)
-    got = kernels.egnn_radius_graph(x, lattice, 2.2 * rc, rc, capacity, status=status)
+    words = int(_hip.lib().mdx_egnn_radius_graph_workspace_words(B, N))
+    assert (words == B * N * ((N + 63) // 64) + B) if (N <= 1024 and B <= 2048) else words == 0
+    got = kernels.egnn_radius_graph(x, lattice, 2.2 * rc, rc, capacity, status=status, two_launches=two_launches)
     E = int(want["n_edges"].item())
-    assert E > 0 and int(got["n_edges"].item()) == E and int(status.item()) == 0
+    assert int(got["n_edges"].item()) == E and int(status.item()) == 0 and (E > 0 or N == 1)
     assert torch.equal(got["counts"], want["counts"]) and torch.equal(got["offsets"], want["offsets"])
     assert torch.equal(got["edges"][:E], want["edges"][:E])
-    small = kernels.egnn_radius_graph(x, lattice, 2.2 * rc, rc, E - 3, status=status)
-    assert int(status.item()) == _hip.STATUS_GRAPH_CAPACITY and torch.equal(small["edges"], want["edges"][:E - 3])
-    assert int(small["n_edges"].item()) == E          # the count is the graph's, not the list's
+    if E > 3:
+        guard = kernels.egnn_radius_graph(x, lattice, 2.2 * rc, rc, E - 3, status=status, two_launches=two_launches)
+        assert int(status.item()) == _hip.STATUS_GRAPH_CAPACITY and torch.equal(guard["edges"], want["edges"][:E - 3])
+        assert int(guard["n_edges"].item()) == E          # the count is the graph's, not the list's
 
 
 @pytest.mark.parametrize("H,C,n_nodes", [(256, 2, 1000), (64, 3, 77), (32, 8, 5)])

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert re.search(rf"\sT\s{sym}\b", exported), f"{sym} is declared in include/mdx_hip.h but not exported"
     lib = _hip.lib()                      # loads without a GPU; no compute call is made here
-    assert lib.mdx_abi_version() == _hip.ABI_VERSION == 13
+    assert lib.mdx_abi_version() == _hip.ABI_VERSION == 14
     # no vendor GEMM library behind the ABI: every matrix product of the library is a hand-written kernel
     needed = subprocess.check_output(["readelf", "-d", _hip.LIB_PATH], text=True)
     assert "hipblas" not in needed.lower() and "rocblas" not in needed.lower(), needed
