@@ -1,7 +1,7 @@
 """The kernels of ONE network forward of the C3 iteration, in launch order with their durations, from a rocprofv3 kernel trace:
     rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline
     python3 tools/kernel_sequence.py /tmp/tr
-(a forward = the launches between two fills of the radius graph)."""
+(a forward = the launches from one graph build -- its first kernel -- to the next)."""
 import csv
 import glob
 import re
@@ -10,7 +10,7 @@ import sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [(r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows]
-marks = [i for i, (n, _) in enumerate(names) if "radius_graph_kernel<true>" in n]
+marks = [i for i, (n, _) in enumerate(names) if "egnn_graph_mask_kernel" in n]
 spans = [(a, b) for a, b in zip(marks, marks[1:]) if b - a > 10]
 # the shortest one: a forward of the default (split-f16) mode, not of the exact-f32 mode bench.py times beside it
 a, b = min(spans, key=lambda ab: sum(us for _, us in names[ab[0]:ab[1]]))
