@@ -152,16 +152,33 @@ __global__ __launch_bounds__(kBlock) void egnn_node_inputs_rows_kernel(const flo
     __syncthreads();
     const int lane = threadIdx.x % 64;
     const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / 64, n_waves = ((int64_t)gridDim.x * blockDim.x) / 64;
-    for (int64_t i = wave; i < n_nodes; i += n_waves) {
-        const float s = sigma[i / atoms_per_structure];
-        const int64_t a = atom_types[i];
-        if (h2)
-            for (int q = lane; q < (H2 >> 2); q += 64) reinterpret_cast<float4*>(h2 + i * H2)[q] = embed_quad(t2, H2, q, s, a, F);
-        for (int q = lane; q < (H >> 2); q += 64) reinterpret_cast<float4*>(h + i * H)[q] = embed_quad(t1, H, q, s, a, F);
-        for (int k = lane; k < n_k; k += 64) {
-            float kr = 0.0f;
-            for (int d = 0; d < 3; ++d) kr = kr + (6.2831855f * x[3 * i + d]) * k_vectors[3 * k + d];
-            uplift(kr, z[2 * (i * n_k + k)], z[2 * (i * n_k + k) + 1]);
+    // A pass of a wavefront = `per` consecutive nodes: their torus uplifts first, ONE (node, wave vector) pair per lane -- the
+    // uplift is a binary64 sine / cosine (correctly rounded to binary32), a few hundred instructions that 13 lanes of 64 would
+    // otherwise run once per node -- then the nodes' embedding rows as 16-byte stores.
+    const int per = n_k <= 64 ? 64 / n_k : 1;
+    for (int64_t i0 = wave * per; i0 < n_nodes; i0 += n_waves * per) {
+        if (n_k <= 64) {
+            const int g = lane / n_k, k = lane - g * n_k;
+            const int64_t i = i0 + g;
+            if (g < per && i < n_nodes) {
+                float kr = 0.0f;
+                for (int d = 0; d < 3; ++d) kr = kr + (6.2831855f * x[3 * i + d]) * k_vectors[3 * k + d];
+                uplift(kr, z[2 * (i * n_k + k)], z[2 * (i * n_k + k) + 1]);
+            }
+        } else {
+            for (int k = lane; k < n_k; k += 64) {
+                float kr = 0.0f;
+                for (int d = 0; d < 3; ++d) kr = kr + (6.2831855f * x[3 * i0 + d]) * k_vectors[3 * k + d];
+                uplift(kr, z[2 * (i0 * n_k + k)], z[2 * (i0 * n_k + k) + 1]);
+            }
+        }
+        for (int g = 0; g < per && i0 + g < n_nodes; ++g) {
+            const int64_t i = i0 + g;
+            const float s = sigma[i / atoms_per_structure];
+            const int64_t a = atom_types[i];
+            if (h2)
+                for (int q = lane; q < (H2 >> 2); q += 64) reinterpret_cast<float4*>(h2 + i * H2)[q] = embed_quad(t2, H2, q, s, a, F);
+            for (int q = lane; q < (H >> 2); q += 64) reinterpret_cast<float4*>(h + i * H)[q] = embed_quad(t1, H, q, s, a, F);
         }
     }
 }
@@ -376,8 +393,9 @@ int mdx_egnn_node_inputs(const float* x, const float* k_vectors, int n_k, const 
     if (second_out && (!second_weight || !second_bias || second_width < 1)) return MDX_ERR_INVALID_ARG;
     const size_t table_bytes = sizeof(float) * (size_t)(1 + n_features) * ((size_t)H + (second_out ? (size_t)second_width : 0));
     if ((H & 3) == 0 && (!second_out || (second_width & 3) == 0) && table_bytes <= 48 * 1024) {
-        // few workgroups (each stages the tables once), many nodes each
-        int64_t blocks = (n_nodes + 63) / 64;
+        // a workgroup stages the tables once (<= 48 KB from L2) and then only stores: eight wavefronts per SIMD keep enough 16-byte
+        // stores in flight (four nodes per wavefront at C3; sixteen per wavefront left the chip a quarter occupied: 41 us)
+        int64_t blocks = (n_nodes + 15) / 16;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(egnn_node_inputs_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), table_bytes,
                            reinterpret_cast<hipStream_t>(stream), x, k_vectors, n_k, sigma, atoms_per_structure, atom_types,
