@@ -435,7 +435,7 @@ def test_radius_graph_static_equals_two_call(cuda):
 
 @pytest.mark.parametrize("two_launches", [True, False], ids=["masks_emit", "count_scan_fill"])
 @pytest.mark.parametrize("B,N", [(3, 5), (7, 64), (70, 64), (2, 200), (257, 65), (520, 64), (2, 513), (1, 1000), (1, 1), (5, 63),
-                                 (3, 128), (256, 216), (2, 1024), (2, 1025), (2049, 8)])
+                                 (3, 128), (256, 216), (2, 1024), (2, 1025), (2049, 8), (2048, 8)])
 def test_egnn_radius_graph_from_relative_coordinates(cuda, B, N, two_launches):
     """mdx_egnn_radius_graph (relative coordinates + lattice parameters in, clip / diagonal cell / positions / scan inside) gives
     bit for bit what the score network built before from torch.clip, diag_embed, matmul, the two radius-graph launches and
@@ -466,6 +466,39 @@ def test_egnn_radius_graph_from_relative_coordinates(cuda, B, N, two_launches):
         guard = kernels.egnn_radius_graph(x, lattice, 2.2 * rc, rc, E - 3, status=status, two_launches=two_launches)
         assert int(status.item()) == _hip.STATUS_GRAPH_CAPACITY and torch.equal(guard["edges"], want["edges"][:E - 3])
         assert int(guard["n_edges"].item()) == E          # the count is the graph's, not the list's
+
+
+def test_egnn_radius_graph_forms_on_random_shapes_and_small_cells(cuda):
+    """The two forms of mdx_egnn_radius_graph against each other and against the two-call search over 40 random (B, N, cutoff,
+    clip) -- including clips BELOW 2.2 x cutoff, where the cell no longer guarantees a single image: the mask kernel then sweeps
+    the 27 images like radius_graph_kernel (a pair within the cutoff through several images is still ONE edge), and a cell shorter
+    than the cutoff raises the same status bit in both forms."""
+    from diffusion_for_multi_scale_molecular_dynamics_amd import _hip, kernels
+    g = torch.Generator().manual_seed(2718)
+    swept = too_large = 0
+    for case in range(40):
+        B = int(torch.randint(1, 40, (1,), generator=g))
+        N = int(torch.randint(1, 300, (1,), generator=g))
+        rc = float(torch.rand(1, generator=g)) * 3.0 + 1.5
+        clip = rc * (2.2 if case % 2 == 0 else float(torch.rand(1, generator=g)) * 1.6 + 0.7)        # 0.7 .. 2.3 x cutoff
+        x = torch.rand(B, N, 3, generator=g).to(cuda)
+        lattice = torch.cat([torch.rand(B, 3, generator=g) * 8.0 + 2.0, torch.zeros(B, 3)], dim=1).to(cuda)
+        cell = torch.diag_embed(lattice[:, :3].clip(min=clip)).contiguous()
+        cart = torch.matmul(x, cell).contiguous()
+        capacity = B * N * (N - 1)
+        st = [torch.zeros(1, dtype=torch.int32, device=cuda) for _ in range(3)]
+        want = kernels.radius_graph_static(cart, cell, rc, capacity, status=st[0])
+        two = kernels.egnn_radius_graph(x, lattice, clip, rc, capacity, status=st[1], two_launches=True)
+        three = kernels.egnn_radius_graph(x, lattice, clip, rc, capacity, status=st[2], two_launches=False)
+        assert int(st[0].item()) == int(st[1].item()) == int(st[2].item()), (case, B, N, rc, clip)
+        E = int(want["n_edges"].item())
+        for got in (two, three):
+            assert int(got["n_edges"].item()) == E
+            assert torch.equal(got["counts"], want["counts"]) and torch.equal(got["offsets"], want["offsets"])
+            assert torch.equal(got["edges"][:E], want["edges"][:E]), (case, B, N, rc, clip)
+        swept += int(bool((cell.diagonal(dim1=1, dim2=2).min() < 2.2 * rc).item()))
+        too_large += int(int(st[1].item()) == _hip.STATUS_CUTOFF_TOO_LARGE)
+    assert swept >= 10 and too_large >= 2          # the sweep path and the status were exercised
 
 
 @pytest.mark.parametrize("H,C,n_nodes", [(256, 2, 1000), (64, 3, 77), (32, 8, 5)])
