@@ -9,9 +9,9 @@ name=$1; shift
 src=$C/mdx_egnn_chain.hip
 if [ "$1" == "--source" ]; then src=$2; shift 2; fi
 mkdir -p $R/tools/_ablate
-make -s -C $C mdx_hip.o mdx_egnn.o
+make -s -C $C mdx_hip.o mdx_egnn.o mdx_egnn_chain_att.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden \
     -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function -I$C "$@" -c -o $R/tools/_ablate/chain_$name.o $src
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_ablate/libmdx_$name.so $C/mdx_hip.o $C/mdx_egnn.o \
-    $R/tools/_ablate/chain_$name.o -L/opt/rocm/lib -lhipblaslt
+    $C/mdx_egnn_chain_att.o $R/tools/_ablate/chain_$name.o
 echo "built tools/_ablate/libmdx_$name.so"
