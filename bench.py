@@ -829,12 +829,11 @@ def measure_workload(job, name, steps, warmup, whole_job_budget_s, egnn_precisio
                     records = json.load(open(os.path.join(ROOT, "profiles", "traffic_graph_r05.json")))
                     entry = next(e for k, e in records.items() if k != "_comment" and e["batch"] == batch and
                                  e["number_of_atoms"] == w["n_atoms"])       # (C4 builds C3's graph: same shape and density)
-                    if True:
-                        traffic = int(entry["bytes_per_build"] * m["bytes"] / entry["algorithmic_bytes"])
-                        m.setdefault("extra", {})["traffic_from"] = (
-                            "profiles/traffic_graph_r05.json: rocprofv3 --pmc passes of the two kernels at this shape "
-                            f"({entry['bytes_per_build']} B per build against {entry['algorithmic_bytes']} B algorithmic), scaled to the "
-                            "edge count of the build timed here; not a measurement of this run")
+                    traffic = int(entry["bytes_per_build"] * m["bytes"] / entry["algorithmic_bytes"])
+                    m.setdefault("extra", {})["traffic_from"] = (
+                        "profiles/traffic_graph_r05.json: rocprofv3 --pmc passes of the two kernels at this shape "
+                        f"({entry['bytes_per_build']} B per build against {entry['algorithmic_bytes']} B algorithmic), scaled to the "
+                        "edge count of the build timed here; not a measurement of this run")
                 else:
                     entry = table[f"{name}/{forward}"]
                     if entry["kernel"] == m["kernel"].split()[0].split("<")[0] and batch == w["batch"]:
