@@ -1000,10 +1000,16 @@ def run_rank(args, w, world, rank):
         also = []
         for name, steps, warmup, resampling, budget in ALSO_MEASURED:
             t0 = time.perf_counter()
-            other = measure_workload(job, name, steps, warmup, budget, args.egnn_precision, resampling_arg=resampling,
-                                     other_mode=False, families=True)
-            if rank == 0:
+            try:
+                other = measure_workload(job, name, steps, warmup, budget, args.egnn_precision, resampling_arg=resampling,
+                                         other_mode=False, families=True)
                 entry = as_line(other, world, args.egnn_precision, args.backend if dist is not None else None)
+            except Exception as exc:          # noqa: BLE001  (a side measurement must not take the primary line with it: say so)
+                if world > 1:
+                    raise                     # (ranks must stay in step: the launcher reports the failing rank)
+                entry = dict(config=dict(workload=name), error=f"{type(exc).__name__}: {exc}"[:500])
+                torch.cuda.synchronize(device)
+            if rank == 0:
                 entry["measured_in_s"] = round(time.perf_counter() - t0, 1)
                 also.append(entry)
 

@@ -591,6 +591,15 @@ def test_bench_contract(cuda, workload):
         assert d["config"]["egnn_edge_chain"] == "f16x3" and d["other_edge_chain_mode"]["egnn_edge_chain"] == "f32"
         assert 0 < d["other_edge_chain_mode"]["value"] < d["value"]
         assert d["config"]["hip_graph"] is True
+        # the default command also measures the other BASELINE configurations; a failing side measurement would be reported
+        # in its entry (`error`) instead of taking the line with it -- none is
+        also = d["also_measured"]
+        assert [a["config"]["workload"][:2] for a in also] == ["C2", "C4", "C5", "C5"]
+        assert all("error" not in a and a["value"] > 0 and a["roofline"]["frac"] > 0 for a in also), also
+        assert [a["config"]["repaint_resampling_steps"] for a in also[2:]] == [0, 1]
+        hbm = d["roofline_hbm"]
+        assert hbm["kernel"].startswith("mdx_egnn_radius_graph") and hbm["launches_per_build"] == 2
+        assert hbm["avg_launch_us"] < hbm["count_scan_fill_form_us"] and hbm["traffic"] >= hbm["algorithmic_bytes_per_launch"]
 
 
 def test_updates_with_device_scalars_equal_host_scalars(cuda):
