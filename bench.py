@@ -1024,7 +1024,10 @@ def run_rank(args, w, world, rank):
     if also is not None:
         result["also_measured"] = also
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(w, args.workload, resampling=m["resampling"])
+        try:
+            result["cpu_baseline"] = cpu_baseline(w, args.workload, resampling=m["resampling"])
+        except Exception as exc:              # noqa: BLE001  (the measured line is printed whatever the CPU leg does: say what it did)
+            result["cpu_baseline"] = dict(value=None, unit="structures/s", kind="port", error=f"{type(exc).__name__}: {exc}"[:500])
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
