@@ -41,16 +41,37 @@ def extract_and_validate_parameters(hyper_params: Dict[AnyStr, Any]):
     return NoiseParameters(**hyper_params["noise"]), load_sampling_parameters(hyper_params["sampling"])
 
 
-def get_axl_network(checkpoint_path, hyper_params: Dict[AnyStr, Any]) -> ScoreNetwork:
-    """Build the network from `model.score_network` and load `axl_network.*` weights from the checkpoint."""
-    assert "model" in hyper_params and "score_network" in hyper_params["model"], \
-        "the config must contain the `model: score_network:` block that describes the checkpoint's network"
-    network = create_score_network(create_score_network_parameters(hyper_params["model"]["score_network"]))
-    checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
-    state = checkpoint.get("state_dict", checkpoint)
-    prefix = "axl_network."
-    state = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} or state
-    network.load_state_dict(state)
+def global_parameters_of(hyper_params: Dict[AnyStr, Any]) -> Optional[Dict[AnyStr, Any]]:
+    """What the reference hands to create_score_network_parameters beside the `model: score_network:` block: for a TRAINING
+    configuration (top-level `elements` and `data: max_atom`) exactly its dict(max_atom, spatial_dimension -- 3 when the file
+    does not say --, elements) (models/instantiate_diffusion_model.py:34-41: a block that contradicts it is refused, as there);
+    otherwise whichever of `elements` / `spatial_dimension` the file has; None when it has neither (a sampling configuration
+    that spells its block out)."""
+    data = hyper_params.get("data")
+    if "elements" in hyper_params and isinstance(data, dict) and "max_atom" in data:
+        return dict(max_atom=data["max_atom"], spatial_dimension=hyper_params.get("spatial_dimension", 3),
+                    elements=hyper_params["elements"])
+    out = {key: hyper_params[key] for key in ("elements", "spatial_dimension") if key in hyper_params}
+    return out or None
+
+
+def get_axl_network(checkpoint_path, hyper_params: Optional[Dict[AnyStr, Any]] = None) -> ScoreNetwork:
+    """:191-205.  The reference rebuilds the network from the hyper-parameters INSIDE the Lightning checkpoint
+    (`load_from_checkpoint`), so its sampling configurations hold no `model:` block; so does this -- without Lightning and
+    without the reference package (utils/lightning_checkpoint.py) -- and loads the `axl_network.*` weights.  A `model:
+    score_network:` block in the configuration, when there is one, takes precedence (a bare state_dict has nothing else)."""
+    from .utils.lightning_checkpoint import load_checkpoint, score_network_parameters_of, state_dict_of
+    checkpoint = load_checkpoint(checkpoint_path)
+    hyper_params = hyper_params or {}
+    if "model" in hyper_params and "score_network" in hyper_params["model"]:
+        parameters = create_score_network_parameters(hyper_params["model"]["score_network"], global_parameters_of(hyper_params))
+    else:
+        parameters = score_network_parameters_of(checkpoint)
+        assert parameters is not None, \
+            "the checkpoint holds no hyper-parameters (not a Lightning checkpoint of the reference's trainer): the config " \
+            "must contain the `model: score_network:` block that describes its network"
+    network = create_score_network(parameters)
+    network.load_state_dict(state_dict_of(checkpoint))
     return network.eval()
 
 
@@ -96,7 +117,7 @@ def main(args: Optional[Any] = None, axl_network: Optional[ScoreNetwork] = None)
         if args.random_init_seed is not None:
             torch.manual_seed(args.random_init_seed)
             axl_network = create_score_network(
-                create_score_network_parameters(hyper_params["model"]["score_network"])).eval()
+                create_score_network_parameters(hyper_params["model"]["score_network"], global_parameters_of(hyper_params))).eval()
         else:
             assert args.checkpoint is not None and os.path.exists(args.checkpoint), \
                 f"The path {args.checkpoint} does not exist. Cannot go on."

@@ -141,3 +141,54 @@ class GaussianWellScoreNetwork(ScoreNetwork):
         logits = torch.zeros(x.shape[0], x.shape[1], 2, device=x.device)
         logits[..., -1] = -torch.inf
         return AXL(A=logits, X=sigma.reshape(-1, 1, 1) * score, L=torch.zeros(x.shape[0], 6, device=x.device))
+
+
+def write_lightning_style_checkpoint(path, network, parameters, extra_state=None):
+    """A checkpoint laid out the way the reference's Lightning trainer writes one (models/axl_diffusion_lightning_model.py:62-95:
+    `save_hyperparameters` -> `hyper_parameters = {"hyper_params": AXLDiffusionParameters(...)}`; `state_dict` keys carry the
+    module prefix `axl_network.`), for a process that has NEITHER Lightning NOR the reference package: the classes the pickle
+    names are declared under the reference's module paths for the duration of the save and removed again, so the reader meets
+    a file whose classes it cannot import -- a dataclass for the score-network parameters with this package's (= the reference's)
+    field names at `...models.score_networks.<architecture>_score_network`, the outer AXLDiffusionParameters, an optimizer
+    parameter object, a `lightning` callback state."""
+    import dataclasses
+    import sys
+    import types
+    ref = "diffusion_for_multi_scale_molecular_dynamics"
+    cls = type(parameters)
+    made = {}
+
+    def module(name):
+        parts = name.split(".")
+        for k in range(1, len(parts) + 1):            # the parent packages too: pickle imports the dotted path
+            prefix = ".".join(parts[:k])
+            if prefix not in sys.modules:
+                made[prefix] = sys.modules[prefix] = types.ModuleType(prefix)
+                made[prefix].__path__ = []
+        return sys.modules[name]
+
+    def declare(module_name, class_name, fields):
+        declared = dataclasses.make_dataclass(class_name, fields)
+        declared.__module__ = module_name
+        setattr(module(module_name), class_name, declared)
+        return declared
+
+    try:
+        net_module = f"{ref}.models.score_networks.{parameters.architecture}_score_network"
+        Stored = declare(net_module, cls.__name__, [(f.name, object, None) for f in dataclasses.fields(cls)])
+        stored = Stored(**{f.name: getattr(parameters, f.name) for f in dataclasses.fields(cls)})
+        stored.num_lattice_parameters = parameters.num_lattice_parameters          # (set by the reference's __post_init__: pickled too)
+        Optimizer = declare(f"{ref}.models.optimizer", "OptimizerParameters", [("name", str, "adamw"), ("learning_rate", float, 1e-3)])
+        Outer = declare(f"{ref}.models.axl_diffusion_lightning_model", "AXLDiffusionParameters",
+                        [("score_network_parameters", object, None), ("loss_parameters", object, None),
+                         ("optimizer_parameters", object, None), ("kmax_target_score", int, 4)])
+        Callback = declare("lightning.pytorch.callbacks.model_checkpoint", "ModelCheckpointState", [("best_model_score", float, 0.25)])
+        state = {"axl_network." + k: v for k, v in network.state_dict().items()}
+        state.update(extra_state or {"loss_calculator.weights": torch.ones(3)})
+        torch.save({"epoch": 7, "global_step": 1234, "pytorch-lightning_version": "2.2.1", "state_dict": state,
+                    "hparams_name": "hyper_params", "callbacks": {"ModelCheckpoint": Callback()},
+                    "hyper_parameters": {"hyper_params": Outer(score_network_parameters=stored, loss_parameters=(1.0, 1.0, 1.0),
+                                                                optimizer_parameters=Optimizer())}}, path)
+    finally:
+        for name in made:
+            del sys.modules[name]

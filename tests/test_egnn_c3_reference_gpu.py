@@ -383,11 +383,15 @@ def test_egnn_options_at_kernel_widths_on_the_gpu_against_reference(cuda, name, 
         assert layer._chain[1] is not None and layer._chain[1].precision == precision, "the fused edge chain did not run"
 
 
-def test_cli_with_the_experiment_configuration_and_a_checkpoint(cuda, tmp_path):
+@pytest.mark.parametrize("network_from", ["model_block", "checkpoint_hyper_parameters"])
+def test_cli_with_the_experiment_configuration_and_a_checkpoint(cuda, tmp_path, network_from):
     """sample_diffusion end to end on the reference's experiment configuration (experiments/.../Si_2x2x2/config_diffusion_egnn.yaml:
     the `model: score_network:` block and the `diffusion_sampling` noise / sampling blocks, T shortened), the network loaded
     from a Lightning-style checkpoint whose keys are the reference module's (`axl_network.` prefix): same files as the reference
-    writes, and the samples equal a direct LangevinGenerator run with the same seed (sub-batches of 3 + 2)."""
+    writes, and the samples equal a direct LangevinGenerator run with the same seed (sub-batches of 3 + 2).
+    checkpoint_hyper_parameters: the REFERENCE's flow (src/.../sample_diffusion.py:191-205) -- the configuration holds `noise:`
+    and `sampling:` only (experiments/.../Si_1x1x1/config_sample_T=1000.yaml) and the network is rebuilt from the hyper-parameters
+    pickled inside the checkpoint, read without Lightning and without the reference package (utils/lightning_checkpoint.py)."""
     import warnings
     import yaml
     from diffusion_for_multi_scale_molecular_dynamics_amd import sample_diffusion
@@ -403,10 +407,16 @@ def test_cli_with_the_experiment_configuration_and_a_checkpoint(cuda, tmp_path):
                     atom_type_greedy_sampling=False, atom_type_transition_in_corrector=False, number_of_samples=5,
                     record_samples=False, use_fixed_lattice_parameters=True, cell_dimensions=[10.86, 10.86, 10.86],
                     rng_mode="device", seed=123, use_hip_graph=True)
-    (tmp_path / "config.yaml").write_text(yaml.safe_dump(dict(noise=noise, sampling=sampling, elements=["Si"],
-                                                              model=dict(score_network=score_network))))
     net = nets.egnn_c3_net(1)
-    torch.save({"state_dict": {"axl_network." + k: v for k, v in net.state_dict().items()}}, tmp_path / "last_model.ckpt")
+    if network_from == "model_block":
+        (tmp_path / "config.yaml").write_text(yaml.safe_dump(dict(noise=noise, sampling=sampling, elements=["Si"],
+                                                                  model=dict(score_network=score_network))))
+        torch.save({"state_dict": {"axl_network." + k: v for k, v in net.state_dict().items()}}, tmp_path / "last_model.ckpt")
+    else:
+        (tmp_path / "config.yaml").write_text(yaml.safe_dump(dict(noise=noise, sampling=sampling)))
+        parameters = net._hyper_params
+        assert {k: getattr(parameters, k) for k in score_network} == score_network
+        nets.write_lightning_style_checkpoint(tmp_path / "last_model.ckpt", net, parameters)
     sample_diffusion.main(["--config", str(tmp_path / "config.yaml"), "--checkpoint", str(tmp_path / "last_model.ckpt"),
                            "--output", str(tmp_path / "out"), "--device", "cuda"])
     samples = torch.load(tmp_path / "out" / "samples.pt", weights_only=False)
