@@ -3,9 +3,10 @@
 Same flags, YAML surface (`noise:`, `sampling:`, optional `elements:`), and output files (`samples.pt` =
 {"cartesian_positions", "original_axl"}, `trajectories.pt`, `config_backup.yaml`, `console.log`).
 Differences, all additive:
-  * the score network comes from `--checkpoint` (a torch / Lightning checkpoint whose state_dict holds the
-    network under the prefix `axl_network.`) together with the `model: score_network:` block of the config, or is
-    randomly initialised with `--random_init_seed` (synthetic benchmarks);
+  * the score network comes from `--checkpoint` as in the reference -- the trainer's Lightning checkpoint: rebuilt from the
+    hyper-parameters pickled inside it, weights under the prefix `axl_network.` (read without Lightning and without the
+    reference package: utils/lightning_checkpoint.py) -- or, additionally, from a bare state_dict together with a `model:
+    score_network:` block in the config, or is randomly initialised with `--random_init_seed` (synthetic benchmarks);
   * under `torchrun` (one process per GPU) the sub-batches are sharded over the ranks and gathered once (RCCL);
     rank 0 writes the files (`trajectories.pt` holds every rank's recorded sub-batches, in sub-batch order);
   * LAMMPS energies (`oracle:`) and Orion reporting are outside the hot path and are not evaluated.
@@ -32,6 +33,7 @@ from .noise_schedulers.noise_parameters import NoiseParameters
 from .sampling.diffusion_sampling import create_batch_of_samples_sharded
 
 logger = logging.getLogger(__name__)
+NULL_ELEMENT = "NULL_ELEMENT_FOR_PADDING"      # data/element_types.py: the reserved padding element
 
 
 def extract_and_validate_parameters(hyper_params: Dict[AnyStr, Any]):
@@ -113,6 +115,13 @@ def main(args: Optional[Any] = None, axl_network: Optional[ScoreNetwork] = None)
                 socket.gethostname(), args.checkpoint, device, world)
 
     noise_parameters, sampling_parameters = extract_and_validate_parameters(hyper_params)
+    if "elements" in hyper_params:                                     # ElementTypes.validate_elements (data/element_types.py:35-38)
+        elements = hyper_params["elements"]
+        assert NULL_ELEMENT not in elements, f"The element '{NULL_ELEMENT}' is reserved and should not be used."
+        assert len(set(elements)) == len(elements), "Each entry in the elements list should be unique."
+    if "oracle" in hyper_params:
+        logger.warning("The configuration has an `oracle:` block: the energy oracle (LAMMPS) is outside this package's scope; "
+                       "samples.pt is written, energies.pt is not.")
     if axl_network is None:
         if args.random_init_seed is not None:
             torch.manual_seed(args.random_init_seed)
@@ -127,8 +136,11 @@ def main(args: Optional[Any] = None, axl_network: Optional[ScoreNetwork] = None)
         from .models.score_networks.force_field_augmented_score_network import (ForceFieldAugmentedScoreNetwork,
                                                                                  ForceFieldParameters)
         force_field_parameters = ForceFieldParameters(**hyper_params["force_field"])
-        logger.info("Augmenting the AXL_network with an excluding Force Field.")
-        axl_network = ForceFieldAugmentedScoreNetwork(axl_network, force_field_parameters)
+        if force_field_parameters.radial_cutoff > 0.0:
+            logger.info("Augmenting the AXL_network with an excluding Force Field.")
+            axl_network = ForceFieldAugmentedScoreNetwork(axl_network, force_field_parameters)
+        else:
+            logger.info("Force field parameters are present, but the radial cutoff is zero. Using original AXL network")
 
     trajectory_initializer = instantiate_trajectory_initializer(
         sampling_parameters=sampling_parameters,

@@ -460,6 +460,27 @@ def test_cli_end_to_end(cuda, tmp_path):
         if sub == "repaint":
             x = samples["original_axl"].X[:, :3].cpu()
             assert torch.equal(x, constraint.constrained_relative_coordinates.expand(12, 3, 3))
+    # the `force_field:` block (src/sample_diffusion.py:132-139): a positive cutoff wraps the network; a zero cutoff never reaches
+    # the reference's "using original network" branch -- ForceFieldParameters refuses it (force_field_augmented_score_network.py:
+    # 34-38) -- and does not here; an `oracle:` block is reported as out of scope, the samples are still written
+    plain = torch.load(tmp_path / "plain" / "samples.pt", weights_only=False)["original_axl"].X
+    (tmp_path / "ff.yaml").write_text(yaml.safe_dump(dict(cfg, force_field=dict(radial_cutoff=2.5, strength=5.0), oracle=dict(name="lammps"))))
+    sample_diffusion.main(["--config", str(tmp_path / "ff.yaml"), "--output", str(tmp_path / "ff"), "--device", "cuda",
+                           "--random_init_seed", "3"])
+    x = torch.load(tmp_path / "ff" / "samples.pt", weights_only=False)["original_axl"].X
+    assert x.shape == plain.shape and not torch.equal(x, plain)
+    log = (tmp_path / "ff" / "console.log").read_text()
+    assert "excluding Force Field" in log and "energies.pt is not" in log and not (tmp_path / "ff" / "energies.pt").exists()
+    (tmp_path / "ff_zero.yaml").write_text(yaml.safe_dump(dict(cfg, force_field=dict(radial_cutoff=0.0, strength=5.0))))
+    with pytest.raises(AssertionError, match="greater than zero"):
+        sample_diffusion.main(["--config", str(tmp_path / "ff_zero.yaml"), "--output", str(tmp_path / "ff_zero"), "--device", "cuda",
+                               "--random_init_seed", "3"])
+    # the `elements` list is validated (data/element_types.py:35-38)
+    for elements, message in ((["Si", "Si"], "should be unique"), (["NULL_ELEMENT_FOR_PADDING"], "is reserved")):
+        (tmp_path / "bad.yaml").write_text(yaml.safe_dump(dict(cfg, elements=elements)))
+        with pytest.raises(AssertionError, match=message):
+            sample_diffusion.main(["--config", str(tmp_path / "bad.yaml"), "--output", str(tmp_path / "bad"), "--device", "cuda",
+                                   "--random_init_seed", "3"])
 
 
 # -------------------------------------------------------------------------------------------------------------
