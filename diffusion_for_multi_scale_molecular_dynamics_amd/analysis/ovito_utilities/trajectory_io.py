@@ -135,5 +135,6 @@ def create_xyz_files(elements: List[str], visualization_artifacts_path: Path, tr
 def write_samples(samples_path, elements: List[str], output_directory, format: str = "cif"):
     """`samples.pt` of sample_diffusion ({"cartesian_positions", "original_axl"}) -> one file per sampled structure: the
     batch is written as a single 'trajectory' whose steps are the samples."""
-    data = torch.load(samples_path, weights_only=False)
+    from ...utils import reference_pickles
+    data = reference_pickles.load(samples_path)           # (this package's samples.pt or the reference's)
     create_io_files(elements, Path(output_directory), None, data[AXL_COMPOSITION], None, format)

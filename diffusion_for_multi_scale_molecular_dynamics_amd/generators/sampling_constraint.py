@@ -40,5 +40,6 @@ def write_sampling_constraint(sampling_constraint: SamplingConstraint, output_pa
 
 
 def read_sampling_constraint(output_path: Path) -> SamplingConstraint:
-    fields = torch.load(output_path, weights_only=False)
+    from ..utils import reference_pickles
+    fields = reference_pickles.load(output_path)
     return SamplingConstraint(**fields)

@@ -89,7 +89,8 @@ class StartFromGivenConfigurationTrajectoryInitializer(TrajectoryInitializer):
         super().__init__(trajectory_initializer_parameters)
         pickle_path = trajectory_initializer_parameters.path_to_starting_configuration_data_pickle
         assert os.path.isfile(pickle_path), f"starting configuration file not found: {pickle_path}"
-        stored = torch.load(pickle_path, weights_only=False)
+        from ..utils import reference_pickles
+        stored = reference_pickles.load(pickle_path)      # (a file made with the reference's tools names ITS AXL class: read here too)
         self.noisy_starting_composition = stored[NOISY_AXL_COMPOSITION]
         self.start_time_step_index = stored["start_time_step_index"]
 

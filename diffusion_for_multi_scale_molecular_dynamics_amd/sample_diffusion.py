@@ -98,6 +98,9 @@ def main(args: Optional[Any] = None, axl_network: Optional[ScoreNetwork] = None)
     parser.add_argument("--path_to_starting_configuration_data_pickle", default=None)
     parser.add_argument("--path_to_sampling_constraint_data_pickle", default=None)
     parser.add_argument("--device", default="cuda", help="Device to use. Defaults to cuda.")
+    parser.add_argument("--reference_pickles", action="store_true",
+                        help="write samples.pt / trajectories.pt naming the REFERENCE's AXL class, so that the reference's own "
+                             "tools read them with a plain torch.load (default: this package's class)")
     parser.add_argument("--random_init_seed", type=int, default=None,
                         help="build the network of `model.score_network` with random weights (synthetic runs)")
     args = parser.parse_args(args)
@@ -151,10 +154,12 @@ def main(args: Optional[Any] = None, axl_network: Optional[ScoreNetwork] = None)
     generator = instantiate_generator(sampling_parameters=sampling_parameters, noise_parameters=noise_parameters,
                                       axl_network=axl_network, trajectory_initializer=trajectory_initializer,
                                       sampling_constraints=sampling_constraints)
-    create_samples_and_write_to_disk(generator, sampling_parameters, device, args.output, rank)
+    create_samples_and_write_to_disk(generator, sampling_parameters, device, args.output, rank,
+                                     for_reference=args.reference_pickles)
 
 
-def create_samples_and_write_to_disk(generator, sampling_parameters, device, output_path, rank: int = 0):
+def create_samples_and_write_to_disk(generator, sampling_parameters, device, output_path, rank: int = 0,
+                                     for_reference: bool = False):
     """:208-270 (energies / Orion reporting excluded)"""
     logger.info("Generating samples...")
     with torch.no_grad():
@@ -168,15 +173,19 @@ def create_samples_and_write_to_disk(generator, sampling_parameters, device, out
                        fallbacks)
     output_directory = Path(output_path)
     if sampling_parameters.record_samples:
-        write_trajectories(generator.sample_trajectory_recorder, sampling_parameters, output_directory)
+        write_trajectories(generator.sample_trajectory_recorder, sampling_parameters, output_directory, for_reference)
     if rank != 0:
         return
-    with open(output_directory / "samples.pt", "wb") as fd:
-        torch.save(samples_batch, fd)
+    if for_reference:
+        from .utils import reference_pickles
+        reference_pickles.save_for_reference(samples_batch, output_directory / "samples.pt")
+    else:
+        with open(output_directory / "samples.pt", "wb") as fd:
+            torch.save(samples_batch, fd)
     logger.info("Done!")
 
 
-def write_trajectories(recorder, sampling_parameters, output_directory: Path):
+def write_trajectories(recorder, sampling_parameters, output_directory: Path, for_reference: bool = False):
     """`trajectories.pt` of the WHOLE run (src/sample_diffusion.py:253-257).  Under several ranks every rank has recorded its own
     sub-batches: each writes `trajectories.rank{r}.pt` into the (shared, single-node) output directory, and after a barrier
     rank 0 puts the entries back in sub-batch order -- the file a single process would have written -- and removes the
@@ -185,7 +194,7 @@ def write_trajectories(recorder, sampling_parameters, output_directory: Path):
     from .sampling.diffusion_sampling import split_sizes
     from .utils.sample_trajectory import merge_sharded_entries
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        recorder.write_to_pickle(output_directory / "trajectories.pt")
+        recorder.write_to_pickle(output_directory / "trajectories.pt", for_reference=for_reference)
         return
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.save(recorder.entries(), output_directory / f"trajectories.rank{rank}.pt")
@@ -194,7 +203,7 @@ def write_trajectories(recorder, sampling_parameters, output_directory: Path):
         paths = [output_directory / f"trajectories.rank{r}.pt" for r in range(world)]
         per_rank = [torch.load(path, weights_only=False) for path in paths]
         sizes = split_sizes(sampling_parameters.number_of_samples, sampling_parameters.sample_batchsize)
-        merge_sharded_entries(per_rank, sizes, world).write_to_pickle(output_directory / "trajectories.pt")
+        merge_sharded_entries(per_rank, sizes, world).write_to_pickle(output_directory / "trajectories.pt", for_reference=for_reference)
         for path in paths:
             os.remove(path)
     dist.barrier()

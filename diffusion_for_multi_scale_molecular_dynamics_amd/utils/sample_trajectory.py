@@ -56,7 +56,8 @@ class SampleTrajectory:
     def record(self, key: str, entry: Union[Dict[str, Any], NamedTuple]):
         self._internal_data[key].append(entry)
 
-    def write_to_pickle(self, path_to_pickle: str):
+    def write_to_pickle(self, path_to_pickle: str, for_reference: bool = False):
+        """for_reference: name the reference's AXL class in the file (utils/reference_pickles.save_for_reference)."""
         if torch.cuda.is_available():
             torch.cuda.synchronize()          # the recorder's asynchronous device-to-host copies (PinnedStaging)
         data = dict(self._internal_data)
@@ -65,6 +66,10 @@ class SampleTrajectory:
                 data[key] = value[0]
         data = _compact(data)                 # views into the staging chunks -> tensors that own exactly their bytes
         self._internal_data = data
+        if for_reference:
+            from . import reference_pickles
+            reference_pickles.save_for_reference(data, path_to_pickle)
+            return
         with open(path_to_pickle, "wb") as fd:
             torch.save(data, fd)
 

@@ -460,6 +460,16 @@ def test_cli_end_to_end(cuda, tmp_path):
         if sub == "repaint":
             x = samples["original_axl"].X[:, :3].cpu()
             assert torch.equal(x, constraint.constrained_relative_coordinates.expand(12, 3, 3))
+    # --reference_pickles: the same run, its files naming the REFERENCE's AXL class (read back through the tolerant loader)
+    from diffusion_for_multi_scale_molecular_dynamics_amd.utils import reference_pickles
+    sample_diffusion.main(["--config", str(tmp_path / "config.yaml"), "--output", str(tmp_path / "for_reference"), "--device", "cuda",
+                           "--random_init_seed", "3", "--reference_pickles"])
+    for name in ("samples.pt", "trajectories.pt"):
+        raw = (tmp_path / "for_reference" / name).read_bytes()
+        assert b"diffusion_for_multi_scale_molecular_dynamics_amd" not in raw and b"diffusion_for_multi_scale_molecular_dynamics" in raw
+    for_reference = reference_pickles.load(tmp_path / "for_reference" / "samples.pt")
+    assert torch.equal(for_reference["original_axl"].X.cpu(),
+                       torch.load(tmp_path / "plain" / "samples.pt", weights_only=False)["original_axl"].X.cpu())
     # the `force_field:` block (src/sample_diffusion.py:132-139): a positive cutoff wraps the network; a zero cutoff never reaches
     # the reference's "using original network" branch -- ForceFieldParameters refuses it (force_field_augmented_score_network.py:
     # 34-38) -- and does not here; an `oracle:` block is reported as out of scope, the samples are still written
