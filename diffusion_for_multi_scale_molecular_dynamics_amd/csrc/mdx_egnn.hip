@@ -155,7 +155,9 @@ __global__ __launch_bounds__(kBlock) void egnn_node_inputs_rows_kernel(const flo
     // A pass of a wavefront = `per` consecutive nodes: their torus uplifts first, ONE (node, wave vector) pair per lane -- the
     // uplift is a binary64 sine / cosine (correctly rounded to binary32), a few hundred instructions that 13 lanes of 64 would
     // otherwise run once per node -- then the nodes' embedding rows as 16-byte stores.
-    const int per = n_k <= 64 ? 64 / n_k : 1;
+    // (at most four nodes per pass: with the 3 wave vectors of one Bloch shell, 64 / n_k = 21 nodes per pass would hand the whole
+    // batch to a fifth of the launch's wavefronts)
+    const int per = n_k <= 64 ? min(4, 64 / n_k) : 1;
     for (int64_t i0 = wave * per; i0 < n_nodes; i0 += n_waves * per) {
         if (n_k <= 64) {
             const int g = lane / n_k, k = lane - g * n_k;

@@ -21,21 +21,35 @@ from ...noisers.relative_coordinates_noiser import RelativeCoordinatesNoiser
 
 class NoisingTransform:
     def __init__(self, noise_parameters: NoiseParameters, num_atom_types: int, spatial_dimension: int,
-                 use_fixed_lattice_parameters: bool = False, use_optimal_transport: bool = False, device="cuda"):
-        assert not use_optimal_transport, "optimal transport is a training-time augmentation (out of scope)"
+                 use_fixed_lattice_parameters: bool = False, use_optimal_transport: bool = True, device="cuda"):
+        """The reference's signature and defaults (:37-44) + `device`.  Optimal transport (the default there) re-assigns atoms
+        while noising a TRAINING batch: outside the sampling hot path, refused loudly rather than silently skipped -- the
+        sampling path passes use_optimal_transport=False (generators/constrained_langevin_generator.py:71)."""
+        if use_optimal_transport:
+            raise NotImplementedError("NoisingTransform(use_optimal_transport=True) is the training-time augmentation, outside "
+                                      "this package's scope: pass use_optimal_transport=False (as the repaint generator does)")
         self.num_atom_types = num_atom_types
         self.noise_scheduler = NoiseScheduler(noise_parameters, num_classes=num_atom_types + 1, device=device)
         self.lattice_noiser = LatticeNoiser(LatticeDataParameters(
             spatial_dimension=spatial_dimension, use_fixed_lattice_parameters=use_fixed_lattice_parameters))
 
+    def _check_batch(self, batch: Dict):
+        """The fields a batch must hold, with their ranks (:46-60)."""
+        for key in (RELATIVE_COORDINATES, ATOM_TYPES, LATTICE_PARAMETERS):
+            assert key in batch, f"The field '{key}' is missing from the input."
+        assert batch[RELATIVE_COORDINATES].dim() == 3 and batch[ATOM_TYPES].dim() == 2 and batch[LATTICE_PARAMETERS].dim() == 2
+
+    def transform(self, batch: Dict) -> Dict:
+        """The training transform (:62-96: a random time index per structure)."""
+        raise NotImplementedError("NoisingTransform.transform noises a training batch at random time indices: outside the "
+                                  "sampling hot path; the sampler's entry point is transform_given_time_index")
+
     def transform_given_time_index(self, batch: Dict, index_i: int) -> Dict:
         """index_i is the one-based time index (t_1 = delta, ..., t_T = 1)  (:98-120)."""
         assert index_i > 0, "The time index should never be smaller than 1."
         idx = index_i - 1
-        for key in (RELATIVE_COORDINATES, ATOM_TYPES, LATTICE_PARAMETERS):
-            assert key in batch, f"The field '{key}' is missing from the input."
+        self._check_batch(batch)
         x0, a0, l0 = batch[RELATIVE_COORDINATES], batch[ATOM_TYPES], batch[LATTICE_PARAMETERS]
-        assert x0.dim() == 3 and a0.dim() == 2 and l0.dim() == 2
         t = self.noise_scheduler.tables
         bsz, natoms, d = x0.shape
         sigma = float(t.sigma[idx])

@@ -287,10 +287,14 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
     # ---------------------------------------------------------------------------------------------------------
     # network
     # ---------------------------------------------------------------------------------------------------------
-    def _get_model_predictions(self, composition: AXL, time_tensor: torch.Tensor, sigma_noise_tensor: torch.Tensor,
-                               cartesian_forces: torch.Tensor) -> AXL:
-        batch = {NOISY_AXL_COMPOSITION: composition, TIME: time_tensor, NOISE: sigma_noise_tensor,
-                 CARTESIAN_FORCES: cartesian_forces}
+    def _get_model_predictions(self, composition: AXL, time, sigma_noise, cartesian_forces: torch.Tensor) -> AXL:
+        """:113-153.  time / sigma_noise: the reference's floats (expanded to [B, 1] here, as there) or -- what the loop passes
+        -- the [B, 1] device tensors the update kernels' schedule fill wrote, so that no scalar crosses the PCIe bus per step."""
+        if not isinstance(time, torch.Tensor) or time.dim() == 0:
+            time = torch.full((composition.X.shape[0], 1), float(time), dtype=torch.float32, device=composition.X.device)
+        if not isinstance(sigma_noise, torch.Tensor) or sigma_noise.dim() == 0:
+            sigma_noise = torch.full((composition.X.shape[0], 1), float(sigma_noise), dtype=torch.float32, device=composition.X.device)
+        batch = {NOISY_AXL_COMPOSITION: composition, TIME: time, NOISE: sigma_noise, CARTESIAN_FORCES: cartesian_forces}
         return self.axl_network(batch, conditional=False)
 
     # ---------------------------------------------------------------------------------------------------------

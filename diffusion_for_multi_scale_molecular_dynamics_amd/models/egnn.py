@@ -159,6 +159,41 @@ class E_GCL(nn.Module):
             out = out * self.att_mlp(out)
         return out
 
+    # ---- the layer's public pieces under the reference's names (src/models/egnn.py:136-262): plain PyTorch, any edge order.
+    # forward() below does not come through them on the GPU (one MFMA kernel per layer); composed as the reference's forward
+    # composes them they give the same function (tests/test_host_cpu.py::test_e_gcl_public_pieces_compose_to_forward).
+    def message_model(self, source: torch.Tensor, target: torch.Tensor, radial: torch.Tensor) -> torch.Tensor:
+        """m_ij = phi_e(h_i, h_j, |x_i - x_j|^2), gated by its own attention value when `attention`."""
+        out = self.message_mlp(torch.cat([source, target, radial], dim=1))
+        return out * self.att_mlp(out) if self.attention else out
+
+    def node_model(self, x: torch.Tensor, edge_index: torch.Tensor, messages: torch.Tensor) -> torch.Tensor:
+        """h_i' = phi_h(h_i, sum or mean over the edges of source i of m_ij) (+ h_i when `residual`)."""
+        from .egnn_utils import unsorted_segment_mean, unsorted_segment_sum
+        reduce = unsorted_segment_mean if self.message_mean else unsorted_segment_sum
+        out = self.node_mlp(torch.cat([x, reduce(messages, edge_index[:, 0], num_segments=x.size(0))], dim=1))
+        return x + out if self.residual else out
+
+    def coord_model(self, coord: torch.Tensor, edge_index: torch.Tensor, coord_diff: torch.Tensor,
+                    messages: torch.Tensor) -> torch.Tensor:
+        """x_i += sum or mean over the edges of source i of (x_i - x_j) phi_x(m_ij) -- IN PLACE, as the reference."""
+        from .egnn_utils import unsorted_segment_mean, unsorted_segment_sum
+        reduce = unsorted_segment_mean if self.coords_mean else unsorted_segment_sum
+        coord += reduce(coord_diff * self.coord_mlp(messages), edge_index[:, 0], num_segments=coord.size(0))
+        return coord
+
+    def coord2radial(self, edge_index: torch.Tensor, coord: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(|x_i - x_j|^2 [E, 1], x_i - x_j [E, d]); with `normalize` the difference is scaled by normalize_radial_norm."""
+        coord_diff = coord[edge_index[:, 0]] - coord[edge_index[:, 1]]
+        radial = torch.sum(coord_diff ** 2, 1).unsqueeze(1)
+        if self.normalize:
+            coord_diff = self.normalize_radial_norm(radial) * coord_diff
+        return radial, coord_diff
+
+    def normalize_radial_norm(self, radial_norm_squared: torch.Tensor) -> torch.Tensor:
+        """tanh(r^2) / sqrt(r^2 + epsilon^2): the scaled difference goes to 0 like r^2 at contact and to unit length far away."""
+        return torch.tanh(radial_norm_squared) / torch.sqrt(radial_norm_squared + self.epsilon ** 2)
+
     def _chain_modules(self):
         """(first message layer, message H->H layers, coordinate H->H layers, coordinate head) if the per-edge MLPs have
         the Linear / SiLU alternation the fused kernel implements, else None.  The layer's options ride along: `tanh` is the

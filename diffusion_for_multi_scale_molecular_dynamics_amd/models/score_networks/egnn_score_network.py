@@ -42,12 +42,10 @@ class EGNNScoreNetworkParameters(ScoreNetworkParameters):
     drop_duplicate_edges: bool = True
 
 
-def positive_bloch_wave_vectors(number_of_complete_shells: int, spatial_dimension: int) -> torch.Tensor:
-    """Integer reciprocal-lattice vectors of the first shells of the cubic point group, one per +-K pair.
-
-    Same set and order as get_cubic_point_group_positive_normalized_bloch_wave_vectors
-    (src/.../utils/lattice_utils.py:130-177): shells by increasing |K|^2 (degenerate shells all kept), vectors of
-    a shell in descending lexicographic order, the first of each {K, -K} pair retained."""
+def complete_lattice_shells(number_of_complete_shells: int, spatial_dimension: int):
+    """The first shells of integer lattice vectors under the cubic point group, zero excluded: shells by increasing |K|^2 (when
+    the last wanted shell shares its length with others, those are kept too), the vectors of a shell in descending lexicographic
+    order -- the set and order of get_cubic_point_group_complete_lattice_shells (src/.../utils/lattice_utils.py:66-126)."""
     n = 2 * number_of_complete_shells
     vectors = [v for v in itertools.product(range(-n, n + 1), repeat=spatial_dimension) if any(v)]
     vectors.sort(key=lambda v: (sum(c * c for c in v), tuple(-c for c in v)))
@@ -65,8 +63,16 @@ def positive_bloch_wave_vectors(number_of_complete_shells: int, spatial_dimensio
         if len(shells) >= number_of_complete_shells and norm > previous_norm:
             break
         previous_norm = norm
+    return shells
+
+
+def positive_bloch_wave_vectors(number_of_complete_shells: int, spatial_dimension: int) -> torch.Tensor:
+    """Integer reciprocal-lattice vectors of the first shells of the cubic point group, one per +-K pair.
+
+    Same set and order as get_cubic_point_group_positive_normalized_bloch_wave_vectors
+    (src/.../utils/lattice_utils.py:130-177): the shells of complete_lattice_shells, the first of each {K, -K} pair retained."""
     half = []
-    for shell in shells:
+    for shell in complete_lattice_shells(number_of_complete_shells, spatial_dimension):
         known = set()
         for v in shell:
             if v in known:

@@ -8,7 +8,7 @@ embedding and the input concatenation are laid out to be a handful of GEMMs with
 import itertools
 import math
 from dataclasses import dataclass
-from typing import AnyStr, Dict
+from typing import Any, AnyStr, Dict
 
 import torch
 from torch import nn
@@ -102,6 +102,14 @@ class MLPScoreNetwork(ScoreNetwork):
             outs.append(AXL(A=o.A, X=o.X[:, inv], L=o.L))
         return AXL(A=torch.stack([o.A for o in outs]).mean(dim=0), X=torch.stack([o.X for o in outs]).mean(dim=0),
                    L=torch.stack([o.L for o in outs]).mean(dim=0))
+
+    def get_permuted_batch(self, batch, permutation) -> Dict[AnyStr, Any]:
+        """The batch with the atoms of its composition re-ordered by `permutation` (atom types and coordinates; the lattice and
+        every other entry as they are) (:250-267)."""
+        comp = batch[NOISY_AXL_COMPOSITION]
+        permuted = dict(batch)
+        permuted[NOISY_AXL_COMPOSITION] = AXL(A=comp.A[:, permutation], X=comp.X[:, permutation], L=comp.L)
+        return permuted
 
     def _single(self, comp: AXL, batch, conditional: bool) -> AXL:
         x = comp.X

@@ -36,6 +36,13 @@ class NoiseScheduler:
                       indices=torch.arange(0, self.noise_parameters.total_time_steps, device=t.device))
         return noise, LangevinDynamics(epsilon=t.epsilon, sqrt_2_epsilon=t.sqrt_2_epsilon)
 
+    def get_random_noise_sample(self, batch_size: int) -> Noise:
+        """One uniformly drawn time index (0 .. T - 1) per structure and the schedule's rows there (:289-308; the training side's
+        entry point -- the sampler walks the indices in order)."""
+        t = self.tables
+        indices = torch.randint(0, self.noise_parameters.total_time_steps, size=(batch_size,), device=t.device)
+        return self.get_noise_from_indices(indices)
+
     def get_noise_from_indices(self, indices: torch.Tensor) -> Noise:
         """noise_scheduler.py:310-346"""
         t = self.tables

@@ -28,12 +28,12 @@ from .generators.load_sampling_parameters import load_sampling_parameters
 from .generators.sampling_constraint import read_sampling_constraint
 from .generators.trajectory_initializer import instantiate_trajectory_initializer
 from .models.score_networks.score_network import ScoreNetwork
+from .data.element_types import ElementTypes
 from .models.score_networks.score_network_factory import create_score_network, create_score_network_parameters
 from .noise_schedulers.noise_parameters import NoiseParameters
 from .sampling.diffusion_sampling import create_batch_of_samples_sharded
 
 logger = logging.getLogger(__name__)
-NULL_ELEMENT = "NULL_ELEMENT_FOR_PADDING"      # data/element_types.py: the reserved padding element
 
 
 def extract_and_validate_parameters(hyper_params: Dict[AnyStr, Any]):
@@ -118,10 +118,8 @@ def main(args: Optional[Any] = None, axl_network: Optional[ScoreNetwork] = None)
                 socket.gethostname(), args.checkpoint, device, world)
 
     noise_parameters, sampling_parameters = extract_and_validate_parameters(hyper_params)
-    if "elements" in hyper_params:                                     # ElementTypes.validate_elements (data/element_types.py:35-38)
-        elements = hyper_params["elements"]
-        assert NULL_ELEMENT not in elements, f"The element '{NULL_ELEMENT}' is reserved and should not be used."
-        assert len(set(elements)) == len(elements), "Each entry in the elements list should be unique."
+    if "elements" in hyper_params:
+        ElementTypes.validate_elements(hyper_params["elements"])
     if "oracle" in hyper_params:
         logger.warning("The configuration has an `oracle:` block: the energy oracle (LAMMPS) is outside this package's scope; "
                        "samples.pt is written, energies.pt is not.")

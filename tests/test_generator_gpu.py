@@ -763,7 +763,10 @@ def test_noising_transform_given_time_index(cuda, oracle):
     l0 = torch.rand(B, 6) + 5
     sched = oracle.noise_schedule(10, num_classes=nat + 1)
     for fixed in (True, False):
-        tr = NoisingTransform(npar, num_atom_types=nat, spatial_dimension=3, use_fixed_lattice_parameters=fixed, device=cuda)
+        with pytest.raises(NotImplementedError, match="training-time"):       # the reference's default (optimal transport): refused loudly
+            NoisingTransform(npar, num_atom_types=nat, spatial_dimension=3, use_fixed_lattice_parameters=fixed, device=cuda)
+        tr = NoisingTransform(npar, num_atom_types=nat, spatial_dimension=3, use_fixed_lattice_parameters=fixed,
+                              use_optimal_transport=False, device=cuda)
         for index_i in (1, 4, 10):
             torch.manual_seed(index_i)
             out = tr.transform_given_time_index({RELATIVE_COORDINATES: x0.to(cuda), ATOM_TYPES: a0.to(cuda),
