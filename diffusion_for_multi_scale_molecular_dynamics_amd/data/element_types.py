@@ -7,32 +7,35 @@ NULL_ELEMENT_ID = -1
 
 
 class ElementTypes:
+    """Both directions of the map live in ONE tuple: the sorted symbols; index = atom type.  The padding symbol is answered
+    beside it."""
+
+    __slots__ = ("_symbols",)
+
     def __init__(self, elements: List[str]):
-        self.validate_elements(elements)
-        self._elements = sorted(elements)
-        self._symbol_of = dict(enumerate(self._elements))
-        self._symbol_of[NULL_ELEMENT_ID] = NULL_ELEMENT
-        self._id_of = {symbol: index for index, symbol in self._symbol_of.items()}
+        ElementTypes.validate_elements(elements)
+        self._symbols = tuple(sorted(elements))
 
     @staticmethod
     def validate_elements(elements: List[str]):
         assert NULL_ELEMENT not in elements, f"The element '{NULL_ELEMENT}' is reserved and should not be used."
         assert len(set(elements)) == len(elements), "Each entry in the elements list should be unique."
 
-    @property
-    def number_of_atom_types(self) -> int:
-        return len(self._elements)
-
-    @property
-    def elements(self) -> List[str]:
-        return self._elements
-
-    @property
-    def element_ids(self) -> List[int]:
-        return list(range(len(self._elements)))
+    number_of_atom_types = property(lambda self: len(self._symbols))
+    elements = property(lambda self: list(self._symbols))
+    element_ids = property(lambda self: list(range(len(self._symbols))))
 
     def get_element(self, element_id: int) -> str:
-        return self._symbol_of[element_id]
+        if element_id == NULL_ELEMENT_ID:
+            return NULL_ELEMENT
+        if not 0 <= element_id < len(self._symbols):
+            raise KeyError(element_id)
+        return self._symbols[element_id]
 
     def get_element_id(self, element: str) -> int:
-        return self._id_of[element]
+        if element == NULL_ELEMENT:
+            return NULL_ELEMENT_ID
+        try:
+            return self._symbols.index(element)
+        except ValueError:
+            raise KeyError(element) from None
