@@ -152,13 +152,16 @@ def main(args: Optional[Any] = None, axl_network: Optional[ScoreNetwork] = None)
     generator = instantiate_generator(sampling_parameters=sampling_parameters, noise_parameters=noise_parameters,
                                       axl_network=axl_network, trajectory_initializer=trajectory_initializer,
                                       sampling_constraints=sampling_constraints)
-    create_samples_and_write_to_disk(generator, sampling_parameters, device, args.output, rank,
+    create_samples_and_write_to_disk(generator, sampling_parameters, None, device, args.output, rank,
                                      for_reference=args.reference_pickles)
 
 
-def create_samples_and_write_to_disk(generator, sampling_parameters, device, output_path, rank: int = 0,
+def create_samples_and_write_to_disk(generator, sampling_parameters, oracle_parameters, device, output_path, rank: int = 0,
                                      for_reference: bool = False):
-    """:208-270 (energies / Orion reporting excluded)"""
+    """:208-270.  oracle_parameters: the reference's third argument (an energy oracle to evaluate the samples with, LAMMPS):
+    outside this package's scope -- anything but None is refused; Orion reporting likewise absent."""
+    if oracle_parameters is not None:
+        raise NotImplementedError("energy oracles (LAMMPS) are outside this package's scope: pass oracle_parameters=None")
     logger.info("Generating samples...")
     with torch.no_grad():
         samples_batch = create_batch_of_samples_sharded(generator=generator, sampling_parameters=sampling_parameters,

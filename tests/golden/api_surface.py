@@ -41,14 +41,75 @@ def compare_callable(where, ref_fn, own_fn, report):
     if ref_p is None or own_p is None:
         return
     names_match = [n for n, _ in ref_p] == [n for n, _ in own_p][:len(ref_p)]
-    defaults_match = all(default == dict(own_p).get(name) for name, default in ref_p)
+    # (a parameter the reference REQUIRES may be optional here: an extension, not a difference)
+    defaults_match = all(default is None or default == dict(own_p).get(name) for name, default in ref_p)
     if not (names_match and defaults_match):
         report["signature_differences"].append(dict(where=where, reference=ref_p, own=own_p))
 
 
+def syntax_parameters(node):
+    import ast
+    args = node.args
+    positional = args.posonlyargs + args.args
+    defaults = [None] * (len(positional) - len(args.defaults)) + [ast.unparse(d) for d in args.defaults]
+    out = list(zip([a.arg for a in positional], defaults))
+    out += [(a.arg, None if d is None else ast.unparse(d)) for a, d in zip(args.kwonlyargs, args.kw_defaults)]
+    return out
+
+
+def compare_by_syntax(rel, reference_source, own_module, report):
+    """The same comparison from the reference module's source text (it cannot be imported here): public functions, classes and
+    their public methods, parameter names and order; defaults compared as source text after `ast.unparse` on both sides."""
+    import ast
+    tree = ast.parse(open(reference_source).read())
+    own_tree = ast.parse(open(own_module.__file__).read())
+    own_functions = {n.name: n for n in own_tree.body if isinstance(n, ast.FunctionDef)}
+    own_classes = {n.name: n for n in own_tree.body if isinstance(n, ast.ClassDef)}
+
+    def compare(where, ref_node, own_node):
+        ref_p, own_p = syntax_parameters(ref_node), syntax_parameters(own_node)
+        names_match = [n for n, _ in ref_p] == [n for n, _ in own_p][:len(ref_p)]
+        # (a parameter the reference REQUIRES may be optional here: an extension, not a difference)
+        defaults_match = all(default is None or default == dict(own_p).get(name) for name, default in ref_p)
+        if not (names_match and defaults_match):
+            report["signature_differences"].append(dict(where=where, reference=ref_p, own=own_p))
+
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and not node.name.startswith("_"):
+            if node.name not in own_functions and not hasattr(own_module, node.name):
+                report["public_missing"].append(f"{rel}.{node.name}")
+            elif node.name in own_functions:
+                compare(f"{rel}.{node.name}", node, own_functions[node.name])
+        elif isinstance(node, ast.ClassDef) and not node.name.startswith("_"):
+            if node.name not in own_classes and not hasattr(own_module, node.name):
+                report["public_missing"].append(f"{rel}.{node.name}")
+                continue
+            own_class = own_classes.get(node.name)
+            own_object = getattr(own_module, node.name)
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and (not item.name.startswith("_") or item.name in PRIVATE_BUT_SERVED | {"__init__"}):
+                    if not hasattr(own_object, item.name):
+                        report["public_missing"].append(f"{rel}.{node.name}.{item.name}")
+                    elif own_class is not None:
+                        mine = [m for m in own_class.body if isinstance(m, ast.FunctionDef) and m.name == item.name]
+                        if mine:
+                            compare(f"{rel}.{node.name}.{item.name}", item, mine[0])
+                elif isinstance(item, ast.AnnAssign) and isinstance(item.target, ast.Name) and not item.target.id.startswith("_"):
+                    # a dataclass field: it must exist here with the same default
+                    import dataclasses as dc
+                    if dc.is_dataclass(own_object):
+                        fields = {f.name: f for f in dc.fields(own_object)}
+                        if item.target.id not in fields:
+                            report["dataclass_differences"].append(dict(where=f"{rel}.{node.name}", missing=[item.target.id]))
+                        elif item.value is not None and not isinstance(item.value, ast.Call):
+                            want = ast.literal_eval(item.value) if isinstance(item.value, (ast.Constant, ast.List, ast.Tuple, ast.UnaryOp)) else None
+                            if want is not None and fields[item.target.id].default != want:
+                                report["dataclass_differences"].append(dict(where=f"{rel}.{node.name}", default_differs=[item.target.id]))
+
+
 def main():
     import diffusion_for_multi_scale_molecular_dynamics_amd as own_package
-    report = dict(modules_compared=[], modules_without_counterpart=[], public_missing=[], served_private_missing=[],
+    report = dict(modules_compared=[], modules_compared_by_syntax=[], modules_without_counterpart=[], public_missing=[], served_private_missing=[],
                   signature_differences=[], dataclass_differences=[])
     for info in sorted(pkgutil.walk_packages(own_package.__path__, OWN + "."), key=lambda m: m.name):
         rel = info.name[len(OWN):]
@@ -58,8 +119,14 @@ def main():
         try:
             ref_module = importlib.import_module(REF + rel)
         except ImportError as exc:
-            # absent in the reference (this package's own modules), or not importable here (it needs torchode / mace / lightning / pymatgen)
-            report["modules_without_counterpart"].append(dict(module=rel, why=f"{type(exc).__name__}: {exc}"[:120]))
+            # absent in the reference (this package's own modules), or not importable here (it needs torchode / mace / lightning /
+            # pymatgen / orion): then its SOURCE TEXT is parsed instead (names, parameters, defaults)
+            source = os.path.join(os.path.dirname(importlib.import_module(REF).__file__), *rel.strip(".").split(".")) + ".py"
+            if os.path.isfile(source):
+                compare_by_syntax(rel, source, own_module, report)
+                report["modules_compared_by_syntax"].append(rel)
+            else:
+                report["modules_without_counterpart"].append(dict(module=rel, why=f"{type(exc).__name__}: {exc}"[:120]))
             continue
         report["modules_compared"].append(rel)
         for name, ref_obj in vars(ref_module).items():

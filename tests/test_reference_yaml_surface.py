@@ -180,8 +180,8 @@ def test_files_cross_between_the_reference_and_this_package(tmp_path):
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference is not on this machine")
 def test_public_surface_of_the_modules_shared_with_the_reference():
-    """tests/golden/api_surface.py: for the 30 modules of this package that exist at the same relative path in the reference
-    (and are importable there), every public class, function and method the reference defines is here, dataclass fields and
+    """tests/golden/api_surface.py: for the 37 modules of this package that exist at the same relative path in the reference
+    (30 importable there, 7 read from their source text), every public class, function and method the reference defines is here, dataclass fields and
     defaults agree, parameters carry the reference's names, order and defaults, and the private methods the reference's tests and
     subclasses reach for are served; the small helpers under the reference's paths return the reference's values.  The modules
     without a counterpart are this package's own (kernels, RNG sources, pickles) or need a dependency the container lacks to
@@ -191,12 +191,18 @@ def test_public_surface_of_the_modules_shared_with_the_reference():
     assert run.returncode == 0, run.stderr[-3000:]
     report = json.loads(run.stdout.strip().splitlines()[-1])
     assert len(report["modules_compared"]) >= 30
-    assert report["public_missing"] == [] and report["served_private_missing"] == []
+    # seven more cannot be imported on the reference's side here (pymatgen, torchode, mace, orion): compared from their source text
+    assert set(report["modules_compared_by_syntax"]) == {
+        ".analysis.ovito_utilities.trajectory_io", ".utils.structure_utils", ".generators.instantiate_generator",
+        ".generators.load_sampling_parameters", ".sampling.diffusion_sampling_parameters",
+        ".models.score_networks.score_network_factory", ".sample_diffusion"}
+    # what is knowingly absent: the pymatgen-based INSIDES of the reference's CIF / XYZ writers (its public entry points
+    # create_cif_files / create_xyz_files / create_io_files are here, writing the text themselves) and the pymatgen Structure factory
+    accepted = {".analysis.ovito_utilities.trajectory_io." + name for name in (
+        "get_list_site_properties_and_atomic_properties_dim", "get_list_trajectory_AXLs", "StructureWriter", "CifStructureWriter",
+        "XyzStructureWriter")} | {".utils.structure_utils.create_structure"}
+    assert set(report["public_missing"]) == accepted and report["served_private_missing"] == []
     assert report["signature_differences"] == [] and report["dataclass_differences"] == []
     assert all(report["helper_values"].values()), report["helper_values"]
     own_only = {".kernels", "._hip", ".generators.noise_sources", ".utils.batch_statistics", ".utils.lightning_checkpoint", ".utils.reference_pickles"}
-    needs_a_missing_dependency = {".analysis.ovito_utilities.trajectory_io", ".utils.structure_utils",                       # pymatgen
-                                  ".generators.instantiate_generator", ".generators.load_sampling_parameters",             # torchode
-                                  ".sampling.diffusion_sampling_parameters", ".models.score_networks.score_network_factory",   # torchode, mace
-                                  ".sample_diffusion"}                                                                       # orion
-    assert {m["module"] for m in report["modules_without_counterpart"]} <= own_only | needs_a_missing_dependency
+    assert {m["module"] for m in report["modules_without_counterpart"]} <= own_only
