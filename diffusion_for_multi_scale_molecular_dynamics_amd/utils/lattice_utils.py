@@ -13,11 +13,17 @@ def get_relative_coordinates_lattice_vectors(number_of_shells: int = 1, spatial_
     return torch.tensor(list(itertools.product(steps, repeat=spatial_dimension)), dtype=torch.float32)
 
 
+def _sort_complete_shell(complete_shell: torch.Tensor) -> torch.Tensor:
+    """The rows of a shell [members, d] in descending lexicographic order: the most positive leading components first (:32-63)."""
+    rows = sorted((tuple(row) for row in complete_shell.tolist()), reverse=True)
+    return torch.tensor(rows, dtype=complete_shell.dtype).reshape(complete_shell.shape)
+
+
 def get_cubic_point_group_complete_lattice_shells(number_of_complete_shells: int, spatial_dimension: int = 3) -> List[torch.Tensor]:
-    """The first complete shells of integer lattice vectors under the cubic point group, one int64 tensor [members, d] per
+    """The first complete shells of integer lattice vectors under the cubic point group, one int32 tensor [members, d] per
     shell (:66-126)."""
     from ..models.score_networks.egnn_score_network import complete_lattice_shells
-    return [torch.tensor(shell, dtype=torch.int64) for shell in complete_lattice_shells(number_of_complete_shells, spatial_dimension)]
+    return [torch.tensor(shell, dtype=torch.int32) for shell in complete_lattice_shells(number_of_complete_shells, spatial_dimension)]
 
 
 def get_cubic_point_group_positive_normalized_bloch_wave_vectors(number_of_complete_shells: int,
@@ -25,4 +31,4 @@ def get_cubic_point_group_positive_normalized_bloch_wave_vectors(number_of_compl
     """One integer reciprocal-lattice vector per {K, -K} pair of the first complete shells of the cubic point group (:129-177):
     the wave vectors of the EGNN's torus uplift (models/score_networks/egnn_score_network.positive_bloch_wave_vectors)."""
     from ..models.score_networks.egnn_score_network import positive_bloch_wave_vectors
-    return positive_bloch_wave_vectors(number_of_complete_shells, spatial_dimension)
+    return positive_bloch_wave_vectors(number_of_complete_shells, spatial_dimension).to(torch.int32)      # (integers, as there)

@@ -185,10 +185,12 @@ def helper_values():
                                                       for n in (1, 2) for d in (1, 2, 3))
     ref_f, own_f = both(".utils.lattice_utils", "get_cubic_point_group_complete_lattice_shells")
     out["complete_lattice_shells"] = all(
-        len(ref_f(n, d)) == len(own_f(n, d)) and all(torch.equal(a.long(), b) for a, b in zip(ref_f(n, d), own_f(n, d)))
+        len(ref_f(n, d)) == len(own_f(n, d)) and all(torch.equal(a, b) and a.dtype == b.dtype for a, b in zip(ref_f(n, d), own_f(n, d)))
         for n in (1, 2, 3) for d in (1, 2, 3))
     ref_f, own_f = both(".utils.lattice_utils", "get_cubic_point_group_positive_normalized_bloch_wave_vectors")
-    out["positive_bloch_wave_vectors"] = all(torch.equal(ref_f(n, d).float(), own_f(n, d)) for n in (1, 2, 3) for d in (1, 2, 3))
+    out["positive_bloch_wave_vectors"] = all(torch.equal(ref_f(n, d), own_f(n, d)) and ref_f(n, d).dtype == own_f(n, d).dtype for n in (1, 2, 3) for d in (1, 2, 3))
+    ref_f, own_f = both(".utils.geometric_utils", "get_cubic_point_group_symmetries")
+    out["cubic_point_group_symmetries"] = all(torch.equal(ref_f(d), own_f(d)) and ref_f(d).dtype == own_f(d).dtype for d in (1, 2, 3))
     times = torch.linspace(0.0, 1.0, 33)
     ref_f, own_f = both(".noise_schedulers.sigma_calculator", "instantiate_sigma_calculator")
     out["sigma_calculators"] = all(

@@ -607,7 +607,8 @@ def test_small_modules_under_the_reference_paths():
     vectors = lattice_utils.get_relative_coordinates_lattice_vectors(1, 3)
     assert vectors.dtype == torch.float32 and vectors.tolist() == [list(map(float, v)) for v in itertools.product((-1, 0, 1), repeat=3)]
     assert lattice_utils.get_relative_coordinates_lattice_vectors(2, 2).shape == (25, 2)
-    assert lattice_utils.get_cubic_point_group_positive_normalized_bloch_wave_vectors(1, 3).tolist() == [[1, 0, 0], [0, 1, 0], [0, 0, 1]]
+    bloch = lattice_utils.get_cubic_point_group_positive_normalized_bloch_wave_vectors(1, 3)
+    assert bloch.dtype == torch.int32 and bloch.tolist() == [[1, 0, 0], [0, 1, 0], [0, 0, 1]]
     data, ids = torch.arange(12.0).reshape(6, 2), torch.tensor([2, 0, 2, 2, 0, 3])
     assert egnn_utils.unsorted_segment_sum(data, ids, 5).tolist() == [[10.0, 12.0], [0.0, 0.0], [10.0, 13.0], [10.0, 11.0], [0.0, 0.0]]
     assert torch.allclose(egnn_utils.unsorted_segment_mean(data, ids, 5),

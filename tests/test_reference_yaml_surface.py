@@ -206,3 +206,26 @@ def test_public_surface_of_the_modules_shared_with_the_reference():
     assert all(report["helper_values"].values()), report["helper_values"]
     own_only = {".kernels", "._hip", ".generators.noise_sources", ".utils.batch_statistics", ".utils.lightning_checkpoint", ".utils.reference_pickles"}
     assert {m["module"] for m in report["modules_without_counterpart"]} <= own_only
+
+
+REFERENCE_TEST_FILES = {        # the reference's own test files that need no GPU: file -> tests it holds (all must pass)
+    "tests/noise_schedulers/test_sigma_calculator.py": 2, "tests/utils/test_lattice_utils.py": 12, "tests/utils/test_noise_utils.py": 6,
+    "tests/models/test_egnn_utils.py": 2, "tests/generators/test_sampling_constraint.py": 2, "tests/sampling/test_diffusion_sampling.py": 1}
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference is not on this machine")
+@pytest.mark.parametrize("test_file", list(REFERENCE_TEST_FILES))
+def test_the_references_own_tests_of_the_host_side_helpers_pass_here(test_file, tmp_path):
+    """The reference's OWN test files, unmodified, run against this package: a child pytest with an import alias
+    (tests/golden/reference_import_alias.py: the reference's module names resolve to this package's modules; the reference's
+    source is not on the path) collects the file from /root/reference/tests and every test in it passes.  Only the files that
+    need no GPU can run in this container (everything that reaches a kernel refuses host tensors: there is no CPU fallback --
+    e.g. tests/utils/test_structure_utils.py::test_compute_distances stops at exactly that message)."""
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    env["PYTHONPATH"] = os.pathsep.join([GOLDEN, ROOT])
+    run = subprocess.run([sys.executable, "-m", "pytest", "-p", "reference_import_alias", os.path.join(REFERENCE, test_file), "-q",
+                          "--no-header", "-p", "no:cacheprovider", "--rootdir", str(tmp_path)],
+                         env=env, cwd=REFERENCE, capture_output=True, text=True, timeout=600)
+    tail = run.stdout.strip().splitlines()[-1] if run.stdout.strip() else run.stderr[-500:]
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-1000:]
+    assert f"{REFERENCE_TEST_FILES[test_file]} passed" in tail and "failed" not in tail and "error" not in tail, tail
