@@ -210,15 +210,17 @@ def test_public_surface_of_the_modules_shared_with_the_reference():
 
 REFERENCE_TEST_FILES = {        # the reference's own test files that need no GPU: file -> tests it holds (all must pass)
     "tests/noise_schedulers/test_sigma_calculator.py": 2, "tests/utils/test_lattice_utils.py": 12, "tests/utils/test_noise_utils.py": 6,
-    "tests/models/test_egnn_utils.py": 2, "tests/generators/test_sampling_constraint.py": 2, "tests/sampling/test_diffusion_sampling.py": 1}
+    "tests/models/test_egnn_utils.py": 2, "tests/generators/test_sampling_constraint.py": 2, "tests/sampling/test_diffusion_sampling.py": 1,
+    "tests/noise_schedulers/test_exploding_variance.py": 6}
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference is not on this machine")
 @pytest.mark.parametrize("test_file", list(REFERENCE_TEST_FILES))
 def test_the_references_own_tests_of_the_host_side_helpers_pass_here(test_file, tmp_path):
     """The reference's OWN test files, unmodified, run against this package: a child pytest with an import alias
-    (tests/golden/reference_import_alias.py: the reference's module names resolve to this package's modules; the reference's
-    source is not on the path) collects the file from /root/reference/tests and every test in it passes.  Only the files that
+    (tests/golden/reference_import_alias.py: the reference's module names -- also in the `src.`-prefixed form some of its test
+    files use -- resolve to this package's modules; the plugin fails the run if any module of the reference's source tree was
+    imported) collects the file from /root/reference/tests and every test in it passes.  Only the files that
     need no GPU can run in this container (everything that reaches a kernel refuses host tensors: there is no CPU fallback --
     e.g. tests/utils/test_structure_utils.py::test_compute_distances stops at exactly that message)."""
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
