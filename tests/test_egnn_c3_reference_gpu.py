@@ -431,3 +431,45 @@ def test_cli_with_the_experiment_configuration_and_a_checkpoint(cuda, tmp_path, 
     with torch.no_grad():
         direct = torch.cat([gen.sample(3, cuda).X, gen.sample(2, cuda).X])
     assert torch.equal(direct.cpu(), axl.X.cpu())
+
+
+def test_cli_with_the_shipped_si_1x1x1_sampling_configuration(cuda, tmp_path):
+    """The reference's own sampling run, as shipped: experiments/training_and_sampling_generative_models/inputs_and_scripts/Si_1x1x1/
+    config_sample_T=1000.yaml (restated below key for key: noise + sampling + the metrics / elements / spatial_dimension / oracle
+    blocks it carries, NO model block) with a Lightning-style checkpoint of the network that directory trains
+    (config_diffusion_egnn.yaml:44-60: EGNN 4 x 256 x 4, fully connected) -- the command line of draw_samples.sh.  The 1000-step
+    job runs in the reference's mode (host draws, eager launches: the file sets no fast-mode key), writes samples.pt and the
+    recorded trajectories, and says that the oracle block is not evaluated."""
+    import yaml
+    from diffusion_for_multi_scale_molecular_dynamics_amd import sample_diffusion
+    from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import (
+        EGNNScoreNetwork, EGNNScoreNetworkParameters)
+    shipped = dict(
+        noise=dict(total_time_steps=1000, sigma_min=0.0001, sigma_max=0.2, schedule_type="linear", corrector_step_epsilon=2.5e-8),
+        sampling=dict(algorithm="predictor_corrector", num_atom_types=1, sample_batchsize=16, spatial_dimension=3,
+                      number_of_corrector_steps=2, number_of_atoms=8, number_of_samples=16, record_samples=True,
+                      use_fixed_lattice_parameters=True, cell_dimensions=[5.43, 5.43, 5.43]),
+        metrics=dict(compute_energies=True, compute_structure_factor=True, structure_factor_max_distance=5.0),
+        elements=["Si"], spatial_dimension=3, oracle=dict(name="lammps", sw_coeff_filename="Si.sw"))
+    (tmp_path / "config_sample.yaml").write_text(yaml.safe_dump(shipped))
+    parameters = EGNNScoreNetworkParameters(num_atom_types=1, n_layers=4, coordinate_hidden_dimensions_size=256,
+                                            coordinate_n_hidden_dimensions=4, coords_agg="mean", message_hidden_dimensions_size=256,
+                                            message_n_hidden_dimensions=4, message_agg="mean", node_hidden_dimensions_size=256,
+                                            node_n_hidden_dimensions=4, attention=False, normalize=False, residual=True, tanh=False,
+                                            edges="fully_connected")
+    torch.manual_seed(21)
+    network = EGNNScoreNetwork(parameters)
+    nets.write_lightning_style_checkpoint(tmp_path / "last_model.ckpt", network, parameters)
+    sample_diffusion.main(["--config", str(tmp_path / "config_sample.yaml"), "--checkpoint", str(tmp_path / "last_model.ckpt"),
+                           "--output", str(tmp_path / "samples"), "--device", "cuda"])
+    samples = torch.load(tmp_path / "samples" / "samples.pt", weights_only=False)
+    axl = samples["original_axl"]
+    assert samples["cartesian_positions"].shape == (16, 8, 3) and axl.A.shape == (16, 8) and axl.L.shape == (16, 6)
+    assert (axl.A == 0).all() and ((axl.X >= 0) & (axl.X < 1)).all() and torch.isfinite(axl.X).all()
+    assert torch.allclose(samples["cartesian_positions"].cpu(), axl.X.cpu() * 5.43)
+    trajectories = torch.load(tmp_path / "samples" / "trajectories.pt", weights_only=False)
+    # (corrector steps are recorded only with record_samples_corrector_steps, which the file does not set: langevin_generator.py:74)
+    assert len(trajectories["predictor_step"]) == 1000 and "corrector_step" not in trajectories
+    assert trajectories["noise"].time.shape == (1000,) and trajectories["sampling_parameters"]["number_of_samples"] == 16
+    log = (tmp_path / "samples" / "console.log").read_text()
+    assert "energies.pt is not" in log and (tmp_path / "samples" / "config_backup.yaml").exists()
