@@ -191,6 +191,14 @@ def helper_values():
     out["positive_bloch_wave_vectors"] = all(torch.equal(ref_f(n, d), own_f(n, d)) and ref_f(n, d).dtype == own_f(n, d).dtype for n in (1, 2, 3) for d in (1, 2, 3))
     ref_f, own_f = both(".utils.geometric_utils", "get_cubic_point_group_symmetries")
     out["cubic_point_group_symmetries"] = all(torch.equal(ref_f(d), own_f(d)) and ref_f(d).dtype == own_f(d).dtype for d in (1, 2, 3))
+    ref_f, own_f = both(".utils.symmetry_utils", "get_all_permutation_indices")
+    out["permutation_indices"] = all(all(torch.equal(a, b) and a.dtype == b.dtype for a, b in zip(ref_f(n), own_f(n))) for n in (1, 2, 4))
+    g0 = torch.Generator().manual_seed(5)
+    values, matrices = torch.rand(3, generator=g0), torch.rand(3, 2, 4, generator=g0)
+    ref_f, own_f = both(".utils.tensor_utils", "broadcast_batch_tensor_to_all_dimensions")
+    ref_m, own_m = both(".utils.tensor_utils", "broadcast_batch_matrix_tensor_to_all_dimensions")
+    out["tensor_utils"] = all(torch.equal(ref_f(values, shape), own_f(values, shape)) and torch.equal(ref_m(matrices, shape), own_m(matrices, shape))
+                              for shape in ((3,), (3, 5), (3, 2, 7)))
     times = torch.linspace(0.0, 1.0, 33)
     ref_f, own_f = both(".noise_schedulers.sigma_calculator", "instantiate_sigma_calculator")
     out["sigma_calculators"] = all(
