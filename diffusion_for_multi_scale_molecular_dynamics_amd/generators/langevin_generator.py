@@ -31,7 +31,7 @@ from ..namespace import AXL, CARTESIAN_FORCES, NOISE, NOISY_AXL_COMPOSITION, TIM
 from ..noise_schedulers.noise_parameters import NoiseParameters
 from ..noise_schedulers.noise_scheduler import NoiseScheduler
 from ..utils.sample_trajectory import PinnedStaging, SampleTrajectory
-from .noise_sources import DevicePhiloxNoise, RecordingNoise, ReferenceOrderNoise
+from .noise_sources import DevicePhiloxNoise, RecordingNoise, ReferenceOrderNoise, one_host_thread
 from .predictor_corrector_axl_generator import PredictorCorrectorAXLGenerator, PredictorCorrectorSamplingParameters
 from .trajectory_initializer import TrajectoryInitializer
 
@@ -175,7 +175,10 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
 
     def _draw_gumbel_sample(self, number_of_samples):
         u = self.noise_source.rand(number_of_samples, self.number_of_atoms, self.num_classes)
-        return -torch.log(-torch.log(u.clip(min=self.small_epsilon)))
+        if u.is_cuda:
+            return -torch.log(-torch.log(u.clip(min=self.small_epsilon)))
+        with one_host_thread():           # (host arithmetic of the parity mode: see noise_sources.one_host_thread)
+            return -torch.log(-torch.log(u.clip(min=self.small_epsilon)))
 
     def _draw_binary_sample(self, number_of_samples):
         return self.noise_source.rand(number_of_samples, self.number_of_atoms)

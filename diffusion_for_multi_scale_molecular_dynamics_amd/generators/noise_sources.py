@@ -14,14 +14,35 @@ from .. import kernels
 from .._hip import TAG_INIT, TAG_INIT_LATTICE
 
 
+class one_host_thread:
+    """The parity mode's host-side tensor work -- a few draws of <= 10^5 numbers per step and the Gumbel transform -- on ONE
+    thread.  torch sizes its intra-op pool by the machine's cores (128 on an MI355X host) whatever share of them the process
+    may use; every small CPU op then wakes that pool, and its spinning workers starve the thread that launches kernels: measured
+    at C3, 40.0 ms per iteration with the default pool, 34.5 with 8 threads, 32.8 with one (device-RNG mode: 31.3;
+    profiles/r05_reference_mode_rate.json).  The numbers drawn do not depend on the thread count (checked by
+    tests/test_host_cpu.py::test_host_draws_do_not_depend_on_the_thread_count).  The caller's setting is restored on exit."""
+
+    def __enter__(self):
+        self.previous = torch.get_num_threads()
+        if self.previous != 1:
+            torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        if self.previous != 1:
+            torch.set_num_threads(self.previous)
+        return False
+
+
 class ReferenceOrderNoise:
     device_rng = False
 
     def rand(self, *shape) -> torch.Tensor:
-        return torch.rand(*shape)
+        with one_host_thread():
+            return torch.rand(*shape)
 
     def randn(self, *shape) -> torch.Tensor:
-        return torch.randn(*shape)
+        with one_host_thread():
+            return torch.randn(*shape)
 
     def initial_coordinates(self, b, n, d, device):
         return self.rand(b, n, d).to(device)

@@ -629,3 +629,30 @@ def test_small_modules_under_the_reference_paths():
     noisy = torch.tensor([[2.0, 5.0, 7.0, 0.3, -0.2, 9.0]])
     assert bt.map_noisy_axl_lattice_parameters_to_unit_cell_vectors(noisy).tolist() == [[[4.0, 0, 0], [0, 5.0, 0], [0, 0, 7.0]]]
     assert noisy[0, 0] == 2.0                                                                   # the caller's tensor is not touched
+
+
+def test_host_draws_do_not_depend_on_the_thread_count():
+    """The parity mode draws on ONE host thread (generators/noise_sources.one_host_thread: the machine-sized intra-op pool costs
+    7 ms per C3 iteration): torch's CPU generator and the Gumbel transform give the same bits with 1, 2 and 8 threads, the
+    caller's thread setting is restored, and ReferenceOrderNoise consumes the global stream exactly as bare torch calls do."""
+    import torch
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.noise_sources import ReferenceOrderNoise, one_host_thread
+    before = torch.get_num_threads()
+    outs = []
+    try:
+        for n in (1, 2, 8):
+            torch.set_num_threads(n)
+            torch.manual_seed(5)
+            a, b, c = torch.randn(512, 64, 3), torch.rand(512, 64, 2), torch.randn(512, 6)
+            outs.append((a, b, c, -torch.log(-torch.log(b.clip(min=1e-8)))))
+        assert all(all(torch.equal(x, y) for x, y in zip(outs[0], other)) for other in outs[1:])
+        torch.set_num_threads(4)
+        with one_host_thread():
+            assert torch.get_num_threads() == 1
+        assert torch.get_num_threads() == 4
+        torch.manual_seed(5)
+        source = ReferenceOrderNoise()
+        drawn = (source.randn(512, 64, 3), source.rand(512, 64, 2), source.randn(512, 6))
+        assert all(torch.equal(x, y) for x, y in zip(drawn, outs[0][:3])) and torch.get_num_threads() == 4
+    finally:
+        torch.set_num_threads(before)
