@@ -14,6 +14,7 @@ from ..models.score_networks.score_network import ScoreNetwork
 from ..namespace import AXL
 from ..noise_schedulers.noise_parameters import NoiseParameters
 from .langevin_generator import LangevinGenerator
+from .noise_sources import upload
 from .predictor_corrector_axl_generator import PredictorCorrectorSamplingParameters
 from .sampling_constraint import SamplingConstraint
 from .trajectory_initializer import TrajectoryInitializer
@@ -60,8 +61,8 @@ class ConstrainedLangevinGenerator(LangevinGenerator):
         if not getattr(self.noise_source, "device_rng", False):
             self.initialize(batch, device)                     # composition_0_known: drawn, only constrained rows kept
             if d_index is None and index_i > 0:                # noising_transform.py:154,179
-                z = self.noise_source.randn(x.shape).to(device=device, dtype=torch.float32).contiguous()
-                u = self.noise_source.rand(batch, self.number_of_atoms, self.num_classes).to(device).contiguous()
+                z = upload(self.noise_source.randn(x.shape), device)
+                u = upload(self.noise_source.rand(batch, self.number_of_atoms, self.num_classes), device)
         # Philox draw id of the repaint noise: that of the predictor step it follows (index_i + 1)
         rng = self._rng(0)
         rng_index = index_i
@@ -77,8 +78,8 @@ class ConstrainedLangevinGenerator(LangevinGenerator):
         device = x.device
         z = u = None
         if not getattr(self.noise_source, "device_rng", False):
-            z = self.noise_source.randn(x.shape).to(device=device, dtype=torch.float32).contiguous()
-            u = self.noise_source.rand(x.shape[0], self.number_of_atoms, self.num_classes).to(device).contiguous()
+            z = upload(self.noise_source.randn(x.shape), device)
+            u = upload(self.noise_source.rand(x.shape[0], self.number_of_atoms, self.num_classes), device)
         kernels.forward_diffusion_step(self._prepare(device), index_i, d_index, z, u, self._rng(0), x, a)
         return AXL(A=a, X=x, L=composition.L)
 

@@ -31,7 +31,7 @@ from ..namespace import AXL, CARTESIAN_FORCES, NOISE, NOISY_AXL_COMPOSITION, TIM
 from ..noise_schedulers.noise_parameters import NoiseParameters
 from ..noise_schedulers.noise_scheduler import NoiseScheduler
 from ..utils.sample_trajectory import PinnedStaging, SampleTrajectory
-from .noise_sources import DevicePhiloxNoise, RecordingNoise, ReferenceOrderNoise, one_host_thread
+from .noise_sources import DevicePhiloxNoise, RecordingNoise, ReferenceOrderNoise, one_host_thread, upload
 from .predictor_corrector_axl_generator import PredictorCorrectorAXLGenerator, PredictorCorrectorSamplingParameters
 from .trajectory_initializer import TrajectoryInitializer
 
@@ -333,8 +333,7 @@ class LangevinGenerator(PredictorCorrectorAXLGenerator):
                         u = self._draw_binary_sample(batch)
             if self.use_fixed_lattice_parameters:
                 z_lattice = None
-            z, gumbel, u, z_lattice = [None if t is None else t.to(device=device, dtype=torch.float32).contiguous()
-                                       for t in (z, gumbel, u, z_lattice)]
+            z, gumbel, u, z_lattice = [upload(t, device) for t in (z, gumbel, u, z_lattice)]
             if not self.use_fixed_lattice_parameters and z_lattice is None:
                 raise MdxError("internal error: lattice noise missing")
 

@@ -33,6 +33,17 @@ class one_host_thread:
         return False
 
 
+def upload(draws, device):
+    """Host draws -> float32 on the device: a plain (blocking) copy from pageable memory.  The host then moves in step with the
+    GPU -- one wait per sub-step, 1.5 ms per C3 iteration against the device-RNG modes -- which is the fast way here: both
+    asynchronous forms were measured and dropped (a page-locked block per upload from torch's caching host allocator: 62.7 ms
+    per iteration; a ring of page-locked buffers allocated once, copies guarded by events: 108 ms -- the host running ahead of
+    eager launches does not suit this loop; `profiles/r05_round_notes.md`).  None stays None."""
+    if draws is None:
+        return None
+    return draws.to(device=device, dtype=torch.float32).contiguous()
+
+
 class ReferenceOrderNoise:
     device_rng = False
 
