@@ -13,6 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch sizes its intra-op pool by the machine's cores (128 on an MI355X host) whatever share of them this process may use: the
+    # CPU checkers of the suite (the oracle's torch modules) then run oversubscribed.  Sixteen threads = a one-GPU box's share.
+    import torch
+    if torch.get_num_threads() > 16:
+        torch.set_num_threads(16)
 
 
 def load_golden(name):
