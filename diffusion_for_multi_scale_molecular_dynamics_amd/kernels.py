@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 
 from . import _hip
-from ._hip import MDX_CORRECTOR, MDX_PREDICTOR, Mlp, PcFlags, Rng, Schedule, check, lib, ptr, stream_handle
+from ._hip import Mlp, PcFlags, Rng, Schedule, check, lib, ptr, stream_handle
 
 F32, I64, I32 = torch.float32, torch.int64, torch.int32
 

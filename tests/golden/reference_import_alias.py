@@ -8,7 +8,6 @@ the run would have tested the reference, not this package)."""
 import importlib
 import importlib.abc
 import importlib.util
-import os
 import sys
 import types
 

@@ -1,5 +1,5 @@
 """Achieved HBM GB/s of the hand-written kernels at sizes large enough to leave the launch-latency regime."""
-import sys, json
+import sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import torch
 import bench
