@@ -1,4 +1,6 @@
 """The hand-written MFMA edge-chain kernel (csrc/mdx_egnn_chain.hip) against fp64 references, through the C ABI."""
+import os
+
 import numpy as np
 import math
 
@@ -1365,3 +1367,77 @@ def test_edge_chain_attention_gate_against_fp64(cuda, precision, H, n_msg, n_crd
     # rows mode + attention: refused, not silently ungated
     with pytest.raises(_hip.MdxError):
         kernels.egnn_edge_chain(pack, proj, coord_d, edges_d, piece_sums=False)
+
+
+EGNN_FUZZ = max(1, int(os.environ.get("MDX_FUZZ", "1")))
+
+
+@pytest.mark.parametrize("seed", range(24 * EGNN_FUZZ))
+def test_random_egnn_configurations_gpu_against_the_cpu_module(cuda, seed):
+    """Seeded random EGNNScoreNetwork configurations -- 1 - 3 spatial dimensions, 1 - 3 graph layers, message / coordinate / node
+    widths 8 ... 256 (equal or not: the chain's zero-padding), 1 - 4 hidden layers each, every combination of attention / tanh /
+    normalize / residual, sum or mean aggregations, fully connected or radial-cutoff graphs, 1 - 3 atom types, 2 - 40 atoms -- on
+    the HIP path in the exact-f32 and the split-f16 arithmetic against THIS package's module evaluated in binary64 on the CPU
+    (the module the reference-made fixtures pin: net_egnn_variants, net_egnn_options_wide, low_dimensions; its radial graphs from
+    the oracle's edge list).  Scores within max(2e-5, 3 x floor) rel-L2 of the binary64 answer, floor = the same module in
+    binary32 on the CPU against its binary64 self (what binary32 costs this random-init network); logits close."""
+    import warnings
+    from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import (
+        EGNNScoreNetwork, EGNNScoreNetworkParameters)
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE, NOISY_AXL_COMPOSITION,
+                                                                              TIME)
+    rng = np.random.default_rng(9000 + seed)
+    d = int(rng.choice([1, 2, 3], p=[0.2, 0.2, 0.6]))
+    nat = int(rng.integers(1, 4))
+    equal = bool(rng.random() < 0.5)
+    widths = [int(rng.choice([8, 16, 32, 48, 64, 96, 128, 256]))] * 3 if equal else [int(rng.choice([8, 16, 32, 48, 64, 128])) for _ in range(3)]
+    radial = bool(rng.random() < 0.6)
+    rc = float(rng.uniform(2.5, 4.0))
+    p = EGNNScoreNetworkParameters(
+        spatial_dimension=d, num_atom_types=nat, n_layers=int(rng.integers(1, 4)),
+        message_hidden_dimensions_size=widths[0], message_n_hidden_dimensions=int(rng.integers(1, 5)),
+        coordinate_hidden_dimensions_size=widths[1], coordinate_n_hidden_dimensions=int(rng.integers(1, 5)),
+        node_hidden_dimensions_size=widths[2], node_n_hidden_dimensions=int(rng.integers(1, 5)),
+        attention=bool(rng.random() < 0.5), tanh=bool(rng.random() < 0.5), normalize=bool(rng.random() < 0.5),
+        residual=bool(rng.random() < 0.7), coords_agg=str(rng.choice(["mean", "sum"])), message_agg=str(rng.choice(["mean", "sum"])),
+        edges="radial_cutoff" if radial else "fully_connected", radial_cutoff=rc if radial else None)
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = EGNNScoreNetwork(p).eval()
+    B, N = int(rng.integers(1, 6)), int(rng.integers(2, 41))
+    g = torch.Generator().manual_seed(seed)
+    lengths = torch.rand(B, d, generator=g) * 4.0 + 2.2 * rc + 0.5           # cells the radial graph accepts (> 2.2 x cutoff)
+    L = torch.cat([lengths, torch.zeros(B, d * (d + 1) // 2 - d)], dim=1)
+    batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.randint(0, nat + 1, (B, N), generator=g), X=torch.rand(B, N, d, generator=g), L=L),
+             TIME: torch.rand(B, 1, generator=g), NOISE: torch.rand(B, 1, generator=g) * 0.2 + 0.01,
+             CARTESIAN_FORCES: torch.zeros(B, N, d)}
+    with torch.no_grad():
+        # the CPU module takes the oracle's edge list (this package's radius graph is the HIP kernel: no host tensors)
+        builder = nets.oracle_edge_builder if radial else None
+        net64 = EGNNScoreNetwork(p, edge_builder=builder).eval()
+        net64.load_state_dict(net.state_dict())
+        net32 = EGNNScoreNetwork(p, edge_builder=builder).eval()
+        net32.load_state_dict(net.state_dict())
+        net64 = net64.double()
+        batch64 = {k: (AXL(A=v.A, X=v.X.double(), L=v.L.double()) if k == NOISY_AXL_COMPOSITION else v.double()) for k, v in batch.items()}
+        want = net64(batch64, conditional=False)
+        scale = float(want.X.norm())
+        # what binary32 arithmetic costs THIS random network: the same module in float32 on the CPU against its binary64 self
+        floor = float((net32(batch, conditional=False).X.double() - want.X).norm()) / max(scale, 1e-30)
+        net = net.to(cuda)
+        on_device = {k: (AXL(*[t.to(cuda) for t in v]) if k == NOISY_AXL_COMPOSITION else v.to(cuda)) for k, v in batch.items()}
+        for precision in ("f32", "f16x3"):
+            net.edge_chain_precision = precision
+            got = net(on_device, conditional=False)
+            net.check_status()
+            err = float((got.X.cpu().double() - want.X).norm()) / max(scale, 1e-30)
+            assert err < max(2e-5, 3.0 * floor), (seed, precision, err, floor, p)
+            finite = torch.isfinite(want.A)
+            assert torch.allclose(got.A.cpu().double()[finite], want.A[finite], rtol=2e-4, atol=2e-5), (seed, precision)
+            assert torch.equal(torch.isfinite(got.A.cpu()), finite)
+            # where the fused edge chain applies (widths up to 256, at most eight layers, an attention gate that fits) it RAN
+            fused = [layer._edge_chain_pack() is not None for layer in net.egnn.graph_layers]
+            assert all(layer._chain[1] is not None and layer._chain[1].precision == precision
+                       for layer, ok in zip(net.egnn.graph_layers, fused) if ok)
+        print(f"FUSED {sum(fused)} of {len(fused)} layers; widths {widths}; d {d}; radial {radial}")
