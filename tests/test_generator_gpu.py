@@ -1577,6 +1577,61 @@ def test_sampler_around_egnn_options_graph_eager_and_oracle(cuda, kind):
     assert torus_rel_l2(outs[True].X, ora.X) < 1e-5
 
 
+@pytest.mark.parametrize("seed", range(8 * FUZZ))
+def test_sampler_around_random_egnn_configurations_graph_equals_eager(cuda, seed):
+    """The sampler around seeded random EGNN configurations (1 - 3 dimensions, 1 - 2 graph layers, widths 16 ... 128 equal or not,
+    every option combination, both graph kinds, 1 - 2 atom types, 0 - 2 correctors, random update flags), device Philox, four time
+    indices: the iteration replayed from a hipGraph equals the eager launches BIT FOR BIT, the CPU oracle's run of the same
+    Philox specification around the same module agrees (atom types exact wherever the logits are not within rounding of a tie:
+    checked through the coordinates' <= 1e-4 torus distance and the fraction of equal types), every layer on the fused chain."""
+    import warnings
+    from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import (
+        EGNNScoreNetwork, EGNNScoreNetworkParameters)
+    P = _pkg()
+    rng = np.random.default_rng(7000 + seed)
+    d = int(rng.choice([1, 2, 3], p=[0.2, 0.2, 0.6]))
+    nat = int(rng.integers(1, 3))
+    widths = [int(rng.choice([16, 32, 64, 128]))] * 3 if rng.random() < 0.5 else [int(rng.choice([16, 32, 48, 64])) for _ in range(3)]
+    radial = bool(rng.random() < 0.6)
+    rc = float(rng.uniform(2.5, 3.5))
+    p = EGNNScoreNetworkParameters(
+        spatial_dimension=d, num_atom_types=nat, n_layers=int(rng.integers(1, 3)),
+        message_hidden_dimensions_size=widths[0], message_n_hidden_dimensions=int(rng.integers(1, 4)),
+        coordinate_hidden_dimensions_size=widths[1], coordinate_n_hidden_dimensions=int(rng.integers(1, 4)),
+        node_hidden_dimensions_size=widths[2], node_n_hidden_dimensions=int(rng.integers(1, 4)),
+        attention=bool(rng.random() < 0.5), tanh=bool(rng.random() < 0.5), normalize=bool(rng.random() < 0.5),
+        residual=bool(rng.random() < 0.7), coords_agg=str(rng.choice(["mean", "sum"])), message_agg=str(rng.choice(["mean", "sum"])),
+        edges="radial_cutoff" if radial else "fully_connected", radial_cutoff=rc if radial else None)
+    N, batch = int(rng.integers(2, 25)), int(rng.integers(1, 5))
+    cell = [float(v) for v in rng.uniform(2.2 * rc + 0.5, 2.2 * rc + 4.0, d)]
+    skw = cases.sampling_ns(N, nat, M=int(rng.integers(0, 3)), greedy=bool(rng.random() < 0.5), one=bool(rng.random() < 0.5),
+                            in_corr=bool(rng.random() < 0.3), cell=cell, d=d)
+    nkw = cases.noise_ns(4, **cases.LIN)
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net_cpu = EGNNScoreNetwork(p, edge_builder=nets.oracle_edge_builder if radial else None).eval()
+    outs = {}
+    for use_graph in (False, True):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net = EGNNScoreNetwork(p).eval()
+            net.load_state_dict(net_cpu.state_dict())
+            npar, spar = P["Noise"](**nkw), P["Sampling"](**skw, rng_mode="device", seed=5 + seed, use_hip_graph=use_graph)
+            gen = P["Langevin"](npar, spar, net.to(cuda))
+            with torch.no_grad():
+                outs[use_graph] = _np(gen.sample(batch, cuda))
+        assert all(layer._chain[1] is not None for layer in net.egnn.graph_layers), ("the fused edge chain did not run", p)
+    assert np.array_equal(outs[False].A, outs[True].A), p
+    assert np.array_equal(outs[False].X.view(np.int32), outs[True].X.view(np.int32)), p
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ora = RS.OracleLangevinGenerator(npar, spar, net_cpu, noise=RS.PhiloxNoise(5 + seed, 0)).sample(batch)
+    assert (ora.A != nat).all() and (outs[True].A != nat).all()
+    assert torus_rel_l2(outs[True].X, ora.X) < 1e-4, (torus_rel_l2(outs[True].X, ora.X), p)
+    assert (outs[True].A == ora.A).mean() > 0.9, p
+
+
 def test_use_hip_graph_with_a_network_that_cannot_be_captured_runs_eagerly(cuda):
     """`use_hip_graph: true` around a score network whose forward needs a host read -- an EGNN with a radius graph whose layer
     width (288) is beyond the fused edge chain's widths, so the edge list is sized after reading the edge count -- used to die inside
