@@ -483,7 +483,13 @@ def test_egnn_radius_graph_forms_on_random_shapes_and_small_cells(cuda):
         N = int(torch.randint(1, 300, (1,), generator=g))
         rc = float(torch.rand(1, generator=g)) * 3.0 + 1.5
         clip = rc * (2.2 if case % 2 == 0 else float(torch.rand(1, generator=g)) * 1.6 + 0.7)        # 0.7 .. 2.3 x cutoff
-        x = torch.rand(B, N, 3, generator=g).to(cuda)
+        x = torch.rand(B, N, 3, generator=g)
+        if case % 5 == 3:           # coordinates outside [0, 1), coincident atoms, a NaN and an infinity: the same edges either way
+            x = x * 3.0 - 1.0
+            x[0, -1] = x[0, 0]
+            if N > 3:
+                x[-1, 1, 0], x[-1, 2, 2] = float("nan"), float("inf")
+        x = x.to(cuda)
         lattice = torch.cat([torch.rand(B, 3, generator=g) * 8.0 + 2.0, torch.zeros(B, 3)], dim=1).to(cuda)
         cell = torch.diag_embed(lattice[:, :3].clip(min=clip)).contiguous()
         cart = torch.matmul(x, cell).contiguous()
