@@ -1447,3 +1447,50 @@ def test_random_egnn_configurations_gpu_against_the_cpu_module(cuda, seed):
             assert all(layer._chain[1] is not None and layer._chain[1].precision == precision
                        for layer, ok in zip(net.egnn.graph_layers, fused) if ok)
         print(f"FUSED {sum(fused)} of {len(fused)} layers; widths {widths}; d {d}; radial {radial}")
+
+
+@pytest.mark.parametrize("name,N,B,edges,rc", [("one_atom_fully_connected", 1, 3, "fully_connected", None), ("one_atom_radial", 1, 3, "radial_cutoff", 2.0),
+                                               ("no_pair_within_the_cutoff", 4, 2, "radial_cutoff", 0.05), ("two_atoms_one_structure", 2, 1, "radial_cutoff", 2.5)])
+def test_egnn_on_graphs_without_edges(cuda, name, N, B, edges, rc):
+    """Degenerate graphs -- a single atom, no pair within the cutoff, one structure of two atoms: the forward is finite (an atom
+    without neighbours is not moved by the EGNN: its score is exactly zero), and the sampler around it runs, the hipGraph replay
+    equal to the eager launches bit for bit, every atom unmasked at the end."""
+    import warnings
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.langevin_generator import LangevinGenerator
+    from diffusion_for_multi_scale_molecular_dynamics_amd.generators.predictor_corrector_axl_generator import \
+        PredictorCorrectorSamplingParameters
+    from diffusion_for_multi_scale_molecular_dynamics_amd.models.score_networks.egnn_score_network import (
+        EGNNScoreNetwork, EGNNScoreNetworkParameters)
+    from diffusion_for_multi_scale_molecular_dynamics_amd.namespace import (AXL, CARTESIAN_FORCES, NOISE, NOISY_AXL_COMPOSITION,
+                                                                              TIME)
+    from diffusion_for_multi_scale_molecular_dynamics_amd.noise_schedulers.noise_parameters import NoiseParameters
+    p = EGNNScoreNetworkParameters(num_atom_types=1, n_layers=2, coordinate_hidden_dimensions_size=32, coordinate_n_hidden_dimensions=2,
+                                   message_hidden_dimensions_size=32, message_n_hidden_dimensions=2, node_hidden_dimensions_size=32,
+                                   node_n_hidden_dimensions=2, edges=edges, radial_cutoff=rc)
+    torch.manual_seed(1)
+    net = EGNNScoreNetwork(p).eval().to(cuda)
+    g = torch.Generator().manual_seed(2)
+    batch = {NOISY_AXL_COMPOSITION: AXL(A=torch.zeros(B, N, dtype=torch.long, device=cuda), X=torch.rand(B, N, 3, generator=g).to(cuda),
+                                        L=torch.tensor([6.0, 6.0, 6.0, 0, 0, 0.0]).repeat(B, 1).to(cuda)),
+             TIME: torch.rand(B, 1, generator=g).to(cuda), NOISE: (torch.rand(B, 1, generator=g) * 0.2).to(cuda),
+             CARTESIAN_FORCES: torch.zeros(B, N, 3, device=cuda)}
+    with torch.no_grad():
+        out = net(batch, conditional=False)
+    net.check_status()
+    assert out.X.shape == (B, N, 3) and torch.isfinite(out.X).all() and torch.isfinite(out.A[..., :-1]).all()
+    if name != "two_atoms_one_structure":
+        assert float(out.X.abs().max()) == 0.0
+    else:
+        assert float(out.X.norm()) > 0.0
+    results = {}
+    for use_graph in (False, True):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            spar = PredictorCorrectorSamplingParameters(number_of_atoms=N, num_atom_types=1, number_of_samples=B, number_of_corrector_steps=1,
+                                                        use_fixed_lattice_parameters=True, cell_dimensions=[6.0] * 3, rng_mode="device",
+                                                        seed=3, use_hip_graph=use_graph)
+            gen = LangevinGenerator(NoiseParameters(total_time_steps=3, sigma_min=1e-4, sigma_max=0.2, schedule_type="linear"), spar, net)
+            with torch.no_grad():
+                results[use_graph] = gen.sample(B, cuda)
+    assert torch.equal(results[False].X, results[True].X) and torch.equal(results[False].A, results[True].A)
+    assert (results[True].A == 0).all() and ((results[True].X >= 0) & (results[True].X < 1)).all()
