@@ -120,6 +120,10 @@ def main(args: Optional[Any] = None, axl_network: Optional[ScoreNetwork] = None)
     noise_parameters, sampling_parameters = extract_and_validate_parameters(hyper_params)
     if "elements" in hyper_params:
         ElementTypes.validate_elements(hyper_params["elements"])
+    if getattr(sampling_parameters, "rng_mode", "reference") == "reference":
+        logger.info("Sampling in the reference's mode (draws from torch's CPU generator in the reference's order, uploaded every step, "
+                    "eager launches: reproduces the reference's run for a given torch.manual_seed).  `rng_mode: device` and "
+                    "`use_hip_graph: true` in the `sampling:` block select the throughput modes (INTEGRATION.md).")
     if "oracle" in hyper_params:
         logger.warning("The configuration has an `oracle:` block: the energy oracle (LAMMPS) is outside this package's scope; "
                        "samples.pt is written, energies.pt is not.")
